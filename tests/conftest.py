@@ -1,0 +1,49 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tiny_meta():
+    with open(os.path.join(GOLD, "tiny_meta.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def tiny_gold():
+    return dict(np.load(os.path.join(GOLD, "tiny_fp32.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def tiny_gold_bf16():
+    return dict(np.load(os.path.join(GOLD, "tiny_bf16.npz"), allow_pickle=False))
+
+
+def tiny_batch(gold, meta):
+    return {
+        "input_ids": torch.from_numpy(gold["in/input_ids"]),
+        "labels": torch.from_numpy(gold["in/labels"]),
+        "attention_mask": torch.from_numpy(gold["in/attention_mask"]),
+        "omic_ids": torch.from_numpy(gold["in/omic_ids"]),
+        "omic_info_list": meta["omic_info_list"],
+    }
+
+
+def tiny_state_dict(meta, dtype=torch.float32):
+    from molly_amd.synth import synth_state_dict
+    shapes = {k: tuple(v) for k, v in meta["state_dict_shapes"].items()}
+    sd = synth_state_dict(shapes, meta["config"]["seed_w"])
+    return {k: v.to(dtype) for k, v in sd.items()}

@@ -1,0 +1,80 @@
+"""CPU: the oracle (oracle/molly_ref.py) against golden vectors produced by the REFERENCE's OmicsOne
+over HF modules (tests/golden/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import tiny_batch, tiny_state_dict
+from oracle import molly_ref as R
+
+
+def _setup(meta, gold, grad=False):
+    llm, dna, prot = R.cfgs_from_meta(meta["config"])
+    sd = tiny_state_dict(meta)
+    if grad:
+        for k, v in sd.items():
+            if k.startswith("model.") or "projector" in k:
+                v.requires_grad_(True)
+        sd["model.lm_head.weight"] = sd["model.model.embed_tokens.weight"]
+    K = meta["config"]["K"]
+    return sd, llm, dna, prot, tiny_batch(gold, meta), {"dna_rna": K, "protein": K}
+
+
+def test_forward_matches_reference(tiny_meta, tiny_gold):
+    sd, llm, dna, prot, batch, kt = _setup(tiny_meta, tiny_gold)
+    col = {}
+    with torch.no_grad():
+        loss, logits = R.omics_forward(sd, llm, dna, prot, batch, kt, collect=col)
+    g = tiny_gold
+    np.testing.assert_allclose(col["enc"]["protein"].numpy(), g["fwd/enc_protein"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(col["enc"]["dna_rna"].numpy(), g["fwd/enc_dna_rna"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(col["inputs_embeds"].numpy(), g["fwd/inputs_embeds"], rtol=0, atol=1e-5)
+    for i, h in enumerate(col["layers"]):
+        np.testing.assert_allclose(h.numpy(), g[f"fwd/layer{i}"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(col["final_hidden"].numpy(), g["fwd/final_hidden"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(logits.numpy()[:, ::2], g["fwd/logits"], rtol=0, atol=5e-5)
+    assert abs(loss.item() - float(g["fwd/loss"])) < 1e-5
+
+
+def test_backward_and_adamw_match_reference(tiny_meta, tiny_gold):
+    sd, llm, dna, prot, batch, kt = _setup(tiny_meta, tiny_gold, grad=True)
+    loss, _ = R.omics_forward(sd, llm, dna, prot, batch, kt)
+    loss.backward()
+    g = tiny_gold
+    names = [k[len("gnorm/"):] for k in g if k.startswith("gnorm/")]
+    assert names, "fixture has no grads"
+    params = {}
+    for n in names:
+        p = sd[n]
+        assert p.grad is not None, n
+        params[n] = p
+        ref = float(g["gnorm/" + n])
+        got = p.grad.double().norm().item()
+        assert abs(got - ref) <= 1e-4 * max(ref, 1e-6) + 1e-7, (n, got, ref)
+        np.testing.assert_allclose(p.grad.flatten()[:256].numpy(), g["ghead/" + n], rtol=0,
+                                   atol=2e-6 + 1e-4 * np.abs(g["ghead/" + n]).max())
+    # one clipped AdamW step with HF's decay/no-decay split
+    total, coef = R.clip_coef([p.grad for p in params.values()], 1.0)
+    assert abs(total.item() - float(g["opt/grad_norm"])) < 1e-4
+    nd = set(g["opt/no_decay"].tolist())
+    with torch.no_grad():
+        for n, p in params.items():
+            assert R.is_no_decay(n) == (n in nd), n
+            gr = p.grad * coef
+            m = torch.zeros_like(p)
+            v = torch.zeros_like(p)
+            R.adamw_step(p, gr, m, v, 1, float(g["opt/lr"]), 0.0 if R.is_no_decay(n) else 1e-2)
+            np.testing.assert_allclose(p.flatten()[:256].numpy(), g["opt/phead/" + n], rtol=0, atol=1e-7)
+            assert abs(p.double().norm().item() - float(g["opt/pnorm/" + n])) < 1e-5
+        loss2, _ = R.omics_forward(sd, llm, dna, prot, batch, kt)
+    assert abs(loss2.item() - float(g["opt/loss_after"])) < 1e-5
+
+
+def test_index_outputs_bit_exact():
+    ids = torch.tensor([[3, 5, 6, 1, 1], [1, 4, 1, 7, 8]])
+    assert R.esm_position_ids(ids, 1).tolist() == [[2, 3, 4, 1, 1], [1, 2, 1, 3, 4]]
+
+
+def test_group_omics_errors():
+    with pytest.raises(ValueError):
+        R.group_omics([[torch.ones(4, dtype=torch.long)]], [[{"type": "lipid", "start": 3}]])
