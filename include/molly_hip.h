@@ -1,0 +1,136 @@
+/* molly_hip.h — C ABI of the MI355X (gfx950) hot-path library `libmolly_hip.so`.
+ *
+ * The reference (SeedLLM/molly) has no FFI of its own: its hot path is the Python nn.Module surface of
+ * `OmicsOne` (reference: src/model/omics_one.py:10-233) whose arithmetic executes inside HuggingFace
+ * transformers / Liger / flash-attn / DeepSpeed CUDA kernels.  This header is the boundary a maintainer
+ * binds instead of those kernels (ctypes stub: INTEGRATION.md).  Each entry point names the reference /
+ * third-party op it replaces ("HF:" = transformers/, pinned 4.53.0 in reference requirements.txt:21).
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is DEVICE memory unless named `h_*`;
+ *  - `stream` is a hipStream_t (0 = default stream); all work is asynchronous on it; no allocation,
+ *    no synchronisation inside (graph-capture safe);
+ *  - bf16 tensors are uint16 storage, row-major, innermost dimension contiguous; `ld*` are in ELEMENTS;
+ *  - return 0 on success; non-zero on a rejected argument or launch failure, message via
+ *    molly_last_error() (thread-local).  Nothing is silently ignored.
+ */
+#ifndef MOLLY_HIP_H
+#define MOLLY_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* molly_last_error(void);
+int molly_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = A[M,K] · B[N,K]^T (+bias[N]) (GELU) (+res[M,N]) (+= C)
+ * replaces: every nn.Linear on the path — Qwen3 q/k/v/o/gate/up/down/lm_head (HF:models/qwen3/
+ * modeling_qwen3.py:76-83,225-236,495), ESM query/key/value/dense (HF:models/esm/modeling_esm.py:336-338,
+ * 402,445,456), Molly's projectors (reference src/model/omics_one.py:23-29,91); the dgrad/wgrad GEMMs that
+ * autograd issues for them; erf-GELU epilogue = HF:models/esm/modeling_esm.py:82-86.
+ * K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, 16-byte aligned bases. */
+enum {
+    MOLLY_GEMM_BIAS = 1,        /* + bias[n] (bf16)                              */
+    MOLLY_GEMM_GELU = 2,        /* exact erf GELU after bias                      */
+    MOLLY_GEMM_RESIDUAL = 4,    /* + res[m,n] (bf16, ldres)                       */
+    MOLLY_GEMM_ACCUMULATE = 8,  /* C += result (same dtype as C)                  */
+    MOLLY_GEMM_OUT_F32 = 16     /* C is fp32 instead of bf16                      */
+};
+int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
+                       int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags);
+
+/* out[C,R] = in[R,C]^T (bf16).  Used to keep W^T copies for dgrad and X^T / dY^T for wgrad. */
+int molly_transpose_bf16(void* stream, const void* in, void* out, int R, int C, int ld_in, int ld_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * RMSNorm — HF:models/qwen3/modeling_qwen3.py:59-64 (Liger rms_norm when --use_liger, reference
+ * src/train.py:130-132): y = w * bf16(x * rsqrt(mean(x^2) + eps)).  H % 8 == 0, H <= 4096.
+ * bwd: dx = norm-backward(g) (+ dres, the residual-branch gradient, fused); dw (+)= sum_rows g*xhat, reduced
+ * deterministically through `workspace` (molly_rmsnorm_bwd_blocks(rows) * H floats). */
+int molly_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* rstd_or_null, int rows, int H, float eps);
+int molly_rmsnorm_bwd_blocks(int rows);
+int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres_or_null, void* dx,
+                      void* dw, int dw_f32, int dw_accumulate, float* workspace, int rows, int H, float eps);
+
+/* per-head RMSNorm (optional) + q pre-scale (optional) + rotary (optional) over the q|k heads of a fused
+ * projection buffer.  Qwen3: q_norm/k_norm then RoPE — HF:models/qwen3/modeling_qwen3.py:252-257,148-170.
+ * ESM-2: q *= hd^-0.5 then fp32 rotary, no norm — HF:models/esm/modeling_esm.py:374-378,56-79.
+ * src[M, ld_src] holds n_q_heads then n_k_heads heads of head_dim; dst likewise; cos/sin fp32 [n_pos, head_dim/2];
+ * positions int32 [M] or NULL (= m %% T, i.e. arange(T) per sample: HF:qwen3:386-389). */
+int molly_norm_rope_fwd(void* stream, const void* src, void* dst, const void* q_norm_w, const void* k_norm_w,
+                        const float* cos, const float* sin, const int* positions, int M, int T, int n_q_heads,
+                        int n_k_heads, int head_dim, int ld_src, int ld_dst, float eps, float q_scale);
+int molly_norm_rope_bwd_blocks(void);
+int molly_norm_rope_bwd(void* stream, const void* src, const void* g, void* dsrc, const void* q_norm_w,
+                        const void* k_norm_w, const float* cos, const float* sin, const int* positions, void* dq_w,
+                        void* dk_w, int dw_f32, int dw_accumulate, float* workspace, int M, int T, int n_q_heads,
+                        int n_k_heads, int head_dim, int ld_src, int ld_g, int ld_out, float eps);
+
+/* SwiGLU — HF:models/qwen3/modeling_qwen3.py:82 (Liger swiglu): out = silu(gate) * up, gate_up = [gate | up] per row. */
+int molly_swiglu_fwd(void* stream, const void* gate_up, void* out, long rows, int ff);
+int molly_swiglu_bwd(void* stream, const void* gate_up, const void* dout, void* dgate_up, long rows, int ff);
+
+/* row gather/scatter: dst[dst_idx[i] | i] (+)= src[src_idx[i] | i]; negative index skips the row.
+ * embedding lookup = reference src/model/omics_one.py:164 (int64 ids as src_idx64);
+ * omic injection hs[b, start+1 : start+1+k] = emb[i, :k] = reference src/model/omics_one.py:93-97 (dst_idx32). */
+int molly_copy_rows(void* stream, const void* src, const int64_t* src_idx64, const int* src_idx32, void* dst,
+                    const int* dst_idx32, long n, int H, int ld_src, int ld_dst, int accumulate);
+/* embedding backward through a sorted index: for unique id u, dE[uid[u]] += sum_k g[order[k]],
+ * k in [seg_start[u], seg_start[u+1]); uid < 0 skips.  Deterministic (no atomics). */
+int molly_embed_bwd(void* stream, const void* g, const int* order, const int* seg_start, const int64_t* uid,
+                    int n_unique, void* dE, int H, int ld_g);
+
+/* cross-entropy on bf16 logits, in place -> d(logits) — HF:loss/loss_utils.py:32-71 (ForCausalLMLoss; Liger
+ * fused-linear-CE when --use_liger).  `labels` are already shifted (row r is scored against labels[r]);
+ * rows with ignore_index get zero loss/grad.  dlogits = (softmax - onehot) * (*scale). */
+int molly_count_valid(void* stream, const int64_t* labels, long n, int ignore_index, float* scale_out, float* count_out);
+int molly_ce_fwd_bwd(void* stream, void* logits, const int64_t* labels, float* row_loss, const float* scale, int rows,
+                     int V, int ld, int ignore_index, int write_grad);
+int molly_sum_f32(void* stream, const float* x, long n, const float* scale_or_null, float* out, int accumulate);
+
+/* LayerNorm forward (affine, eps 1e-5) — ESM pre-LN blocks and emb_layer_norm_after: HF:models/esm/
+ * modeling_esm.py:429,518,552. */
+int molly_layernorm_fwd(void* stream, const void* x, const void* w, const void* b, void* y, int rows, int H, float eps);
+
+/* ESM embeddings — HF:models/esm/modeling_esm.py:224-271 (+ position ids :1050-1063): word embedding,
+ * token-dropout rescale, optional learned absolute positions (pos_emb NULL for rotary models), x mask.
+ * Also emits the int32 position ids and per-sequence valid key length (last non-pad index + 1). */
+int molly_esm_embed(void* stream, const int64_t* ids, const void* word_emb, const void* pos_emb_or_null, void* out,
+                    int* pos_ids_out_or_null, int* kv_len_out_or_null, int n_seq, int K, int H, int pad_id, int mask_id,
+                    int token_dropout);
+
+/* optimizer shard step — torch.optim.AdamW (HF `adamw_torch`, reference src/trainer/omics_trainer.py:53-60) on an
+ * fp32 master shard with bf16 grads; global-norm clip = torch.nn.utils.clip_grad_norm_ (reference
+ * src/trainer/domain_loss.py:676-708; DeepSpeed gradient_clipping, src/configs/ds_z2_config.json:5). */
+int molly_sqnorm_blocks(void);
+int molly_sqnorm_bf16(void* stream, const void* g, long n, float* workspace, float* out, int accumulate);
+int molly_clip_coef(void* stream, const float* norm_sq, float max_norm, float pre_scale, float* norm_out, float* coef_out);
+int molly_adamw_step(void* stream, float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* param_out,
+                     long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     const float* grad_scale_or_null);
+int molly_cast_f32_to_bf16(void* stream, const float* in, void* out, long n);
+int molly_cast_bf16_to_f32(void* stream, const void* in, float* out, long n);
+
+/* ------------------------------------------------------------------------------------------------
+ * flash attention — replaces FlashAttention-2 / SDPA / eager attention chosen by --attn_impl (reference
+ * src/train.py:578-582): Qwen3 causal GQA hd=128 (HF:models/qwen3/modeling_qwen3.py:185-208) and ESM
+ * bidirectional hd=64 with key-padding mask (HF:models/esm/modeling_esm.py:292-317).
+ * Q/K/V/O are token-major: row (b*T + t) with row stride ld*, head h at column h*head_dim.
+ * mask = (causal ? key <= query : all) AND kv_lo[b] <= key < kv_hi[b]  (NULL = whole sequence).
+ * lse2[B, n_heads, T] = log2-domain log-sum-exp of the scaled scores (saved for the backward). */
+int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2, const int* kv_lo,
+                   const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv,
+                   int ldo, float scale, int causal);
+
+/* ------------------------------------------------------------------------------------------------
+ * layout / instruction probes (used by tests/test_gpu_probes.py to pin the gfx950 operand maps the
+ * kernels rely on; not part of the product path) */
+int molly_probe_mfma16(void* stream, const void* A16x32, const void* B16x32, float* D16x16);
+int molly_probe_tr16(void* stream, const void* tile_in, void* lanes_out /* [64][4] u16 */, int row_stride_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,937 @@
+// HBM-bound kernels of Molly's hot path (gfx950): norms, rotary, SwiGLU, embedding gather/scatter,
+// cross-entropy, transposes, AdamW.  All of them stream bf16 as 16-byte vectors (guide G13), keep the
+// math in fp32 and touch every byte once (or state why not).  Roofline for each: HBM (~6.3 TB/s achievable).
+#include "common.h"
+#include "molly_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// transpose: out[C,R] = in[R,C]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R,
+                                                        int C, int ld_in, int ld_out) {
+    __shared__ bf16_t tile[64][66];   // +2 pad: conflict-light column reads
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(size_t)r * ld_in + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (HF:models/qwen3/modeling_qwen3.py:59-64): y = w * bf16(x * rsqrt(mean(x^2)+eps))
+// one wave per row, 4 rows per block; row kept in registers (H <= 8192)
+// ------------------------------------------------------------------------------------------------
+constexpr int RN_MAXC = 8;   // 8 chunks * 64 lanes * 8 elems = 4096 (Qwen3-8B hidden size)
+
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd_out, int rows,
+                                                          int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = H >> 3;
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)row * H);
+    u32x4 v[NC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = xr[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bflo(v[i][e]), b = bfhi(v[i][e]);
+                ss += a * a + b * b;
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    if (rstd_out && lane == 0) rstd_out[row] = rstd;
+    const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+    u32x4* yr = reinterpret_cast<u32x4*>(y + (size_t)row * H);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const u32x4 wv = wr[c];
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // HF rounds the normalised value to bf16 BEFORE the gain multiply
+                const uint32_t t = pack_bf2(bflo(v[i][e]) * rstd, bfhi(v[i][e]) * rstd);
+                o[e] = pack_bf2(bflo(t) * bflo(wv[e]), bfhi(t) * bfhi(wv[e]));
+            }
+            yr[c] = o;
+        }
+    }
+}
+
+// backward: dx = rstd*(g*w - xhat*mean(g*w*xhat)) (+dres) ; dw partial per block (fp32) -> workspace[nblk][H]
+// persistent over rows: block b handles rows b*4+wave, stride gridDim*4
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          const bf16_t* __restrict__ g, const bf16_t* __restrict__ dres,
+                                                          bf16_t* __restrict__ dx, float* __restrict__ dw_part, int rows,
+                                                          int H, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    float* sdw = reinterpret_cast<float*>(sm_raw);   // [4][H] would be big; instead waves accumulate in regs
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = H >> 3;
+    float dwacc[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[i][e] = 0.f;
+    const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)row * H);
+        const u32x4* gr = reinterpret_cast<const u32x4*>(g + (size_t)row * H);
+        u32x4 xv[NC], gv[NC];
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                xv[i] = xr[c];
+                gv[i] = gr[c];
+                const u32x4 wv = wr[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = bflo(xv[i][e]), b = bfhi(xv[i][e]);
+                    ss += a * a + b * b;
+                    dot += bflo(gv[i][e]) * bflo(wv[e]) * a + bfhi(gv[i][e]) * bfhi(wv[e]) * b;
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        dot = wave_sum(dot);
+        const float rstd = rsqrtf(ss / (float)H + eps);
+        const float coef = dot * rstd * rstd * rstd / (float)H;   // mean(g*w*xhat)*rstd, xhat = x*rstd
+        u32x4* dxr = reinterpret_cast<u32x4*>(dx + (size_t)row * H);
+        const u32x4* rr = dres ? reinterpret_cast<const u32x4*>(dres + (size_t)row * H) : nullptr;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                const u32x4 wv = wr[c];
+                u32x4 rv = u32x4{0, 0, 0, 0};
+                if (rr) rv = rr[c];
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xa = bflo(xv[i][e]), xb = bfhi(xv[i][e]);
+                    const float ga = bflo(gv[i][e]), gb = bfhi(gv[i][e]);
+                    float da = ga * bflo(wv[e]) * rstd - xa * coef;
+                    float db = gb * bfhi(wv[e]) * rstd - xb * coef;
+                    if (rr) { da += bflo(rv[e]); db += bfhi(rv[e]); }
+                    o[e] = pack_bf2(da, db);
+                    dwacc[i][2 * e] += ga * xa * rstd;
+                    dwacc[i][2 * e + 1] += gb * xb * rstd;
+                }
+                dxr[c] = o;
+            }
+        }
+    }
+    // combine the 4 waves' partials through LDS (one chunk column at a time), then write the block partial
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + i * 64;
+        __syncthreads();
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdw[(wave * 64 + lane) * 8 + e] = dwacc[i][e];
+        }
+        __syncthreads();
+        if (wave == 0 && c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = sdw[(0 * 64 + lane) * 8 + e] + sdw[(1 * 64 + lane) * 8 + e] +
+                                sdw[(2 * 64 + lane) * 8 + e] + sdw[(3 * 64 + lane) * 8 + e];
+                dw_part[(size_t)blockIdx.x * H + c * 8 + e] = t;
+            }
+        }
+    }
+}
+
+// out[j] (+)= sum_b part[b][j]  — deterministic column reduce of block partials
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nb, int H, int row_stride,
+                                                     void* out, int out_f32, int accumulate) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= H) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += part[(size_t)b * row_stride + j];
+    if (out_f32) {
+        float* o = reinterpret_cast<float*>(out);
+        o[j] = accumulate ? o[j] + s : s;
+    } else {
+        bf16_t* o = reinterpret_cast<bf16_t*>(out);
+        o[j] = f2bf(accumulate ? bf2f(o[j]) + s : s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-head RMSNorm (optional) + scale (optional) + rotary (optional) on the q/k heads of a fused
+// projection buffer.  Qwen3: q_norm/k_norm then RoPE (HF:qwen3:252-257,148-170).  ESM-2: q*hd^-0.5 then
+// fp32 rotary, no norm (HF:esm:374-378,56-79).  One thread owns the pair (i, i+hd/2) of one head.
+// src [M, ld_src] heads at column head*hd ; dst [M, ld_dst] ; cos/sin fp32 [n_pos, hd/2]
+// ------------------------------------------------------------------------------------------------
+struct RopeArgs {
+    const bf16_t* src; bf16_t* dst;
+    const bf16_t* qw; const bf16_t* kw;      // per-head norm gains (nullable = no norm)
+    const float* cos; const float* sin;      // nullable = no rotary
+    const int* pos;                          // nullable: position = m % T
+    int M, T, nq, nk, hd, ld_src, ld_dst;
+    float eps, q_scale;
+};
+
+__global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
+    const int half = p.hd >> 1;
+    const int heads_per_blk = 256 / half;
+    const int i = threadIdx.x % half;
+    const long item = (long)blockIdx.x * heads_per_blk + threadIdx.x / half;
+    const int nh = p.nq + p.nk;
+    const long total = (long)p.M * nh;
+    const bool live = item < total;
+    const int m = live ? (int)(item / nh) : 0, head = live ? (int)(item % nh) : 0;
+    const bf16_t* s = p.src + (size_t)m * p.ld_src + head * p.hd;
+    float x1 = live ? bf2f(s[i]) : 0.f, x2 = live ? bf2f(s[i + half]) : 0.f;
+    const bool isq = head < p.nq;
+    const bf16_t* w = isq ? p.qw : p.kw;
+    if (w) {
+        float ss = x1 * x1 + x2 * x2;
+        for (int o = half >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = rsqrtf(ss / (float)p.hd + p.eps);
+        x1 = bf2f(f2bf(x1 * rstd)) * bf2f(w[i]);
+        x2 = bf2f(f2bf(x2 * rstd)) * bf2f(w[i + half]);
+        x1 = bf2f(f2bf(x1));
+        x2 = bf2f(f2bf(x2));
+    }
+    if (isq && p.q_scale != 1.0f) {
+        x1 = bf2f(f2bf(x1 * p.q_scale));
+        x2 = bf2f(f2bf(x2 * p.q_scale));
+    }
+    float y1 = x1, y2 = x2;
+    if (p.cos) {
+        const int pos = p.pos ? p.pos[m] : (m % p.T);
+        const float c = p.cos[(size_t)pos * half + i], sn = p.sin[(size_t)pos * half + i];
+        y1 = x1 * c - x2 * sn;
+        y2 = x2 * c + x1 * sn;
+    }
+    if (live) {
+        bf16_t* d = p.dst + (size_t)m * p.ld_dst + head * p.hd;
+        d[i] = f2bf(y1);
+        d[i + half] = f2bf(y2);
+    }
+}
+
+// backward of the above (Qwen3 form: norm + rotary; q_scale==1).  g = d(dst) [M, ld_dst];
+// writes d(src) for the q/k heads [M, ld_out] and per-block fp32 partials of d(q_norm.w), d(k_norm.w):
+// dw_part[blk][2][hd]
+struct RopeBwdArgs {
+    const bf16_t* src; const bf16_t* g; bf16_t* dsrc;
+    const bf16_t* qw; const bf16_t* kw;
+    const float* cos; const float* sin; const int* pos;
+    float* dw_part;
+    int M, T, nq, nk, hd, ld_src, ld_g, ld_out;
+    float eps;
+    long items_per_blk;
+};
+
+__global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    float* sdw = reinterpret_cast<float*>(sm_raw);          // [2][hd]
+    const int half = p.hd >> 1;
+    const int heads_per_it = 256 / half;
+    const int i = threadIdx.x % half, sub = threadIdx.x / half;
+    const int nh = p.nq + p.nk;
+    const long total = (long)p.M * nh;
+    for (int t = threadIdx.x; t < 2 * p.hd; t += 256) sdw[t] = 0.f;
+    __syncthreads();
+    float dwq1 = 0.f, dwq2 = 0.f, dwk1 = 0.f, dwk2 = 0.f;
+    const long begin = (long)blockIdx.x * p.items_per_blk;
+    const long end = min(begin + p.items_per_blk, total);
+    for (long base = begin; base < end; base += heads_per_it) {
+        const long item = base + sub;
+        const bool live = item < end;
+        const int m = live ? (int)(item / nh) : 0, head = live ? (int)(item % nh) : 0;
+        const bool isq = head < p.nq;
+        const bf16_t* s = p.src + (size_t)m * p.ld_src + head * p.hd;
+        const bf16_t* gg = p.g + (size_t)m * p.ld_g + head * p.hd;
+        const float x1 = live ? bf2f(s[i]) : 0.f, x2 = live ? bf2f(s[i + half]) : 0.f;
+        float g1 = live ? bf2f(gg[i]) : 0.f, g2 = live ? bf2f(gg[i + half]) : 0.f;
+        if (p.cos) {
+            const int pos = p.pos ? p.pos[m] : (m % p.T);
+            const float c = p.cos[(size_t)pos * half + i], sn = p.sin[(size_t)pos * half + i];
+            const float t1 = g1 * c + g2 * sn, t2 = g2 * c - g1 * sn;
+            g1 = t1; g2 = t2;
+        }
+        const bf16_t* w = isq ? p.qw : p.kw;
+        float d1 = g1, d2 = g2;
+        if (w) {
+            const float w1 = bf2f(w[i]), w2 = bf2f(w[i + half]);
+            float ss = x1 * x1 + x2 * x2;
+            float dot = g1 * w1 * x1 + g2 * w2 * x2;
+            for (int o = half >> 1; o > 0; o >>= 1) {
+                ss += __shfl_xor(ss, o, 64);
+                dot += __shfl_xor(dot, o, 64);
+            }
+            const float rstd = rsqrtf(ss / (float)p.hd + p.eps);
+            const float coef = dot * rstd * rstd * rstd / (float)p.hd;
+            d1 = g1 * w1 * rstd - x1 * coef;
+            d2 = g2 * w2 * rstd - x2 * coef;
+            if (live) {
+                if (isq) { dwq1 += g1 * x1 * rstd; dwq2 += g2 * x2 * rstd; }
+                else     { dwk1 += g1 * x1 * rstd; dwk2 += g2 * x2 * rstd; }
+            }
+        }
+        if (live) {
+            bf16_t* d = p.dsrc + (size_t)m * p.ld_out + head * p.hd;
+            d[i] = f2bf(d1);
+            d[i + half] = f2bf(d2);
+        }
+    }
+    atomicAdd(&sdw[i], dwq1);
+    atomicAdd(&sdw[i + half], dwq2);
+    atomicAdd(&sdw[p.hd + i], dwk1);
+    atomicAdd(&sdw[p.hd + i + half], dwk2);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * p.hd; t += 256) p.dw_part[(size_t)blockIdx.x * 2 * p.hd + t] = sdw[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// SwiGLU (HF:models/qwen3/modeling_qwen3.py:82): act = silu(gate) * up ; gu = [gate | up] per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long rows,
+                                                         int ff) {
+    const int nch = ff >> 3;
+    const long total = rows * nch;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / nch;
+        const int c = (int)(t % nch);
+        const u32x4 g = *reinterpret_cast<const u32x4*>(gu + (size_t)r * 2 * ff + c * 8);
+        const u32x4 u = *reinterpret_cast<const u32x4*>(gu + (size_t)r * 2 * ff + ff + c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ga = bflo(g[e]), gb = bfhi(g[e]);
+            // HF computes silu in bf16 (rounds), then the product (rounds)
+            const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+            o[e] = pack_bf2(sa * bflo(u[e]), sb * bfhi(u[e]));
+        }
+        *reinterpret_cast<u32x4*>(out + (size_t)r * ff + c * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dout,
+                                                         bf16_t* __restrict__ dgu, long rows, int ff) {
+    const int nch = ff >> 3;
+    const long total = rows * nch;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / nch;
+        const int c = (int)(t % nch);
+        const u32x4 g = *reinterpret_cast<const u32x4*>(gu + (size_t)r * 2 * ff + c * 8);
+        const u32x4 u = *reinterpret_cast<const u32x4*>(gu + (size_t)r * 2 * ff + ff + c * 8);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(dout + (size_t)r * ff + c * 8);
+        u32x4 og, ou;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ga = bflo(g[e]), gb = bfhi(g[e]);
+            const float siga = 1.f / (1.f + __expf(-ga)), sigb = 1.f / (1.f + __expf(-gb));
+            const float da = bflo(d[e]), db = bfhi(d[e]);
+            og[e] = pack_bf2(da * bflo(u[e]) * siga * (1.f + ga * (1.f - siga)),
+                             db * bfhi(u[e]) * sigb * (1.f + gb * (1.f - sigb)));
+            ou[e] = pack_bf2(da * ga * siga, db * gb * sigb);
+        }
+        *reinterpret_cast<u32x4*>(dgu + (size_t)r * 2 * ff + c * 8) = og;
+        *reinterpret_cast<u32x4*>(dgu + (size_t)r * 2 * ff + ff + c * 8) = ou;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row gather / scatter:  dst[dst_idx[i] or i, :] = src[src_idx[i] or i, :]   (H % 8 == 0), idx < 0 skips
+// embedding lookup (reference src/model/omics_one.py:164) = gather with int64 ids;
+// omic injection (src/model/omics_one.py:93-97) = scatter with an int32 row map.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict__ src, const long* __restrict__ src_idx64,
+                                                        const int* __restrict__ src_idx32, bf16_t* __restrict__ dst,
+                                                        const int* __restrict__ dst_idx32, long n, int H, int ld_src,
+                                                        int ld_dst, int accumulate) {
+    const int nch = H >> 3;
+    const long total = n * nch;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long i = t / nch;
+        const int c = (int)(t % nch);
+        long s = src_idx64 ? src_idx64[i] : (src_idx32 ? (long)src_idx32[i] : i);
+        long d = dst_idx32 ? (long)dst_idx32[i] : i;
+        if (s < 0 || d < 0) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)s * ld_src + c * 8);
+        u32x4* dp = reinterpret_cast<u32x4*>(dst + (size_t)d * ld_dst + c * 8);
+        if (accumulate) {
+            const u32x4 o = *dp;
+            u32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = pack_bf2(bflo(o[e]) + bflo(v[e]), bfhi(o[e]) + bfhi(v[e]));
+            *dp = r;
+        } else {
+            *dp = v;
+        }
+    }
+}
+
+// embedding backward: dE[id] += g[row] for every row whose `keep[row]` != 0, summed in fp32 through a sorted
+// index (rows grouped by id): seg_start[u]..seg_start[u+1] are positions in `order` of unique id `uid[u]`.
+// One wave per unique id -> deterministic, no atomics.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict__ g, const int* __restrict__ order,
+                                                        const int* __restrict__ seg_start, const long* __restrict__ uid,
+                                                        int n_unique, bf16_t* __restrict__ dE, int H, int ld_g) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_unique) return;
+    const int b = seg_start[u], e = seg_start[u + 1];
+    const long id = uid[u];
+    if (id < 0) return;
+    const int nch = H >> 3;
+    for (int c = lane; c < nch; c += 64) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = b; k < e; ++k) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(g + (size_t)order[k] * ld_g + c * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[2 * j] += bflo(v[j]); acc[2 * j + 1] += bfhi(v[j]); }
+        }
+        u32x4* dp = reinterpret_cast<u32x4*>(dE + (size_t)id * H + c * 8);
+        const u32x4 o = *dp;
+        u32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = pack_bf2(bflo(o[j]) + acc[2 * j], bfhi(o[j]) + acc[2 * j + 1]);
+        *dp = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-entropy on a chunk of bf16 logits, in place -> d(logits)   (HF:loss/loss_utils.py:32-71)
+// labels are ALREADY shifted (row r predicts labels[r]); ignore_index rows get zero grad / zero loss.
+// dlogits = (softmax - onehot) * (*scale)   with *scale = 1/n_valid computed on device beforehand.
+// one block per row; pass 1 online (max,sum), pass 2 rewrite.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16_t* __restrict__ logits, const long* __restrict__ labels,
+                                                         float* __restrict__ row_loss, const float* __restrict__ scale,
+                                                         int V, int ld, int ignore_index, int write_grad) {
+    __shared__ float red[16];
+    const long row = blockIdx.x;
+    bf16_t* lr = logits + (size_t)row * ld;
+    const long lab = labels[row];
+    const int nch = V >> 3;
+    if (lab == ignore_index) {
+        if (threadIdx.x == 0) row_loss[row] = 0.f;
+        if (write_grad) {
+            for (int c = threadIdx.x; c < nch; c += 256) *reinterpret_cast<u32x4*>(lr + c * 8) = u32x4{0, 0, 0, 0};
+        }
+        return;
+    }
+    if (lab < 0 || lab >= V) {             // torch asserts here; we poison the loss instead of reading OOB
+        if (threadIdx.x == 0) row_loss[row] = __builtin_nanf("");
+        return;
+    }
+    float mx = -INFINITY, sm = 0.f;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(lr + c * 8);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[2 * e] = bflo(v[e]); f[2 * e + 1] = bfhi(v[e]); }
+        float cm = f[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
+        const float nm = fmaxf(mx, cm);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += __expf(f[e] - nm);
+        sm = sm * __expf(mx - nm) + s;
+        mx = nm;
+    }
+    const float gmx = block_max(mx, red);
+    sm = sm * __expf(mx - gmx);            // mx=-inf lanes (no chunk): exp(-inf)=0 and sm=0
+    if (mx == -INFINITY) sm = 0.f;
+    const float gsm = block_sum(sm, red);
+    const float lse = gmx + __logf(gsm);
+    const float xl = bf2f(lr[lab]);
+    __syncthreads();
+    if (threadIdx.x == 0) row_loss[row] = lse - xl;
+    if (!write_grad) return;
+    const float sc = *scale;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        u32x4* pv = reinterpret_cast<u32x4*>(lr + c * 8);
+        const u32x4 v = *pv;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = __expf(bflo(v[e]) - lse), b = __expf(bfhi(v[e]) - lse);
+            const long j = (long)c * 8 + 2 * e;
+            if (j == lab) a -= 1.f;
+            if (j + 1 == lab) b -= 1.f;
+            o[e] = pack_bf2(a * sc, b * sc);
+        }
+        *pv = o;
+    }
+}
+
+// n_valid = #(labels != ignore) ; scale_out = 1/max(n_valid,1) ; count_out = n_valid   (single block)
+__global__ __launch_bounds__(1024) void count_valid_kernel(const long* __restrict__ labels, long n, int ignore_index,
+                                                           float* scale_out, float* count_out) {
+    __shared__ float red[16];
+    float c = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) c += (labels[i] != ignore_index) ? 1.f : 0.f;
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        *count_out = c;
+        *scale_out = 1.f / fmaxf(c, 1.f);
+    }
+}
+
+// deterministic sum of a float vector, optionally scaled by *scale: out = sum(x) * (*scale)  (single block)
+__global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, long n, const float* scale, float* out,
+                                                       int accumulate) {
+    __shared__ float red[16];
+    float c = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) c += x[i];
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        const float v = c * (scale ? *scale : 1.f);
+        *out = accumulate ? *out + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward (ESM: HF:models/esm/modeling_esm.py:429,518,552; nn.LayerNorm eps 1e-5, affine)
+// ------------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int rows,
+                                                            int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = H >> 3;
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)row * H);
+    u32x4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = xr[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bflo(v[i][e]) + bfhi(v[i][e]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bflo(v[i][e]) - mean, bb = bfhi(v[i][e]) - mean;
+                ss += a * a + bb * bb;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+    const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+    const u32x4* br = reinterpret_cast<const u32x4*>(b);
+    u32x4* yr = reinterpret_cast<u32x4*>(y + (size_t)row * H);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const u32x4 wv = wr[c], bv = br[c];
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = pack_bf2((bflo(v[i][e]) - mean) * rstd * bflo(wv[e]) + bflo(bv[e]),
+                                (bfhi(v[i][e]) - mean) * rstd * bfhi(wv[e]) + bfhi(bv[e]));
+            yr[c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ESM embeddings (HF:models/esm/modeling_esm.py:224-271,1050-1063).  One block per sequence:
+// mask = ids != pad ; token-dropout rescale (1-0.12)/(1-n_mask/n_valid) ; masked-token rows zeroed ;
+// absolute position ids = cumsum(mask)*mask + pad ; output multiplied by mask.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void esm_embed_kernel(const long* __restrict__ ids, const bf16_t* __restrict__ wemb,
+                                                        const bf16_t* __restrict__ pemb, bf16_t* __restrict__ out,
+                                                        int* __restrict__ pos_out, int* __restrict__ klen_out, int K, int H,
+                                                        int pad_id, int mask_id, int token_dropout) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    int* spos = reinterpret_cast<int*>(sm_raw);     // [K] position ids
+    __shared__ float red[16];
+    const int seq = blockIdx.x;
+    const long* sid = ids + (size_t)seq * K;
+    float nv = 0.f, nm = 0.f;
+    for (int t = threadIdx.x; t < K; t += 256) {
+        const long id = sid[t];
+        nv += (id != pad_id) ? 1.f : 0.f;
+        nm += (id == mask_id) ? 1.f : 0.f;
+    }
+    nv = block_sum(nv, red);
+    nm = block_sum(nm, red);
+    for (int t = threadIdx.x; t < K; t += 256) spos[t] = sid[t] != pad_id;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // serial cumsum over LDS: K <= 8192, negligible next to the encoder GEMMs
+        int run = 0;
+        int last_valid = 0;
+        for (int t = 0; t < K; ++t) {
+            const int mk = spos[t];
+            run += mk;
+            spos[t] = mk ? run + pad_id : pad_id;
+            if (mk) last_valid = t + 1;
+        }
+        if (klen_out) klen_out[seq] = last_valid;
+    }
+    __syncthreads();
+    const int nch = H >> 3;
+    for (int t = threadIdx.x; t < K * nch; t += 256) {
+        const int tok = t / nch, c = t % nch;
+        const long id = sid[tok];
+        u32x4 o = u32x4{0, 0, 0, 0};
+        if (id != pad_id) {
+            float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (!(token_dropout && id == mask_id)) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wemb + (size_t)id * H + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f[2 * e] = bflo(v[e]); f[2 * e + 1] = bfhi(v[e]); }
+                if (token_dropout) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = bf2f(f2bf(f[e] * (1.f - 0.15f * 0.8f) / (1.f - nm / nv)));
+                }
+            }
+            if (pemb) {
+                const u32x4 pv = *reinterpret_cast<const u32x4*>(pemb + (size_t)spos[tok] * H + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f[2 * e] += bflo(pv[e]); f[2 * e + 1] += bfhi(pv[e]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf2(f[2 * e], f[2 * e + 1]);
+        }
+        *reinterpret_cast<u32x4*>(out + ((size_t)seq * K + tok) * H + c * 8) = o;
+    }
+    if (pos_out)
+        for (int t = threadIdx.x; t < K; t += 256) pos_out[(size_t)seq * K + t] = spos[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer: squared-norm partials, clip coefficient, AdamW shard step
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_part_kernel(const bf16_t* __restrict__ g, long n, float* __restrict__ part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const long nch = n >> 3;
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(g + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = bflo(v[e]), b = bfhi(v[e]); s += a * a + b * b; }
+    }
+    if (blockIdx.x == 0)
+        for (long i = (nch << 3) + threadIdx.x; i < n; i += 256) { const float a = bf2f(g[i]); s += a * a; }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// norm_sq (device scalar, possibly all-reduced across ranks) -> total norm, clip coefficient
+// coef = min(1, max_norm / (norm + 1e-6)) * pre_scale       (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* norm_sq, float max_norm, float pre_scale, float* norm_out, float* coef_out) {
+    const float n = sqrtf(*norm_sq) * pre_scale;
+    *norm_out = n;
+    float c = max_norm > 0.f ? fminf(1.f, max_norm / (n + 1e-6f)) : 1.f;
+    *coef_out = c * pre_scale;
+}
+
+// torch.optim.AdamW single-tensor math on an fp32 master shard; grad bf16 scaled by *gscale; emits bf16 param
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                    const bf16_t* __restrict__ grad, bf16_t* __restrict__ param_out, long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.f;
+    const long nch = n >> 2;
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+        f32x4 p = *reinterpret_cast<f32x4*>(master + c * 4);
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + c * 4);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + c * 4);
+        const u32x2 gr = *reinterpret_cast<const u32x2*>(grad + c * 4);
+        float g[4] = {bflo(gr[0]) * gs, bfhi(gr[0]) * gs, bflo(gr[1]) * gs, bfhi(gr[1]) * gs};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            p[e] *= (1.f - lr * wd);
+            mm[e] = b1 * mm[e] + (1.f - b1) * g[e];
+            vv[e] = b2 * vv[e] + (1.f - b2) * g[e] * g[e];
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            p[e] -= (lr / bc1) * (mm[e] / denom);
+        }
+        *reinterpret_cast<f32x4*>(master + c * 4) = p;
+        *reinterpret_cast<f32x4*>(m + c * 4) = mm;
+        *reinterpret_cast<f32x4*>(v + c * 4) = vv;
+        *reinterpret_cast<u32x2*>(param_out + c * 4) = u32x2{pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3])};
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    const long nch = n >> 2;
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(in + c * 4);
+        *reinterpret_cast<u32x2*>(out + c * 4) = u32x2{pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3])};
+    }
+    if (blockIdx.x == 0)
+        for (long i = (nch << 2) + threadIdx.x; i < n; i += 256) out[i] = f2bf(in[i]);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = bf2f(in[i]);
+}
+
+inline int grid_for(long items, int per_block = 256, int cap = 2048) {
+    long g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+// pick the smallest register-resident chunk count that covers H (512 elements per chunk)
+#define NC_DISPATCH(H, F)          \
+    do {                           \
+        if ((H) <= 512) F(1);      \
+        else if ((H) <= 1024) F(2);\
+        else if ((H) <= 1536) F(3);\
+        else if ((H) <= 2048) F(4);\
+        else if ((H) <= 2560) F(5);\
+        else F(8);                 \
+    } while (0)
+
+extern "C" int molly_transpose_bf16(void* stream, const void* in, void* out, int R, int C, int ld_in, int ld_out) {
+    MOLLY_CHECK(R > 0 && C > 0 && ld_in >= C && ld_out >= R, "transpose: bad shape R=%d C=%d", R, C);
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, R,
+                       C, ld_in, ld_out);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* rstd, int rows, int H,
+                                 float eps) {
+    MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "rmsnorm: H=%d must be a multiple of 8 and <= %d", H,
+                RN_MAXC * 512);
+#define RMS_FWD(NC)                                                                                              \
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<NC>, dim3(cdiv(rows, 4)), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)w, \
+                       (bf16_t*)y, rstd, rows, H, eps)
+    NC_DISPATCH(H, RMS_FWD);
+#undef RMS_FWD
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_rmsnorm_bwd_blocks(int rows) { return grid_for(rows, 4, 512); }
+
+extern "C" int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres, void* dx,
+                                 void* dw, int dw_f32, int dw_accumulate, float* workspace, int rows, int H, float eps) {
+    MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "rmsnorm_bwd: bad H=%d", H);
+    MOLLY_CHECK(workspace, "rmsnorm_bwd: workspace of molly_rmsnorm_bwd_blocks(rows)*H floats required");
+    const int nb = molly_rmsnorm_bwd_blocks(rows);
+#define RMS_BWD(NC)                                                                                                  \
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<NC>, dim3(nb), dim3(256), 4 * 64 * 8 * sizeof(float), ST, (const bf16_t*)x,   \
+                       (const bf16_t*)w, (const bf16_t*)g, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows, H, eps)
+    NC_DISPATCH(H, RMS_BWD);
+#undef RMS_BWD
+    MOLLY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, ST, workspace, nb, H, H, dw, dw_f32, dw_accumulate);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_norm_rope_fwd(void* stream, const void* src, void* dst, const void* q_norm_w, const void* k_norm_w,
+                                   const float* cos, const float* sin, const int* positions, int M, int T, int n_q_heads,
+                                   int n_k_heads, int head_dim, int ld_src, int ld_dst, float eps, float q_scale) {
+    MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0, "norm_rope: head_dim=%d", head_dim);
+    MOLLY_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr), "norm_rope: give both norm gains or neither");
+    MOLLY_CHECK((cos == nullptr) == (sin == nullptr), "norm_rope: give both cos and sin or neither");
+    RopeArgs p{(const bf16_t*)src, (bf16_t*)dst, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, cos, sin, positions,
+               M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_dst, eps, q_scale};
+    const long items = (long)M * (n_q_heads + n_k_heads);
+    const int hpb = 256 / (head_dim / 2);
+    hipLaunchKernelGGL(norm_rope_fwd_kernel, dim3((unsigned)((items + hpb - 1) / hpb)), dim3(256), 0, ST, p);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_norm_rope_bwd_blocks(void) { return 1024; }
+
+extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g, void* dsrc, const void* q_norm_w,
+                                   const void* k_norm_w, const float* cos, const float* sin, const int* positions,
+                                   void* dq_w, void* dk_w, int dw_f32, int dw_accumulate, float* workspace, int M, int T,
+                                   int n_q_heads, int n_k_heads, int head_dim, int ld_src, int ld_g, int ld_out,
+                                   float eps) {
+    MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0, "norm_rope_bwd: head_dim=%d",
+                head_dim);
+    MOLLY_CHECK(workspace, "norm_rope_bwd: workspace of molly_norm_rope_bwd_blocks()*2*head_dim floats required");
+    const int nb = molly_norm_rope_bwd_blocks();
+    const long items = (long)M * (n_q_heads + n_k_heads);
+    const int hpi = 256 / (head_dim / 2);
+    long ipb = (items + nb - 1) / nb;
+    ipb = (ipb + hpi - 1) / hpi * hpi;
+    RopeBwdArgs p{(const bf16_t*)src, (const bf16_t*)g, (bf16_t*)dsrc, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w,
+                  cos, sin, positions, workspace, M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_g, ld_out, eps, ipb};
+    hipLaunchKernelGGL(norm_rope_bwd_kernel, dim3(nb), dim3(256), 2 * head_dim * sizeof(float), ST, p);
+    MOLLY_LAUNCH_CHECK();
+    if (q_norm_w) {
+        MOLLY_CHECK(dq_w && dk_w, "norm_rope_bwd: gain gradients requested without output pointers");
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 256)), dim3(256), 0, ST, workspace, nb, head_dim, 2 * head_dim,
+                           dq_w, dw_f32, dw_accumulate);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 256)), dim3(256), 0, ST, workspace + head_dim, nb, head_dim,
+                           2 * head_dim, dk_w, dw_f32, dw_accumulate);
+        MOLLY_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int molly_swiglu_fwd(void* stream, const void* gate_up, void* out, long rows, int ff) {
+    MOLLY_CHECK(rows > 0 && ff % 8 == 0, "swiglu: ff=%d must be a multiple of 8", ff);
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (ff / 8))), dim3(256), 0, ST, (const bf16_t*)gate_up,
+                       (bf16_t*)out, rows, ff);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_swiglu_bwd(void* stream, const void* gate_up, const void* dout, void* dgate_up, long rows, int ff) {
+    MOLLY_CHECK(rows > 0 && ff % 8 == 0, "swiglu_bwd: ff=%d must be a multiple of 8", ff);
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (ff / 8))), dim3(256), 0, ST, (const bf16_t*)gate_up,
+                       (const bf16_t*)dout, (bf16_t*)dgate_up, rows, ff);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_copy_rows(void* stream, const void* src, const int64_t* src_idx64, const int* src_idx32, void* dst,
+                               const int* dst_idx32, long n, int H, int ld_src, int ld_dst, int accumulate) {
+    MOLLY_CHECK(n >= 0 && H % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, "copy_rows: H/ld must be multiples of 8");
+    MOLLY_CHECK(!(src_idx64 && src_idx32), "copy_rows: give at most one source index");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(n * (H / 8))), dim3(256), 0, ST, (const bf16_t*)src,
+                       (const long*)src_idx64, src_idx32, (bf16_t*)dst, dst_idx32, n, H, ld_src, ld_dst, accumulate);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_embed_bwd(void* stream, const void* g, const int* order, const int* seg_start, const int64_t* uid,
+                               int n_unique, void* dE, int H, int ld_g) {
+    MOLLY_CHECK(H % 8 == 0 && ld_g % 8 == 0, "embed_bwd: H must be a multiple of 8");
+    if (n_unique <= 0) return 0;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(n_unique, 4)), dim3(256), 0, ST, (const bf16_t*)g, order, seg_start,
+                       (const long*)uid, n_unique, (bf16_t*)dE, H, ld_g);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_count_valid(void* stream, const int64_t* labels, long n, int ignore_index, float* scale_out,
+                                 float* count_out) {
+    hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, ST, (const long*)labels, n, ignore_index, scale_out,
+                       count_out);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_ce_fwd_bwd(void* stream, void* logits, const int64_t* labels, float* row_loss, const float* scale,
+                                int rows, int V, int ld, int ignore_index, int write_grad) {
+    MOLLY_CHECK(rows > 0 && V % 8 == 0 && ld % 8 == 0, "ce: V=%d and ld=%d must be multiples of 8", V, ld);
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, ST, (bf16_t*)logits, (const long*)labels, row_loss,
+                       scale, V, ld, ignore_index, write_grad);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_sum_f32(void* stream, const float* x, long n, const float* scale, float* out, int accumulate) {
+    hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, ST, x, n, scale, out, accumulate);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_layernorm_fwd(void* stream, const void* x, const void* w, const void* b, void* y, int rows, int H,
+                                   float eps) {
+    MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "layernorm: bad H=%d", H);
+#define LN_FWD(NC)                                                                                                 \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<NC>, dim3(cdiv(rows, 4)), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)w, \
+                       (const bf16_t*)b, (bf16_t*)y, rows, H, eps)
+    NC_DISPATCH(H, LN_FWD);
+#undef LN_FWD
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_esm_embed(void* stream, const int64_t* ids, const void* word_emb, const void* pos_emb, void* out,
+                               int* pos_ids_out, int* kv_len_out, int n_seq, int K, int H, int pad_id, int mask_id,
+                               int token_dropout) {
+    MOLLY_CHECK(n_seq > 0 && K > 0 && K <= 8192 && H % 8 == 0, "esm_embed: bad shape n_seq=%d K=%d H=%d", n_seq, K, H);
+    hipLaunchKernelGGL(esm_embed_kernel, dim3(n_seq), dim3(256), K * sizeof(int), ST, (const long*)ids,
+                       (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (bf16_t*)out, pos_ids_out, kv_len_out, K, H, pad_id,
+                       mask_id, token_dropout);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_sqnorm_blocks(void) { return 1024; }
+
+extern "C" int molly_sqnorm_bf16(void* stream, const void* g, long n, float* workspace, float* out, int accumulate) {
+    MOLLY_CHECK(workspace && ((uintptr_t)g % 16) == 0, "sqnorm: workspace required, 16-byte aligned input");
+    const int nb = molly_sqnorm_blocks();
+    hipLaunchKernelGGL(sqnorm_part_kernel, dim3(nb), dim3(256), 0, ST, (const bf16_t*)g, n, workspace);
+    MOLLY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, ST, workspace, (long)nb, (const float*)nullptr, out,
+                       accumulate);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_clip_coef(void* stream, const float* norm_sq, float max_norm, float pre_scale, float* norm_out,
+                               float* coef_out) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST, norm_sq, max_norm, pre_scale, norm_out, coef_out);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_adamw_step(void* stream, float* master, float* exp_avg, float* exp_avg_sq, const void* grad,
+                                void* param_out, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int step, const float* grad_scale) {
+    MOLLY_CHECK(n % 4 == 0 && step >= 1, "adamw: n=%ld must be a multiple of 4 and step >= 1", n);
+    if (n == 0) return 0;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, master, exp_avg, exp_avg_sq,
+                       (const bf16_t*)grad, (bf16_t*)param_out, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
+                       grad_scale);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_cast_f32_to_bf16(void* stream, const float* in, void* out, long n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, ST, in, (bf16_t*)out, n);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_cast_bf16_to_f32(void* stream, const void* in, float* out, long n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, ST, (const bf16_t*)in, out, n);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,151 @@
+"""Tensor-level wrappers over the C ABI (include/molly_hip.h).  PyTorch is plumbing here: it owns device
+memory and the stream; every FLOP runs in libmolly_hip.so.  No wrapper has a torch fallback."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ._lib import lib
+
+BF16 = torch.bfloat16
+GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32 = 1, 2, 4, 8, 16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"molly_amd: {name} must live on the GPU (no CPU path exists)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"molly_amd: {name} must be {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"molly_amd: {name} must be contiguous in its last dimension")
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+            res: Optional[torch.Tensor] = None, gelu: bool = False, accumulate: bool = False,
+            out_dtype=BF16) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ b[N,K]^T (+bias) (gelu) (+res) (+= out).  2-D views with arbitrary row stride."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2, (a.shape, b.shape)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    _chk(out, None, "out")
+    flags = 0
+    if bias is not None:
+        _chk(bias, BF16, "bias"); flags |= GEMM_BIAS
+    if gelu:
+        flags |= GEMM_GELU
+    if res is not None:
+        _chk(res, BF16, "res"); flags |= GEMM_RESIDUAL
+    if accumulate:
+        flags |= GEMM_ACCUMULATE
+    if out.dtype == torch.float32:
+        flags |= GEMM_OUT_F32
+    elif out.dtype != BF16:
+        raise TypeError("gemm_nt: out must be bf16 or fp32")
+    lib().call("molly_gemm_nt_bf16", _stream(), a, b, out, bias, res, M, N, K, a.stride(0), b.stride(0), out.stride(0),
+               res.stride(0) if res is not None else 0, flags)
+    return out
+
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, BF16, "x")
+    R, C = x.shape
+    if out is None:
+        out = torch.empty((C, R), dtype=BF16, device=x.device)
+    lib().call("molly_transpose_bf16", _stream(), x, out, R, C, x.stride(0), out.stride(0))
+    return out
+
+
+def rmsnorm_fwd(x, w, eps, out=None):
+    _chk(x, BF16, "x")
+    rows, H = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    lib().call("molly_rmsnorm_fwd", _stream(), x, w, out, None, rows, H, float(eps))
+    return out
+
+
+def rmsnorm_bwd(x, w, g, dw, eps, dres=None, dx=None, dw_accumulate=True, workspace=None):
+    rows, H = x.shape
+    assert x.is_contiguous() and g.is_contiguous()
+    if dx is None:
+        dx = torch.empty_like(x)
+    nb = lib().query("molly_rmsnorm_bwd_blocks", rows)
+    if workspace is None:
+        workspace = torch.empty(nb * H, dtype=torch.float32, device=x.device)
+    assert workspace.numel() >= nb * H
+    lib().call("molly_rmsnorm_bwd", _stream(), x, w, g, dres, dx, dw, int(dw.dtype == torch.float32), int(dw_accumulate),
+               workspace, rows, H, float(eps))
+    return dx
+
+
+def norm_rope_fwd(src, dst, nq, nk, hd, T, qw=None, kw=None, cos=None, sin=None, positions=None, eps=1e-6, q_scale=1.0):
+    M = src.shape[0]
+    lib().call("molly_norm_rope_fwd", _stream(), src, dst, qw, kw, cos, sin, positions, M, T, nq, nk, hd,
+               src.stride(0), dst.stride(0), float(eps), float(q_scale))
+    return dst
+
+
+def norm_rope_bwd(src, g, dsrc, nq, nk, hd, T, qw, kw, cos, sin, dqw, dkw, positions=None, eps=1e-6,
+                  dw_accumulate=True, workspace=None):
+    M = src.shape[0]
+    nb = lib().query("molly_norm_rope_bwd_blocks")
+    if workspace is None:
+        workspace = torch.empty(nb * 2 * hd, dtype=torch.float32, device=src.device)
+    lib().call("molly_norm_rope_bwd", _stream(), src, g, dsrc, qw, kw, cos, sin, positions, dqw, dkw,
+               int(dqw.dtype == torch.float32) if dqw is not None else 0, int(dw_accumulate), workspace, M, T, nq, nk, hd,
+               src.stride(0), g.stride(0), dsrc.stride(0), float(eps))
+    return dsrc
+
+
+def swiglu_fwd(gu, out=None):
+    rows, ff2 = gu.shape
+    assert gu.is_contiguous()
+    if out is None:
+        out = torch.empty((rows, ff2 // 2), dtype=BF16, device=gu.device)
+    lib().call("molly_swiglu_fwd", _stream(), gu, out, rows, ff2 // 2)
+    return out
+
+
+def swiglu_bwd(gu, dout, dgu=None):
+    rows, ff2 = gu.shape
+    if dgu is None:
+        dgu = torch.empty_like(gu)
+    lib().call("molly_swiglu_bwd", _stream(), gu, dout, dgu, rows, ff2 // 2)
+    return dgu
+
+
+def copy_rows(src, dst, n, src_idx64=None, src_idx32=None, dst_idx32=None, accumulate=False):
+    H = src.shape[-1]
+    lib().call("molly_copy_rows", _stream(), src, src_idx64, src_idx32, dst, dst_idx32, n, H, src.stride(-2),
+               dst.stride(-2), int(accumulate))
+    return dst
+
+
+def layernorm_fwd(x, w, b, eps, out=None):
+    rows, H = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    lib().call("molly_layernorm_fwd", _stream(), x, w, b, out, rows, H, float(eps))
+    return out
+
+
+def attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, kv_lo=None, kv_hi=None, out=None, lse=None):
+    """q/k/v: 2-D views [B*T, *] whose row holds the heads of one token (head h at column h*hd)."""
+    if out is None:
+        out = torch.empty((B * T, nh * hd), dtype=BF16, device=q.device)
+    if lse is None:
+        lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    lib().call("molly_attn_fwd", _stream(), q, k, v, out, lse, kv_lo, kv_hi, B, T, nh, nkv, hd, q.stride(0), k.stride(0),
+               v.stride(0), out.stride(0), float(scale), int(causal))
+    return out, lse

@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library loads and exports every symbol include/molly_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from molly_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "libmolly_hip.so not built (run __graft_entry__.build())"
+    protos = _lib.parse_header()
+    assert len(protos) >= 20
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in protos if not hasattr(cdll, n)]
+    assert not missing, missing
+
+
+def test_header_has_no_torch_types_and_cites_reference():
+    src = open(_lib.HEADER).read()
+    assert "torch" not in src.lower().replace("pytorch", "") or "at::" not in src
+    assert 'extern "C"' in src
+    assert "reference" in src and "HF:" in src
+
+
+def test_error_channel_and_abi_version():
+    m = _lib.lib()
+    assert m.fn["molly_abi_version"]() >= 1
+    # argument validation happens before any launch: callable without a GPU
+    rc = m.fn["molly_gemm_nt_bf16"](None, None, None, None, None, None, 128, 128, 48, 48, 48, 128, 0, 0)
+    assert rc != 0 and "multiple of 64" in m.last_error()
+
+
+def test_product_package_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle\.molly_ref|importlib.*oracle", re.M)
+    for dp, _, fns in os.walk(os.path.join(ROOT, "molly_amd")):
+        for fn in fns:
+            if fn.endswith(".py"):
+                txt = open(os.path.join(dp, fn)).read()
+                assert not pat.search(txt), f"{fn} references the oracle"

@@ -1,0 +1,259 @@
+"""GPU: each HIP kernel (through the C ABI) against a plain fp32 PyTorch statement of the same op on the same
+seeded inputs.  Tolerances are bf16-output tolerances and are written next to each check."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from molly_amd import ops
+    from molly_amd._lib import lib
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _close(got, ref, atol, rtol, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off; max err {err.max().item():.4g} " \
+                          f"(ref absmax {ref.abs().max().item():.4g})"
+
+
+# ------------------------------------------------------------------------------------------------
+def test_probe_mfma_layout_exact_integers():
+    """A = asymmetric small ints, B = other small ints: D must equal A @ B^T exactly (pins the operand/C maps)."""
+    A = torch.randint(-3, 4, (16, 32), generator=torch.Generator().manual_seed(1)).float()
+    B = torch.randint(-3, 4, (16, 32), generator=torch.Generator().manual_seed(2)).float()
+    D = torch.empty(16, 16, dtype=torch.float32, device=DEV)
+    lib().call("molly_probe_mfma16", 0, A.to(DEV, BF), B.to(DEV, BF), D)
+    torch.cuda.synchronize()
+    assert torch.equal(D.cpu(), A @ B.T)
+
+
+@pytest.mark.parametrize("stride", [16, 64, 128])
+def test_probe_tr16_semantics(stride):
+    """ds_read_b64_tr_b16: lane i of 16-lane group g must receive column i of rows 4g..4g+3 (element q = row q)."""
+    tile = torch.arange(16 * stride, dtype=torch.int32).reshape(16, stride)
+    out = torch.empty(64, 4, dtype=torch.int16, device=DEV)
+    lib().call("molly_probe_tr16", 0, tile.to(torch.int16).to(DEV), out, stride)
+    torch.cuda.synchronize()
+    out = out.cpu().to(torch.int32)
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        for q in range(4):
+            assert out[lane, q].item() == tile[4 * g + q, i].item(), (lane, q, out[lane].tolist())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 200, 128), (2048, 1024, 2048), (64, 1024, 256),
+                                   (1, 128, 64)])
+def test_gemm_nt_plain(M, N, K):
+    a = _rand(M, K, seed=1).to(BF)
+    b = _rand(N, K, seed=2).to(BF)
+    out = ops.gemm_nt(a, b)
+    ref = a.float() @ b.float().T
+    # bf16 output: half-ulp 2^-9 relative + fp32 accumulation-order noise
+    _close(out, ref, atol=2e-2 * math.sqrt(K / 64), rtol=8e-3, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_nt_exact_small_integers():
+    """Integer data: every product/sum is exact in fp32 and bf16-representable -> bit-exact result required."""
+    M, N, K = 256, 128, 128
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    b = torch.randint(-2, 3, (N, K), generator=g).float()
+    out = ops.gemm_nt(a.to(DEV, BF), b.to(DEV, BF), out_dtype=torch.float32)
+    assert torch.equal(out.cpu(), a @ b.T)
+
+
+def test_gemm_nt_epilogues():
+    M, N, K = 200, 256, 128
+    a, b = _rand(M, K, seed=4).to(BF), _rand(N, K, seed=5).to(BF)
+    bias, res = _rand(N, seed=6).to(BF), _rand(M, N, seed=7).to(BF)
+    base = a.float() @ b.float().T
+    _close(ops.gemm_nt(a, b, bias=bias), base + bias.float(), 3e-2, 8e-3, "bias")
+    _close(ops.gemm_nt(a, b, bias=bias, gelu=True), torch.nn.functional.gelu(base + bias.float()), 3e-2, 8e-3, "gelu")
+    _close(ops.gemm_nt(a, b, res=res), base + res.float(), 3e-2, 8e-3, "residual")
+    acc = _rand(M, N, seed=8)
+    out = acc.clone()
+    ops.gemm_nt(a, b, out=out, accumulate=True)
+    _close(out, base + acc, 1e-3, 1e-5, "fp32 accumulate")
+    # strided views (fused-QKV style): write into a column slice of a wider buffer
+    wide = torch.zeros(M, 3 * N, dtype=BF, device=DEV)
+    ops.gemm_nt(a, b, out=wide[:, N:2 * N])
+    _close(wide[:, N:2 * N], base, 3e-2, 8e-3, "strided out")
+    assert wide[:, :N].abs().max() == 0 and wide[:, 2 * N:].abs().max() == 0
+
+
+def test_gemm_rejects_bad_k():
+    a, b = _rand(64, 48).to(BF), _rand(64, 48).to(BF)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm_nt(a, b)
+
+
+def test_transpose():
+    x = _rand(300, 200, seed=9).to(BF)
+    assert torch.equal(ops.transpose(x), x.T.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+def _rmsnorm_ref(x, w, eps):
+    xf = x.float()
+    return (w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(BF).float())
+
+
+@pytest.mark.parametrize("rows,H", [(37, 256), (512, 2048), (64, 2560), (16, 4096), (8, 1024)])
+def test_rmsnorm_fwd_bwd(rows, H):
+    x = _rand(rows, H, seed=10).to(BF)
+    w = (1 + 0.1 * _rand(H, seed=11)).to(BF)
+    y = ops.rmsnorm_fwd(x, w, 1e-6)
+    _close(y, _rmsnorm_ref(x, w, 1e-6), 1e-2, 8e-3, "rmsnorm fwd")
+    g = _rand(rows, H, seed=12).to(BF)
+    dres = _rand(rows, H, seed=13).to(BF)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    yr = wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    yr.backward(g.float())
+    dw = torch.zeros(H, dtype=torch.float32, device=DEV)
+    dx = ops.rmsnorm_bwd(x, w, g, dw, 1e-6, dres=dres)
+    _close(dx, xr.grad + dres.float(), 2e-2, 1e-2, "rmsnorm dx")
+    _close(dw, wr.grad, 2e-3 * math.sqrt(rows), 1e-3, "rmsnorm dw")
+
+
+def test_swiglu_fwd_bwd():
+    rows, ff = 130, 512
+    gu = _rand(rows, 2 * ff, seed=14).to(BF)
+    out = ops.swiglu_fwd(gu)
+    gr = gu.float().requires_grad_(True)
+    ref = torch.nn.functional.silu(gr[:, :ff]) * gr[:, ff:]
+    _close(out, ref, 1e-2, 1e-2, "swiglu fwd")
+    d = _rand(rows, ff, seed=15).to(BF)
+    ref.backward(d.float())
+    _close(ops.swiglu_bwd(gu, d), gr.grad, 1e-2, 1e-2, "swiglu bwd")
+
+
+def _rope_tables(T, hd, theta, dtype=torch.float32):
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(T).float()[:, None] * inv
+    return fr.cos().to(dtype).float().to(DEV).contiguous(), fr.sin().to(dtype).float().to(DEV).contiguous()
+
+
+def _norm_rope_ref(x, nq, nk, hd, T, qw, kw, cos, sin, eps, q_scale):
+    M = x.shape[0]
+    xh = x.view(M, nq + nk, hd)
+    if qw is not None:
+        w = torch.cat([qw.view(1, 1, hd).expand(1, nq, hd), kw.view(1, 1, hd).expand(1, nk, hd)], 1)
+        xh = w * (xh * torch.rsqrt(xh.pow(2).mean(-1, keepdim=True) + eps))
+    if q_scale != 1.0:
+        xh = torch.cat([xh[:, :nq] * q_scale, xh[:, nq:]], 1)
+    if cos is not None:
+        pos = torch.arange(M, device=x.device) % T
+        c = torch.cat([cos, cos], -1)[pos][:, None, :]
+        s = torch.cat([sin, sin], -1)[pos][:, None, :]
+        rot = torch.cat([-xh[..., hd // 2:], xh[..., :hd // 2]], -1)
+        xh = xh * c + rot * s
+    return xh.reshape(M, -1)
+
+
+@pytest.mark.parametrize("hd,nq,nk,norm", [(128, 4, 2, True), (64, 2, 2, False)])
+def test_norm_rope_fwd_bwd(hd, nq, nk, norm):
+    B, T = 2, 96
+    M = B * T
+    extra = 2 * hd                      # v columns after q|k in the fused buffer
+    src = _rand(M, (nq + nk) * hd + extra, seed=16).to(BF)
+    cos, sin = _rope_tables(T, hd, 1e6 if norm else 1e4)
+    qw = (1 + 0.1 * _rand(hd, seed=17)).to(BF) if norm else None
+    kw = (1 + 0.1 * _rand(hd, seed=18)).to(BF) if norm else None
+    q_scale = 1.0 if norm else hd ** -0.5
+    dst = torch.empty(M, (nq + nk) * hd, dtype=BF, device=DEV)
+    ops.norm_rope_fwd(src, dst, nq, nk, hd, T, qw, kw, cos, sin, eps=1e-6, q_scale=q_scale)
+    xr = src[:, :(nq + nk) * hd].float().requires_grad_(True)
+    qwr = qw.float().requires_grad_(True) if norm else None
+    kwr = kw.float().requires_grad_(True) if norm else None
+    ref = _norm_rope_ref(xr, nq, nk, hd, T, qwr, kwr, cos, sin, 1e-6, q_scale)
+    _close(dst, ref, 1.5e-2, 1e-2, "norm_rope fwd")
+    if not norm:
+        return
+    g = _rand(M, (nq + nk) * hd, seed=19).to(BF)
+    ref.backward(g.float())
+    dsrc = torch.zeros(M, (nq + nk) * hd + extra, dtype=BF, device=DEV)
+    dqw = torch.zeros(hd, dtype=torch.float32, device=DEV)
+    dkw = torch.zeros(hd, dtype=torch.float32, device=DEV)
+    ops.norm_rope_bwd(src, g, dsrc, nq, nk, hd, T, qw, kw, cos, sin, dqw, dkw, eps=1e-6)
+    _close(dsrc[:, :(nq + nk) * hd], xr.grad, 2e-2, 1e-2, "norm_rope dsrc")
+    assert dsrc[:, (nq + nk) * hd:].abs().max() == 0
+    _close(dqw, qwr.grad, 5e-2, 5e-3, "dq_norm_w")
+    _close(dkw, kwr.grad, 5e-2, 5e-3, "dk_norm_w")
+
+
+def test_layernorm_fwd():
+    x = _rand(70, 1280, seed=20).to(BF)
+    w, b = (1 + 0.1 * _rand(1280, seed=21)).to(BF), (0.1 * _rand(1280, seed=22)).to(BF)
+    ref = torch.nn.functional.layer_norm(x.float(), (1280,), w.float(), b.float(), 1e-5)
+    _close(ops.layernorm_fwd(x, w, b, 1e-5), ref, 1.5e-2, 8e-3, "layernorm")
+
+
+def test_copy_rows_gather_scatter():
+    E = _rand(50, 64, seed=23).to(BF)
+    ids = torch.tensor([3, 49, 0, 3, 7], device=DEV, dtype=torch.int64)
+    out = torch.zeros(5, 64, dtype=BF, device=DEV)
+    ops.copy_rows(E, out, 5, src_idx64=ids)
+    assert torch.equal(out, E[ids])
+    dst = torch.zeros(10, 64, dtype=BF, device=DEV)
+    rows = torch.tensor([9, -1, 2, 4, 0], device=DEV, dtype=torch.int32)
+    ops.copy_rows(out, dst, 5, dst_idx32=rows)
+    assert torch.equal(dst[9], out[0]) and torch.equal(dst[2], out[2]) and dst[1].abs().max() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, B, T, nh, nkv, hd, scale, causal, lo=None, hi=None):
+    qh = q.float().view(B, T, nh, hd).transpose(1, 2)
+    kh = k.float().view(B, T, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    vh = v.float().view(B, T, nkv, hd).transpose(1, 2).repeat_interleave(nh // nkv, 1)
+    s = qh @ kh.transpose(2, 3) * scale
+    idx = torch.arange(T, device=q.device)
+    ok = torch.ones(B, 1, T, T, dtype=torch.bool, device=q.device)
+    if causal:
+        ok = ok & (idx[None, :] <= idx[:, None])[None, None]
+    if lo is not None:
+        ok = ok & ((idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None]))[:, None, None, :]
+    s = s.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    o = (p @ vh).transpose(1, 2).reshape(B * T, nh * hd)
+    lse2 = torch.logsumexp(s, -1) / math.log(2.0)
+    return o, lse2
+
+
+@pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [
+    (128, 4, 2, 256, True, False), (128, 4, 2, 200, True, True), (64, 2, 2, 64, False, True),
+    (64, 4, 4, 320, False, False), (128, 2, 1, 512, True, True)])
+def test_attn_fwd(hd, nh, nkv, T, causal, ragged):
+    B = 2
+    M = B * T
+    # fused token-major buffer: q heads | k heads | v heads
+    qkv = _rand(M, (nh + 2 * nkv) * hd, seed=24).to(BF)
+    q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+    lo = hi = None
+    if ragged:
+        lo = torch.tensor([0, 3], device=DEV, dtype=torch.int32)
+        hi = torch.tensor([T, T - 37], device=DEV, dtype=torch.int32)
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, lo, hi)
+    ro, rl = _attn_ref(q, k, v, B, T, nh, nkv, hd, scale, causal, lo, hi)
+    # rows with no visible key: ours = 0 / -inf by definition
+    live = torch.isfinite(rl)
+    rof = ro.view(B, T, nh, hd).transpose(1, 2)
+    of = o.float().view(B, T, nh, hd).transpose(1, 2)
+    _close(of[live], rof[live], 2e-2, 1e-2, "attn O")     # bf16 P and bf16 output
+    _close(lse[live], rl[live], 2e-3, 1e-4, "attn lse2")
