@@ -124,6 +124,14 @@ int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, vo
                    const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv,
                    int ldo, float scale, int causal);
 
+/* backward of molly_attn_fwd (what autograd runs through flash-attn's backward in the reference).  Recomputes P from
+ * Q, K and lse2; writes dQ [.., n_heads*hd], dK/dV [.., n_kv_heads*hd] (GQA group already summed), bitwise
+ * reproducible (no atomics).  delta_ws: B*n_heads*T floats of scratch. */
+int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                   const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo, const int* kv_hi,
+                   int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv, int ldo, int lddo,
+                   int lddq, int lddk, int lddv, float scale, int causal);
+
 /* ------------------------------------------------------------------------------------------------
  * layout / instruction probes (used by tests/test_gpu_probes.py to pin the gfx950 operand maps the
  * kernels rely on; not part of the product path) */

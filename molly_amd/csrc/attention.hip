@@ -27,13 +27,17 @@ struct AttnArgs {
     int causal;
 };
 
-// chunk swizzles (16-byte chunks inside one row of HD bf16): see DESIGN.md "attention LDS images"
-template <int HD> __device__ __forceinline__ int k_swz(int row, int ch) {
-    return HD == 128 ? (ch ^ (row & 15)) : (ch ^ ((row >> 1) & 7));
+// One LDS image serves row reads (ds_read_b128, MFMA operand with the tile row on the lane) AND transposed reads
+// (ds_read_b64_tr_b16, tile row as the contraction index) — guide T10 "One image for row reads AND transposed reads".
+// 16-byte chunk `ch` of row `row` is stored at chunk position dswz(row, ch):
+//   HD=128 (256-B rows = one bank row):  ch ^ (((row&3)<<2) | ((row>>2)&3))
+//   HD=64  (128-B rows, two per bank row): ch ^ ((((row>>1)&1)<<2) | ((row>>2)&3))
+// Both are conflict-free for the b128 row reads of 16 rows distinct mod 16 and for the 4-row x 16-column tr blocks.
+template <int HD> __device__ __forceinline__ int dswz(int row, int ch) {
+    return HD == 128 ? (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) : (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)));
 }
-template <int HD> __device__ __forceinline__ int v_swz(int row, int ch) {
-    return HD == 128 ? (ch ^ ((row & 3) << 2)) : (ch ^ (((row >> 1) & 1) << 2));
-}
+template <int HD> __device__ __forceinline__ int k_swz(int row, int ch) { return dswz<HD>(row, ch); }
+template <int HD> __device__ __forceinline__ int v_swz(int row, int ch) { return dswz<HD>(row, ch); }
 
 // stage a [64 keys][HD] tile with global_load_lds; LDS image is lane-linear, swizzle applied to the SOURCE chunk.
 template <int HD, bool IS_V>
@@ -223,6 +227,305 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+
+// ================================================================================================
+// backward.  Two kernels, both recomputing P from Q,K and the forward's LSE (no atomics, bitwise reproducible):
+//   dq kernel : grid like the forward (query blocks); per key tile  S^T = K Q^T, dP^T = V dO^T,
+//               dS^T = P^T ⊙ (dP^T − δ),  dQ^T += K^T dS^T          (K tile read by rows AND transposed)
+//   dkv kernel: grid over key blocks; per query tile  S = Q K^T, dP = dO V^T (key on the lane),
+//               dV^T += dO^T P,  dK^T += Q^T dS                      (Q/dO tiles read by rows AND transposed)
+// δ[q] = rowsum(dO ⊙ O) comes from a small preprocess kernel.  7 MFMA products instead of flash-bwd's 5, traded
+// for no cross-workgroup dQ reduction (guide Appendix B "Attention backward": dQ atomics are rate-limited).
+// ================================================================================================
+struct AttnBwdArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO;
+    const float* LSE; const float* delta;
+    bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+    const int* kv_lo; const int* kv_hi;
+    int T, nh, nkv, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float scale, scale_log2;
+    int causal;
+};
+
+// delta[b, head, q] = sum_d dO[q,d] * O[q,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
+                                                         float* __restrict__ delta, int B, int T, int nh, int hd, int ldo,
+                                                         int lddo) {
+    const int lanes = hd / 8;                         // threads per (token, head)
+    const long item = ((long)blockIdx.x * 256 + threadIdx.x) / lanes;
+    const int c = threadIdx.x % lanes;
+    const long total = (long)B * T * nh;
+    float s = 0.f;
+    if (item < total) {
+        const long tok = item / nh;
+        const int head = (int)(item % nh);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(O + (size_t)tok * ldo + head * hd + c * 8);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(dO + (size_t)tok * lddo + head * hd + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += bflo(a[e]) * bflo(d[e]) + bfhi(a[e]) * bfhi(d[e]);
+    }
+    for (int o = lanes >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (item < total && c == 0) {
+        const long tok = item / nh;
+        const int head = (int)(item % nh);
+        const long b = tok / T, t = tok % T;
+        delta[((size_t)b * nh + head) * T + t] = s;
+    }
+}
+
+// A operand (row index = d, contraction = tile row) of a 32x32x16 MFMA from a row-major [rows][HD] LDS tile via
+// ds_read_b64_tr_b16: returns tile[row0 + 16*sp + perm(j,h)][32*dt + (lane&31)] for j = 0..7.
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int row0, int sp, int dt, int lane) {
+    const int h = lane >> 5, gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
+    const int col = 32 * dt + gcol + 4 * gp;
+    const int rowa = row0 + 16 * sp + 4 * h + gq, rowb = rowa + 8;
+    const bf16_t* pa = tile + rowa * HD + dswz<HD>(rowa, col >> 3) * 8 + (col & 7);
+    const bf16_t* pb = tile + rowb * HD + dswz<HD>(rowb, col >> 3) * 8 + (col & 7);
+    const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
+    const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
+    return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+}
+// row-read fragment: tile[row][16*s + 8*h .. +7]
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t* tile, int row, int s, int h) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * HD + dswz<HD>(row, 2 * s + h) * 8);
+}
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int base) {
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pack_bf2(a[base + 2 * j], a[base + 2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);        // [2 stages][K tile | V tile]
+    constexpr int TILE = BKV * HD;
+    constexpr int NS = HD / 16, ND = HD / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qb = gridDim.x - 1 - blockIdx.x;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int kvh = head / (p.nh / p.nkv);
+    const int q0 = qb * BQ + wave * 32;
+    const int T = p.T;
+    const int lo = p.kv_lo ? p.kv_lo[b] : 0;
+    const int hi = p.kv_hi ? p.kv_hi[b] : T;
+    const bf16_t* Kb = p.K + (size_t)b * T * p.ldk + kvh * HD;
+    const bf16_t* Vb = p.V + (size_t)b * T * p.ldv + kvh * HD;
+
+    const int qi = q0 + r;
+    const int qrow = qi < T ? qi : T - 1;
+    bf16x8 qf[NS], dof[NS];
+    {
+        const bf16_t* qp = p.Q + ((size_t)b * T + qrow) * p.ldq + head * HD + 8 * h;
+        const bf16_t* dp = p.dO + ((size_t)b * T + qrow) * p.ldo + head * HD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+            dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+        }
+    }
+    float lse = p.LSE[((size_t)b * p.nh + head) * T + qrow];
+    lse = (lse == -INFINITY) ? 0.f : lse;
+    const float dlt = p.delta[((size_t)b * p.nh + head) * T + qrow];
+
+    f32x16 dq[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+
+    const int blk_q_last = min(qb * BQ + BQ - 1, T - 1);
+    const int kv_end = p.causal ? min(blk_q_last + 1, hi) : hi;
+    const int t_first = lo / BKV;
+    const int t_last = kv_end > lo ? (kv_end - 1) / BKV : t_first - 1;
+    if (t_last >= t_first) {
+        stage_kv<HD, false>(Kb, p.ldk, t_first * BKV, T, smem, wave, lane);
+        stage_kv<HD, true>(Vb, p.ldv, t_first * BKV, T, smem + TILE, wave, lane);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_first; t <= t_last; ++t) {
+        const bf16_t* sK = smem + cur * 2 * TILE;
+        const bf16_t* sV = sK + TILE;
+        if (t + 1 <= t_last) {
+            bf16_t* nK = smem + (cur ^ 1) * 2 * TILE;
+            stage_kv<HD, false>(Kb, p.ldk, (t + 1) * BKV, T, nK, wave, lane);
+            stage_kv<HD, true>(Vb, p.ldv, (t + 1) * BKV, T, nK + TILE, wave, lane);
+        }
+        const int k0 = t * BKV;
+        const bool skip = p.causal && (k0 > q0 + 31);
+        if (!skip) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sT, dpT;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sT[e] = 0.f; dpT[e] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, 32 * sub + r, s, h), qf[s], sT, 0, 0, 0);
+                    dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, 32 * sub + r, s, h), dof[s], dpT, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = k0 + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
+                    const float pr = ok ? exp2f(sT[e] * p.scale_log2 - lse) : 0.f;
+                    sT[e] = pr * (dpT[e] - dlt);                    // dS^T (unscaled)
+                }
+                const bf16x8 f0 = acc_to_frag(sT, 0), f1 = acc_to_frag(sT, 8);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sK, 32 * sub, 0, d, lane), f0, dq[d], 0, 0, 0);
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sK, 32 * sub, 1, d, lane), f1, dq[d], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (qi < T) {
+        bf16_t* op = p.dQ + ((size_t)b * T + qi) * p.lddq + head * HD;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = 32 * d + 8 * g4 + 4 * h;
+                *reinterpret_cast<u32x2*>(op + dd) =
+                    u32x2{pack_bf2(dq[d][4 * g4] * p.scale, dq[d][4 * g4 + 1] * p.scale),
+                          pack_bf2(dq[d][4 * g4 + 2] * p.scale, dq[d][4 * g4 + 3] * p.scale)};
+            }
+    }
+}
+
+// dK/dV: block = 128 keys (4 waves x 32 keys) of one (batch, kv head); loops over the group's query heads and query tiles.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TILE = BKV * HD;                               // 64 query rows per tile
+    constexpr int NS = HD / 16, ND = HD / 32;
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);          // [2 stages][Q tile | dO tile]
+    float* sStat = reinterpret_cast<float*>(smem_raw + 2 * 2 * TILE * sizeof(bf16_t));   // [2 stages][lse 64 | delta 64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int kb = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int group = p.nh / p.nkv;
+    const int T = p.T;
+    const int lo = p.kv_lo ? p.kv_lo[b] : 0;
+    const int hi = p.kv_hi ? p.kv_hi[b] : T;
+    const int key0 = kb * 128 + wave * 32;
+    const int key = key0 + r;
+    const int krow = key < T ? key : T - 1;
+    const bool key_ok = key >= lo && key < hi;
+
+    bf16x8 kf[NS], vf[NS];
+    {
+        const bf16_t* kp = p.K + ((size_t)b * T + krow) * p.ldk + kvh * HD + 8 * h;
+        const bf16_t* vp = p.V + ((size_t)b * T + krow) * p.ldv + kvh * HD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+            vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
+        }
+    }
+    f32x16 dk[ND], dv[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+
+    // query tiles this block needs: causal -> tiles whose last row >= first key of the block
+    const int nqt = (T + BKV - 1) / BKV;
+    const int qt_first = p.causal ? (kb * 128) / BKV : 0;
+    const int n_tiles = nqt > qt_first ? nqt - qt_first : 0;
+    const int total = n_tiles * group;                           // iteration it -> (head g, tile qt_first + j)
+
+    auto stage = [&](int it, int stg) {
+        const int g = it / n_tiles, qt = qt_first + it % n_tiles;
+        const int head = kvh * group + g;
+        const bf16_t* Qb = p.Q + (size_t)b * T * p.ldq + head * HD;
+        const bf16_t* Db = p.dO + (size_t)b * T * p.ldo + head * HD;
+        bf16_t* sQ = smem + stg * 2 * TILE;
+        stage_kv<HD, false>(Qb, p.ldq, qt * BKV, T, sQ, wave, lane);
+        stage_kv<HD, false>(Db, p.ldo, qt * BKV, T, sQ + TILE, wave, lane);
+        if (tid < 128) {
+            const int j = tid & 63;
+            int q = qt * BKV + j;
+            q = q < T ? q : T - 1;
+            const size_t idx = ((size_t)b * p.nh + head) * T + q;
+            float v = tid < 64 ? p.LSE[idx] : p.delta[idx];
+            if (tid < 64 && v == -INFINITY) v = 0.f;
+            sStat[stg * 128 + tid] = v;
+        }
+    };
+    if (total > 0) stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < total; ++it) {
+        if (it + 1 < total) stage(it + 1, cur ^ 1);
+        const int qt = qt_first + it % n_tiles;
+        const int qbase = qt * BKV;
+        const bf16_t* sQ = smem + cur * 2 * TILE;
+        const bf16_t* sD = sQ + TILE;
+        const float* sL = sStat + cur * 128;
+        const bool skip = p.causal && (qbase + BKV - 1 < key0);   // every query of the tile precedes this wave's keys
+        if (!skip) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16 sA, dpA;                                   // [q rows (regs), key cols (lane)]
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sA[e] = 0.f; dpA[e] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, 32 * sub + r, s, h), kf[s], sA, 0, 0, 0);
+                    dpA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sD, 32 * sub + r, s, h), vf[s], dpA, 0, 0, 0);
+                }
+                f32x16 pA;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ql = 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;   // row inside the tile
+                    const int q = qbase + ql;
+                    const bool ok = key_ok && q < T && (!p.causal || key <= q);
+                    const float pr = ok ? exp2f(sA[e] * p.scale_log2 - sL[ql]) : 0.f;
+                    pA[e] = pr;
+                    sA[e] = pr * (dpA[e] - sL[64 + ql]);                        // dS (unscaled)
+                }
+                const bf16x8 p0 = acc_to_frag(pA, 0), p1 = acc_to_frag(pA, 8);
+                const bf16x8 d0 = acc_to_frag(sA, 0), d1 = acc_to_frag(sA, 8);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 32 * sub, 0, d, lane), p0, dv[d], 0, 0, 0);
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 32 * sub, 1, d, lane), p1, dv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 32 * sub, 0, d, lane), d0, dk[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 32 * sub, 1, d, lane), d1, dk[d], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (key < T) {
+        bf16_t* kp = p.dK + ((size_t)b * T + key) * p.lddk + kvh * HD;
+        bf16_t* vp = p.dV + ((size_t)b * T + key) * p.lddv + kvh * HD;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = 32 * d + 8 * g4 + 4 * h;
+                *reinterpret_cast<u32x2*>(kp + dd) =
+                    u32x2{pack_bf2(dk[d][4 * g4] * p.scale, dk[d][4 * g4 + 1] * p.scale),
+                          pack_bf2(dk[d][4 * g4 + 2] * p.scale, dk[d][4 * g4 + 3] * p.scale)};
+                *reinterpret_cast<u32x2*>(vp + dd) = u32x2{pack_bf2(dv[d][4 * g4], dv[d][4 * g4 + 1]),
+                                                           pack_bf2(dv[d][4 * g4 + 2], dv[d][4 * g4 + 3])};
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
@@ -247,6 +550,47 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
         hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                              const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo,
+                              const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk,
+                              int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal) {
+    MOLLY_CHECK(head_dim == 128 || head_dim == 64, "attn_bwd: head_dim=%d not built (64 and 128 are)", head_dim);
+    MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_bwd: n_heads %% n_kv_heads != 0");
+    MOLLY_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 &&
+                    lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: row strides must be multiples of 8");
+    MOLLY_CHECK(delta_ws && lse2, "attn_bwd: lse2 and a delta workspace of B*n_heads*T floats are required");
+    MOLLY_CHECK(lddo == ldo, "attn_bwd: dO must share O's row stride");
+    hipStream_t st = (hipStream_t)stream;
+    const long items = (long)B * T * n_heads;
+    const int per_blk = 256 / (head_dim / 8);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + per_blk - 1) / per_blk)), dim3(256), 0, st,
+                       (const bf16_t*)O, (const bf16_t*)dO, delta_ws, B, T, n_heads, head_dim, ldo, lddo);
+    MOLLY_LAUNCH_CHECK();
+    AttnBwdArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, lse2, delta_ws,
+                  (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, kv_lo, kv_hi, T, n_heads, n_kv_heads, ldq, ldk, ldv, ldo,
+                  lddq, lddk, lddv, scale, scale * LOG2E, causal};
+    const size_t lds_dq = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
+    const size_t lds_dkv = lds_dq + 2 * 128 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
+        attr_set = true;
+    }
+    dim3 gq(cdiv(T, BQ), n_heads, B), gk(cdiv(T, 128), n_kv_heads, B);
+    if (head_dim == 128) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(256), lds_dkv, st, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), lds_dq, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), lds_dkv, st, p);
+    }
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

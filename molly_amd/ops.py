@@ -149,3 +149,56 @@ def attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, kv_lo=None, kv_hi=None, 
     lib().call("molly_attn_fwd", _stream(), q, k, v, out, lse, kv_lo, kv_hi, B, T, nh, nkv, hd, q.stride(0), k.stride(0),
                v.stride(0), out.stride(0), float(scale), int(causal))
     return out, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, causal, dq, dk, dv, kv_lo=None, kv_hi=None, delta_ws=None):
+    if delta_ws is None:
+        delta_ws = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    lib().call("molly_attn_bwd", _stream(), q, k, v, o, do, lse, delta_ws, dq, dk, dv, kv_lo, kv_hi, B, T, nh, nkv, hd,
+               q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
+               float(scale), int(causal))
+    return dq, dk, dv
+
+
+def ce_fwd_bwd(logits, labels, row_loss, scale, ignore_index=-100, write_grad=True):
+    rows, V = logits.shape
+    lib().call("molly_ce_fwd_bwd", _stream(), logits, labels, row_loss, scale, rows, V, logits.stride(0), ignore_index,
+               int(write_grad))
+
+
+def count_valid(labels, scale_out, count_out, ignore_index=-100):
+    lib().call("molly_count_valid", _stream(), labels, labels.numel(), ignore_index, scale_out, count_out)
+
+
+def sum_f32(x, out, scale=None, accumulate=False):
+    lib().call("molly_sum_f32", _stream(), x, x.numel(), scale, out, int(accumulate))
+
+
+def esm_embed(ids, word_emb, pos_emb, out, pos_ids, kv_len, pad_id, mask_id, token_dropout):
+    n_seq, K = ids.shape
+    H = word_emb.shape[1]
+    lib().call("molly_esm_embed", _stream(), ids, word_emb, pos_emb, out, pos_ids, kv_len, n_seq, K, H, pad_id, mask_id,
+               int(token_dropout))
+    return out
+
+
+def embed_bwd(g, order, seg_start, uid, n_unique, dE):
+    lib().call("molly_embed_bwd", _stream(), g, order, seg_start, uid, n_unique, dE, dE.shape[1], g.stride(0))
+
+
+def sqnorm(g, out, workspace, accumulate=False):
+    lib().call("molly_sqnorm_bf16", _stream(), g, g.numel(), workspace, out, int(accumulate))
+
+
+def clip_coef(norm_sq, max_norm, pre_scale, norm_out, coef_out):
+    lib().call("molly_clip_coef", _stream(), norm_sq, float(max_norm), float(pre_scale), norm_out, coef_out)
+
+
+def adamw_step(master, m, v, grad, param_out, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    lib().call("molly_adamw_step", _stream(), master, m, v, grad, param_out, master.numel(), float(lr), float(beta1),
+               float(beta2), float(eps), float(wd), int(step), grad_scale)
+
+
+def cast_f32_to_bf16(x, out):
+    lib().call("molly_cast_f32_to_bf16", _stream(), x, out, x.numel())
+    return out

