@@ -110,6 +110,11 @@ int molly_clip_coef(void* stream, const float* norm_sq, float max_norm, float pr
 int molly_adamw_step(void* stream, float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* param_out,
                      long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      const float* grad_scale_or_null);
+/* out[j] (+)= sum_r x[r, j] — bias gradient of the projector nn.Linear (reference src/model/omics_one.py:23-29).
+ * workspace: molly_colsum_parts(rows) * H floats. */
+int molly_colsum_parts(int rows);
+int molly_colsum_bf16(void* stream, const void* x, int rows, int H, int ld, void* out, int out_f32, int accumulate,
+                      float* workspace);
 int molly_cast_f32_to_bf16(void* stream, const float* in, void* out, long n);
 int molly_cast_bf16_to_f32(void* stream, const void* in, float* out, long n);
 

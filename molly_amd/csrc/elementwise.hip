@@ -701,6 +701,17 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = bf2f(in[i]);
 }
 
+// column sums of a bf16 matrix, stage 1: part[p][j] = sum over the p-th row slab of x[:, j]
+__global__ __launch_bounds__(256) void colsum_bf16_part_kernel(const bf16_t* __restrict__ x, int rows, int H, int ld,
+                                                               float* __restrict__ part, int rows_per_part) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= H) return;
+    const int r0 = blockIdx.y * rows_per_part, r1 = min(rows, r0 + rows_per_part);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * ld + j]);
+    part[(size_t)blockIdx.y * H + j] = s;
+}
+
 inline int grid_for(long items, int per_block = 256, int cap = 2048) {
     long g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -918,6 +929,20 @@ extern "C" int molly_adamw_step(void* stream, float* master, float* exp_avg, flo
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, master, exp_avg, exp_avg_sq,
                        (const bf16_t*)grad, (bf16_t*)param_out, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
                        grad_scale);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_colsum_parts(int rows) { return rows >= 1024 ? 64 : (rows >= 64 ? 16 : 1); }
+
+extern "C" int molly_colsum_bf16(void* stream, const void* x, int rows, int H, int ld, void* out, int out_f32,
+                                 int accumulate, float* workspace) {
+    MOLLY_CHECK(rows > 0 && H > 0 && workspace, "colsum: bad shape or missing workspace (molly_colsum_parts(rows)*H floats)");
+    const int np = molly_colsum_parts(rows);
+    const int rpp = cdiv(rows, np);
+    hipLaunchKernelGGL(colsum_bf16_part_kernel, dim3(cdiv(H, 256), np), dim3(256), 0, ST, (const bf16_t*)x, rows, H, ld,
+                       workspace, rpp);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, ST, workspace, np, H, H, out, out_f32, accumulate);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

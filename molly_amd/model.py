@@ -1,0 +1,451 @@
+"""`OmicsOne` — drop-in for the reference's multimodal wrapper (reference: src/model/omics_one.py:10-233).
+
+Same constructor, attributes, `forward` / `generate` / `process_omic_sequences` signatures, error behaviour and
+state-dict keys; the arithmetic runs in libmolly_hip.so.  Differences that are deliberate (and invisible in results):
+  * omic rows are grouped on the host in ONE pass and moved with ONE H2D copy per modality, instead of the per-row
+    `.to(device)` + device->host sync assert + per-span slice-copy launches (reference :104-118, :71-72, :93-97);
+  * the encoders' MaskedLM head, which the reference computes and discards (:75-91), is never run;
+  * lm_head + CE run fused and chunked (what Liger's fused-linear-CE does under --use_liger, reference src/train.py:130-132).
+
+Sub-models are parameter shells with HuggingFace names (`Qwen3ForCausalLM`, `EsmForMaskedLM` below) that callers attach
+exactly like the reference does (src/train.py:127,143,152); `prepare()` re-homes every tensor into flat HBM buffers.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import EncConfig, LlmConfig, OmicsModalConfig
+from .esm import EsmEngine
+from .params import FlatBuffer, enc_param_specs, is_no_decay, trainable_specs
+from .qwen3 import Qwen3Engine
+
+BF16 = torch.bfloat16
+
+
+class CausalLMOutputWithPast(dict):
+    """Minimal stand-in for HF's ModelOutput: attribute AND key access (HF Trainer reads outputs["loss"])."""
+
+    def __init__(self, loss=None, logits=None, past_key_values=None, hidden_states=None, attentions=None):
+        super().__init__()
+        for k, v in dict(loss=loss, logits=logits, past_key_values=past_key_values, hidden_states=hidden_states,
+                         attentions=attentions).items():
+            if v is not None:
+                self[k] = v
+        self.loss, self.logits, self.past_key_values = loss, logits, past_key_values
+        self.hidden_states, self.attentions = hidden_states, attentions
+
+
+# ---- parameter shells with the HF module tree (names = checkpoint keys; nn.Linear leaves for LoRA discovery,
+# reference src/utils/tools.py:354-361) -------------------------------------------------------------------------
+def _lin(i, o, bias):
+    m = nn.Linear(i, o, bias=bias, device="meta")
+    return m
+
+
+class _Shell(nn.Module):
+    def materialize(self, std=0.02, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        for n, p in list(self.named_parameters()):
+            shape = p.shape
+            if is_no_decay(n) and n.endswith("weight"):
+                val = torch.ones(shape)
+            elif n.endswith("bias"):
+                val = torch.zeros(shape)
+            else:
+                val = torch.randn(shape, generator=g) * std
+            mod, leaf = self, n
+            *path, leaf = n.split(".")
+            for k in path:
+                mod = getattr(mod, k) if not k.isdigit() else mod[int(k)]
+            setattr(mod, leaf, nn.Parameter(val))
+        return self
+
+
+class _Norm(nn.Module):
+    def __init__(self, n, bias=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, device="meta"))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(n, device="meta"))
+
+
+class Qwen3ForCausalLM(_Shell):
+    def __init__(self, config: LlmConfig):
+        super().__init__()
+        c = self.config = config
+        h, hd = c.hidden_size, c.head_dim
+        self.model = nn.Module()
+        self.model.embed_tokens = nn.Embedding(c.vocab_size, h, device="meta")
+        layers = []
+        for _ in range(c.num_hidden_layers):
+            l = nn.Module()
+            l.self_attn = nn.Module()
+            l.self_attn.q_proj = _lin(h, c.num_attention_heads * hd, False)
+            l.self_attn.k_proj = _lin(h, c.num_key_value_heads * hd, False)
+            l.self_attn.v_proj = _lin(h, c.num_key_value_heads * hd, False)
+            l.self_attn.o_proj = _lin(c.num_attention_heads * hd, h, False)
+            l.self_attn.q_norm, l.self_attn.k_norm = _Norm(hd), _Norm(hd)
+            l.mlp = nn.Module()
+            l.mlp.gate_proj, l.mlp.up_proj, l.mlp.down_proj = (_lin(h, c.intermediate_size, False),
+                                                               _lin(h, c.intermediate_size, False),
+                                                               _lin(c.intermediate_size, h, False))
+            l.input_layernorm, l.post_attention_layernorm = _Norm(h), _Norm(h)
+            layers.append(l)
+        self.model.layers = nn.ModuleList(layers)
+        self.model.norm = _Norm(h)
+        self.lm_head = _lin(h, c.vocab_size, False)
+        if c.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+
+    def materialize(self, std=0.02, seed=0):
+        super().materialize(std, seed)
+        if self.config.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+        else:
+            g = torch.Generator().manual_seed(seed + 1)
+            self.lm_head.weight = nn.Parameter(torch.randn(self.lm_head.weight.shape, generator=g) * std)
+        return self
+
+    @classmethod
+    def from_config(cls, config, seed=0):
+        return cls(config).materialize(seed=seed)
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+
+class EsmForMaskedLM(_Shell):
+    def __init__(self, config: EncConfig):
+        super().__init__()
+        c = self.config = config
+        he = c.hidden_size
+        self.esm = nn.Module()
+        self.esm.embeddings = nn.Module()
+        self.esm.embeddings.word_embeddings = nn.Embedding(c.vocab_size, he, device="meta")
+        if c.position_embedding_type == "absolute":
+            self.esm.embeddings.position_embeddings = nn.Embedding(c.max_position_embeddings, he, device="meta")
+        self.esm.encoder = nn.Module()
+        layers = []
+        for _ in range(c.num_hidden_layers):
+            l = nn.Module()
+            l.attention = nn.Module()
+            l.attention.self = nn.Module()
+            l.attention.self.query, l.attention.self.key, l.attention.self.value = (_lin(he, he, True), _lin(he, he, True),
+                                                                                    _lin(he, he, True))
+            l.attention.output = nn.Module()
+            l.attention.output.dense = _lin(he, he, True)
+            l.attention.LayerNorm = _Norm(he, bias=True)
+            l.intermediate = nn.Module()
+            l.intermediate.dense = _lin(he, c.intermediate_size, True)
+            l.output = nn.Module()
+            l.output.dense = _lin(c.intermediate_size, he, True)
+            l.LayerNorm = _Norm(he, bias=True)
+            layers.append(l)
+        self.esm.encoder.layer = nn.ModuleList(layers)
+        self.esm.encoder.emb_layer_norm_after = _Norm(he, bias=True)
+
+    @classmethod
+    def from_config(cls, config, seed=0):
+        return cls(config).materialize(seed=seed)
+
+
+# ---- host-side batch assembly -----------------------------------------------------------------------------------
+def group_omics(omic_ids, omic_info_list, K_cfg: Dict[str, int], T: int):
+    """reference: src/model/omics_one.py:99-118 + :93-97.  One pass over the batch on the host; returns per modality
+    (ids int64 [N,K], dst_rows int32 [N*K]) where dst_rows[i*K+j] = b*T + start+1+j for j < min(K_cfg, K), else -1.
+    'pad' rows skipped; unknown type -> ValueError; start == -1 keeps the row in the encoder batch but never scatters."""
+    out = {"dna_rna": ([], []), "protein": ([], [])}
+    for b in range(len(omic_info_list)):
+        rows = omic_ids[b]
+        for j, info in enumerate(omic_info_list[b]):
+            t = info["type"]
+            if t in ("dna", "rna"):
+                g = out["dna_rna"]
+            elif t == "protein":
+                g = out["protein"]
+            elif t == "pad":
+                continue
+            else:
+                raise ValueError(f"Unsupported omic type: {t}")
+            g[0].append(rows[j])
+            g[1].append((b, int(info["start"])))
+    res = {}
+    for name, (rows, where) in out.items():
+        if not rows:
+            res[name] = None
+            continue
+        ids = torch.stack([torch.as_tensor(r) for r in rows], 0).to(torch.int64).cpu()
+        N, K = ids.shape
+        k = min(K_cfg[name], K)
+        dst = np.full((N, K), -1, dtype=np.int32)
+        for i, (b, start) in enumerate(where):
+            if start == -1:
+                continue
+            if start + 1 + k > T:
+                raise RuntimeError(
+                    f"omic span at start={start} (+{k} tokens) exceeds the sequence length {T} "
+                    "(reference fails here too: src/model/omics_one.py:97 after truncation, SURVEY.md §0.4-6)")
+            dst[i, :k] = b * T + start + 1 + np.arange(k, dtype=np.int32)
+        res[name] = (ids, torch.from_numpy(dst.reshape(-1)))
+    return res
+
+
+def check_trailing_pad(ids: torch.Tensor, pad: int = 1):
+    """The attention kernel masks keys by a per-sequence valid LENGTH; the reference's mask is `ids != 1`
+    (src/model/omics_one.py:70).  They coincide when pads are trailing, which is what the reference tokenisation emits
+    (padding='max_length', src/dataset/omics_dataset.py:430-444).  Interior pads are rejected loudly."""
+    m = ids != pad
+    n_valid = m.sum(1)
+    last = torch.where(m.any(1), (m.long() * torch.arange(1, ids.shape[1] + 1)).max(1).values, torch.zeros_like(n_valid))
+    if not torch.equal(n_valid, last):
+        raise NotImplementedError("omic ids with pad tokens (id 1) in the interior of a sequence are not supported")
+
+
+def embed_backward_index(input_ids_flat: np.ndarray, overwritten: np.ndarray):
+    """Sorted index for the embedding-gradient kernel: rows grouped by token id, overwritten (placeholder) rows dropped
+    — their embedding rows get no gradient because the reference overwrites them in place (omics_one.py:97)."""
+    ids = input_ids_flat.astype(np.int64).copy()
+    keep = ~overwritten
+    rows = np.nonzero(keep)[0].astype(np.int32)
+    order = rows[np.argsort(ids[rows], kind="stable")]
+    sorted_ids = ids[order]
+    if len(order) == 0:
+        return order, np.zeros(1, np.int32), np.zeros(0, np.int64)
+    bounds = np.nonzero(np.diff(sorted_ids))[0] + 1
+    seg = np.concatenate([[0], bounds, [len(order)]]).astype(np.int32)
+    uid = sorted_ids[seg[:-1]]
+    return order, seg, uid
+
+
+# ---- the model ---------------------------------------------------------------------------------------------------
+class OmicsOne(nn.Module):
+    def __init__(self, config: OmicsModalConfig):
+        super().__init__()
+        self.text_config = config.text_config
+        self.dna_rna_config = config.dna_rna_config
+        self.protein_config = config.protein_config
+        self.model = None
+        self.dna_rna_model = None
+        self.protein_model = None
+        self.dna_rna_projector = nn.Linear(self.dna_rna_config.hidden_size, self.text_config.hidden_size)
+        self.dna_rna_project_token_num = config.dna_rna_project_token_num
+        self.protein_projector = nn.Linear(self.protein_config.hidden_size, self.text_config.hidden_size)
+        self.protein_project_token_num = config.protein_project_token_num
+        self._rt = None
+
+    # reference: src/model/omics_one.py:32-47 (ids are stored, never read)
+    def set_special_tokens(self, tokenizer):
+        for m in ("dna", "rna", "protein"):
+            for part in ("start", "end", "pad"):
+                setattr(self, f"{m}_{part}_token_id", tokenizer.convert_tokens_to_ids(f"<|{m}_{part}|>"))
+
+    # ---- runtime --------------------------------------------------------------------------------------------
+    def prepare(self, device="cuda", train_llm=True, train_mlp=True, ce_chunk_rows=16384, rope_table_dtype=BF16):
+        """Re-home all tensors into flat bf16 HBM buffers and build the HIP engines.  Trainable group = LLM + projectors
+        (reference default `--train-llm --train-mlp`, encoders frozen: src/utils/tools.py:313-338)."""
+        assert self.model is not None and self.dna_rna_model is not None and self.protein_model is not None, \
+            "attach .model / .dna_rna_model / .protein_model first (reference: src/train.py:127,143,152)"
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("molly_amd.OmicsOne runs on the GPU only; the CPU oracle lives in /oracle (tests only)")
+        sd = self.state_dict()
+        decay, no_decay = trainable_specs(self.text_config, self.dna_rna_config, self.protein_config)
+        P = FlatBuffer(decay + no_decay, dev, pad_to=8 * 64)
+        self.n_decay = P.offsets[no_decay[0][0]]
+        enc = {}
+        for pre, cfg in (("dna_rna_model.", self.dna_rna_config), ("protein_model.", self.protein_config)):
+            enc[pre] = FlatBuffer(enc_param_specs(cfg, pre), dev)
+        for buf in [P] + list(enc.values()):
+            for n, v in buf.views.items():
+                v.copy_(sd[n].to(dev))
+        # re-point module parameters at the flat views (so state_dict()/save keep working and see updates)
+        with torch.no_grad():
+            named = dict(self.named_parameters(remove_duplicate=False))
+            named.update(dict(self.named_buffers()))
+            for buf in [P] + list(enc.values()):
+                for n, v in buf.views.items():
+                    if n in named:
+                        named[n].data = v
+            if self.text_config.tie_word_embeddings:
+                self.model.lm_head.weight = self.model.model.embed_tokens.weight
+        G = P.like() if (train_llm or train_mlp) else None
+        rt = type("Runtime", (), {})()
+        rt.dev, rt.P, rt.G, rt.enc = dev, P, G, enc
+        rt.llm = Qwen3Engine(self.text_config, P, G, dev, ce_chunk_rows=ce_chunk_rows, rope_table_dtype=rope_table_dtype)
+        rt.dna = EsmEngine(self.dna_rna_config, enc["dna_rna_model."], dev, "dna_rna_model.", rope_table_dtype)
+        rt.prot = EsmEngine(self.protein_config, enc["protein_model."], dev, "protein_model.", rope_table_dtype)
+        rt.train_llm, rt.train_mlp = train_llm, train_mlp
+        if G is not None:
+            rt.llm.refresh_transposed_weights()
+        self._rt = rt
+        return self
+
+    def _runtime(self):
+        if self._rt is None:
+            self.prepare()
+        return self._rt
+
+    def _embed_and_inject(self, input_ids, omic_ids, omic_info_list, B, T, keep_for_backward):
+        """reference: src/model/omics_one.py:164-172 — token embeddings, then encoder -> projector -> overwrite."""
+        rt = self._rt
+        h = self.text_config.hidden_size
+        M = B * T
+        rt.llm.reserve(M, B, T, training=keep_for_backward)
+        hs = rt.llm.A[0]["x"] if keep_for_backward else rt.llm.x_out
+        ids_dev = input_ids.reshape(-1).to(rt.dev, non_blocking=True)
+        ops.copy_rows(rt.llm.embed, hs, M, src_idx64=ids_dev)
+        overwritten = np.zeros(M, dtype=bool)
+        saved = {}
+        if omic_ids is not None:
+            for i in range(len(omic_ids)):
+                assert len(omic_ids[i]) == len(omic_info_list[i]), \
+                    f"Mismatch in DNA count vs start_pos count at index {i}"
+            groups = group_omics(omic_ids, omic_info_list,
+                                 {"dna_rna": self.dna_rna_project_token_num, "protein": self.protein_project_token_num}, T)
+            for name, eng, proj in (("dna_rna", rt.dna, "dna_rna_projector"), ("protein", rt.prot, "protein_projector")):
+                if groups[name] is None:
+                    continue
+                ids, dst = groups[name]
+                assert bool((ids < eng.cfg.vocab_size).all()), \
+                    f"out-of-range token: {ids[ids >= eng.cfg.vocab_size]}"
+                check_trailing_pad(ids, 1)
+                try:
+                    enc_out = eng.forward(ids.to(rt.dev, non_blocking=True))
+                except Exception as e:  # reference re-wraps encoder failures (omics_one.py:89-90)
+                    raise RuntimeError(f"Error processing omic sequences: {e}")
+                emb = ops.gemm_nt(enc_out, rt.P.views[proj + ".weight"], bias=rt.P.views[proj + ".bias"])
+                dst_dev = dst.to(rt.dev, non_blocking=True)
+                ops.copy_rows(emb, hs, emb.shape[0], dst_idx32=dst_dev)
+                valid = dst.numpy() >= 0
+                overwritten[dst.numpy()[valid]] = True
+                saved[name] = (enc_out, dst_dev, proj)
+        return hs, overwritten, saved
+
+    @staticmethod
+    def _kv_range(attention_mask, B, T, dev):
+        """attention_mask [B,T] of 0/1 with contiguous ones (right- or left-padded) -> per-sample [lo, hi)."""
+        if attention_mask is None:
+            return None, None
+        m = attention_mask.cpu().bool()
+        if bool(m.all()):
+            return None, None
+        idx = torch.arange(T)
+        lo = torch.where(m.any(1), (~m).long().cumprod(1).sum(1), torch.zeros(B, dtype=torch.long))
+        n = m.sum(1)
+        hi = lo + n
+        span = (idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None])
+        if not torch.equal(span, m):
+            raise NotImplementedError("attention_mask must be one contiguous run of ones per sample (right- or left-padded)")
+        return lo.to(torch.int32).to(dev), hi.to(torch.int32).to(dev)
+
+    def forward_backward(self, input_ids, attention_mask, omic_ids, omic_info_list, labels, accumulate=False):
+        """One training micro-step on the native path: forward + loss + full backward into the flat grad buffer.
+        Returns the loss as a device scalar (no host sync).  Loss semantics = per-micro-batch token mean
+        (HF:loss/loss_utils.py:49-71 with num_items_in_batch=None: the reference swallows it)."""
+        rt = self._runtime()
+        B, T = input_ids.shape
+        M = B * T
+        lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
+        hs, overwritten, saved = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, True)
+        shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
+        shifted = shifted.to(rt.dev, non_blocking=True)
+        rt.llm.forward(hs, B, T, lo, hi, labels_shifted=shifted, training=True)
+        d_hs = rt.llm.loss_and_backward(accumulate=accumulate)
+        # ---- gradient of the input embeddings: text rows -> embed_tokens, omic rows -> projector
+        if rt.train_llm:
+            order, seg, uid = embed_backward_index(input_ids.reshape(-1).cpu().numpy(), overwritten)
+            if len(uid):
+                ops.embed_bwd(d_hs, torch.from_numpy(order).to(rt.dev), torch.from_numpy(seg).to(rt.dev),
+                              torch.from_numpy(uid).to(rt.dev), len(uid), rt.llm.d_embed)
+        if rt.train_mlp:
+            for name, (enc_out, dst_dev, proj) in saved.items():
+                N = enc_out.shape[0]
+                d_emb = torch.zeros(N, self.text_config.hidden_size, dtype=BF16, device=rt.dev)
+                ops.copy_rows(d_hs, d_emb, N, src_idx32=dst_dev)
+                Np = (N + 63) // 64 * 64
+                ta = torch.zeros(d_emb.shape[1], Np, dtype=BF16, device=rt.dev)
+                tb = torch.zeros(enc_out.shape[1], Np, dtype=BF16, device=rt.dev)
+                ops.transpose(d_emb, ta[:, :N])
+                ops.transpose(enc_out, tb[:, :N])
+                ops.gemm_nt(ta, tb, out=rt.G.views[proj + ".weight"], accumulate=accumulate)
+                ops.colsum(d_emb, rt.G.views[proj + ".bias"], accumulate=accumulate)
+        if not accumulate:
+            # projector of a modality absent from this batch still owns grad slots: they must read as zero
+            for name, proj in (("dna_rna", "dna_rna_projector"), ("protein", "protein_projector")):
+                if name not in saved:
+                    rt.G.views[proj + ".weight"].zero_()
+                    rt.G.views[proj + ".bias"].zero_()
+        return rt.llm.scal[2]
+
+    def process_omic_sequences(self, hidden_states, omic_ids_list, omic_info_list, device=None):
+        """reference: src/model/omics_one.py:49-136 — in-place overwrite of `hidden_states` [B,T,h]; returns it."""
+        rt = self._runtime()
+        B, T, h = hidden_states.shape
+        groups = group_omics(omic_ids_list, omic_info_list,
+                             {"dna_rna": self.dna_rna_project_token_num, "protein": self.protein_project_token_num}, T)
+        flat = hidden_states.view(B * T, h)
+        for name, eng, proj in (("dna_rna", rt.dna, "dna_rna_projector"), ("protein", rt.prot, "protein_projector")):
+            if groups[name] is None:
+                continue
+            ids, dst = groups[name]
+            assert bool((ids < eng.cfg.vocab_size).all()), f"out-of-range token: {ids[ids >= eng.cfg.vocab_size]}"
+            check_trailing_pad(ids, 1)
+            try:
+                enc_out = eng.forward(ids.to(rt.dev))
+            except Exception as e:
+                raise RuntimeError(f"Error processing omic sequences: {e}")
+            emb = ops.gemm_nt(enc_out, rt.P.views[proj + ".weight"], bias=rt.P.views[proj + ".bias"])
+            ops.copy_rows(emb, flat, emb.shape[0], dst_idx32=dst.to(rt.dev))
+        return hidden_states
+
+    def forward(self, input_ids=None, attention_mask=None, omic_ids=None, omic_info_list=None, labels=None,
+                past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, task_label=None, task_num=None, **kwargs):
+        """reference: src/model/omics_one.py:138-185.  Inference / evaluation forward: returns logits (and the loss when
+        labels are given).  Training goes through `forward_backward` (the native fused path) — under
+        torch.is_grad_enabled() with labels this method runs it and returns a loss whose .backward() hands the already
+        computed flat gradients to autograd, so HF-Trainer-style loops keep working."""
+        rt = self._runtime()
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused path")
+        B, T = input_ids.shape
+        if labels is not None and torch.is_grad_enabled() and rt.G is not None:
+            loss = self.forward_backward(input_ids, attention_mask, omic_ids, omic_info_list, labels)
+            return CausalLMOutputWithPast(loss=_attach_grads(self, loss))
+        lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
+        hs, _, _ = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, False)
+        shifted = None
+        if labels is not None:
+            shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous().to(rt.dev)
+        loss, logits = rt.llm.forward(hs, B, T, lo, hi, labels_shifted=shifted, training=False, return_logits=True)
+        return CausalLMOutputWithPast(loss=loss.clone() if loss is not None else None,
+                                      logits=logits.view(B, T, -1))
+
+
+class _GradHandOff(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss, model, *params):
+        ctx.model = model
+        ctx.n = len(params)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        rt = ctx.model._rt
+        grads = []
+        named = dict(ctx.model.named_parameters())
+        for n, p in named.items():
+            if p.requires_grad and n in rt.G.views:
+                grads.append(rt.G.views[n].to(p.dtype) * gout)
+        return (None, None, *grads)
+
+
+def _attach_grads(model, loss):
+    params = [p for n, p in model.named_parameters() if p.requires_grad and n in model._rt.G.views]
+    return _GradHandOff.apply(loss, model, *params)

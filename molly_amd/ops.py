@@ -146,6 +146,8 @@ def attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, kv_lo=None, kv_hi=None, 
         out = torch.empty((B * T, nh * hd), dtype=BF16, device=q.device)
     if lse is None:
         lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    elif lse is False:          # caller does not need the log-sum-exp (forward-only encoders)
+        lse = None
     lib().call("molly_attn_fwd", _stream(), q, k, v, out, lse, kv_lo, kv_hi, B, T, nh, nkv, hd, q.stride(0), k.stride(0),
                v.stride(0), out.stride(0), float(scale), int(causal))
     return out, lse
@@ -201,4 +203,14 @@ def adamw_step(master, m, v, grad, param_out, lr, beta1, beta2, eps, wd, step, g
 
 def cast_f32_to_bf16(x, out):
     lib().call("molly_cast_f32_to_bf16", _stream(), x, out, x.numel())
+    return out
+
+
+def colsum(x, out, accumulate=False, workspace=None):
+    rows, H = x.shape
+    npart = lib().query("molly_colsum_parts", rows)
+    if workspace is None:
+        workspace = torch.empty(npart * H, dtype=torch.float32, device=x.device)
+    lib().call("molly_colsum_bf16", _stream(), x, rows, H, x.stride(0), out, int(out.dtype == torch.float32),
+               int(accumulate), workspace)
     return out

@@ -1,0 +1,258 @@
+"""Qwen3 decoder forward/backward on the HIP kernels.
+
+Restates (without importing) what the reference executes through HuggingFace + Liger + flash-attn when
+`OmicsOne.forward` calls `self.model(inputs_embeds=..., labels=...)` (reference: src/model/omics_one.py:175-184):
+HF:models/qwen3/modeling_qwen3.py:294-323 (layer), :240-281 (attention), :76-83 (MLP), :367-425 (model),
+:448-507 + HF:loss/loss_utils.py:49-71 (lm_head + shifted CE).  The backward is hand-scheduled: there is no
+autograd graph and no tracing; every saved activation lives in a pre-allocated HBM slab.
+
+GEMM forms: forward  y = x W^T          -> NT on (x, W)
+                        dgrad    dx = dy W           -> NT on (dy, W^T copy)       [W^T refreshed after each optimizer step]
+                        wgrad    dW = dy^T x         -> NT on (dy^T, x^T)          [transposed on the fly]
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .config import LlmConfig
+from .params import FlatBuffer
+
+BF16 = torch.bfloat16
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+def rope_tables(n_pos: int, head_dim: int, theta: float, device, table_dtype=BF16):
+    """cos/sin [n_pos, head_dim/2] fp32.  HF computes them in fp32 and casts to the model dtype
+    (HF:models/qwen3/modeling_qwen3.py:126-137) — `table_dtype` reproduces that rounding."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = torch.arange(n_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return (fr.cos().to(table_dtype).float().to(device).contiguous(),
+            fr.sin().to(table_dtype).float().to(device).contiguous())
+
+
+class Qwen3Engine:
+    def __init__(self, cfg: LlmConfig, params: FlatBuffer, grads: Optional[FlatBuffer], device, prefix: str = "model.",
+                 ce_chunk_rows: int = 16384, rope_table_dtype=BF16):
+        self.cfg, self.P, self.G, self.dev, self.pre = cfg, params, grads, device, prefix
+        self.h, self.hd = cfg.hidden_size, cfg.head_dim
+        self.nh, self.nkv, self.ff, self.V, self.L = (cfg.num_attention_heads, cfg.num_key_value_heads,
+                                                      cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers)
+        self.nqkv = (self.nh + 2 * self.nkv) * self.hd
+        self.nqk = (self.nh + self.nkv) * self.hd
+        self.ce_chunk_rows = ce_chunk_rows
+        self.rope_table_dtype = rope_table_dtype
+        self.cap = 0
+        self._wt: Optional[FlatBuffer] = None
+        self._views()
+
+    # ---- weight views ---------------------------------------------------------------------------------------
+    def _layer_views(self, buf: FlatBuffer, i: int):
+        lp = f"{self.pre}model.layers.{i}."
+        return dict(
+            qkv=buf.span(lp + "self_attn.q_proj.weight", lp + "self_attn.v_proj.weight", self.h),
+            o=buf.views[lp + "self_attn.o_proj.weight"],
+            gu=buf.span(lp + "mlp.gate_proj.weight", lp + "mlp.up_proj.weight", self.h),
+            down=buf.views[lp + "mlp.down_proj.weight"],
+            ln1=buf.views[lp + "input_layernorm.weight"], ln2=buf.views[lp + "post_attention_layernorm.weight"],
+            qn=buf.views[lp + "self_attn.q_norm.weight"], kn=buf.views[lp + "self_attn.k_norm.weight"],
+        )
+
+    def _views(self):
+        self.W = [self._layer_views(self.P, i) for i in range(self.L)]
+        self.embed = self.P.views[self.pre + "model.embed_tokens.weight"]
+        self.head = self.embed if self.cfg.tie_word_embeddings else self.P.views[self.pre + "lm_head.weight"]
+        self.norm_w = self.P.views[self.pre + "model.norm.weight"]
+        if self.G is not None:
+            self.dW = [self._layer_views(self.G, i) for i in range(self.L)]
+            self.d_embed = self.G.views[self.pre + "model.embed_tokens.weight"]
+            self.d_head = self.d_embed if self.cfg.tie_word_embeddings else self.G.views[self.pre + "lm_head.weight"]
+            self.d_norm_w = self.G.views[self.pre + "model.norm.weight"]
+
+    def refresh_transposed_weights(self):
+        """W^T copies used by the dgrad GEMMs; call after every optimizer step (weights changed)."""
+        if self._wt is None:
+            specs = []
+            for i in range(self.L):
+                specs += [(f"{i}.qkv", (self.h, self.nqkv)), (f"{i}.o", (self.nh * self.hd, self.h)),
+                          (f"{i}.gu", (self.h, 2 * self.ff)), (f"{i}.down", (self.ff, self.h))]
+            specs.append(("head", (self.h, self.V)))
+            self._wt = FlatBuffer(specs, self.dev)
+        for i, w in enumerate(self.W):
+            for k in ("qkv", "o", "gu", "down"):
+                ops.transpose(w[k], self._wt.views[f"{i}.{k}"])
+        ops.transpose(self.head, self._wt.views["head"])
+
+    # ---- activation slabs -----------------------------------------------------------------------------------
+    def reserve(self, M: int, B: int, T: int, training: bool):
+        """Allocate (once) every buffer a forward/backward over M = B*T tokens needs."""
+        if self.cap >= M and getattr(self, "_train_alloc", False) >= training and self.BT == (B, T):
+            return
+        dev, h, ff = self.dev, self.h, self.ff
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        self.cap, self.BT, self._train_alloc = M, (B, T), training
+        nl = self.L if training else 1                    # inference keeps one layer's worth of scratch
+        self.A = []
+        for _ in range(nl):
+            self.A.append(dict(x=e(M, h), xn=e(M, h), qkv=e(M, self.nqkv), qk=e(M, self.nqk), attn=e(M, self.nh * self.hd),
+                               lse=e(B, self.nh, T, dt=torch.float32), x2=e(M, h), xn2=e(M, h), gu=e(M, 2 * ff), act=e(M, ff)))
+        self.x_out = e(M, h)
+        self.hn = e(M, h)
+        self.C = min(self.ce_chunk_rows, M)
+        self.logits = e(self.C, self.V)
+        self.row_loss = e(M, dt=torch.float32)
+        self.scal = torch.zeros(8, dtype=torch.float32, device=dev)   # [0]=1/n_valid [1]=n_valid [2]=loss
+        self.cos, self.sin = rope_tables(T, self.hd, self.cfg.rope_theta, dev, self.rope_table_dtype)
+        if training:
+            Mp = _ceil(M, 64)
+            Cp = _ceil(self.C, 64)
+            widest = max(2 * ff, self.nqkv, self.nh * self.hd, h)
+            self.tA = torch.zeros(widest * Mp, dtype=BF16, device=dev)      # dy^T scratch (zero pad columns stay zero)
+            self.tB = torch.zeros(max(ff, h, self.nh * self.hd) * Mp, dtype=BF16, device=dev)   # x^T scratch
+            self.tL = torch.zeros(self.V * Cp, dtype=BF16, device=dev)      # dlogits^T scratch
+            self.d_a = e(M, h); self.d_b = e(M, h); self.d_c = e(M, h)      # residual-stream gradients (ping-pong)
+            self.d_act = e(M, ff); self.d_gu = e(M, 2 * ff)
+            self.d_attn = e(M, self.nh * self.hd); self.d_qkv = e(M, self.nqkv); self.d_qk = e(M, self.nqk)
+            self.delta = e(B, self.nh, T, dt=torch.float32)
+            nb1 = ops.lib().query("molly_rmsnorm_bwd_blocks", M)
+            nb2 = ops.lib().query("molly_norm_rope_bwd_blocks")
+            self.ws = torch.empty(max(nb1 * h, nb2 * 2 * self.hd), dtype=torch.float32, device=dev)
+            self.Mp, self.Cp = Mp, Cp
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward(self, inputs_embeds: torch.Tensor, B: int, T: int, kv_lo=None, kv_hi=None,
+                labels_shifted: Optional[torch.Tensor] = None, training: bool = True, return_logits: bool = False):
+        """inputs_embeds [B*T, h] bf16.  labels_shifted int64 [B*T]: row r is scored against labels_shifted[r]
+        (HF shift: pad one ignore column then drop the first, HF:loss/loss_utils.py:60-63).
+        Returns (loss device-scalar view or None, logits [B*T, V] or None)."""
+        cfg, M = self.cfg, B * T
+        self.reserve(M, B, T, training)
+        self.B_, self.T_, self.kv = B, T, (kv_lo, kv_hi)
+        x = inputs_embeds
+        for i in range(self.L):
+            a = self.A[i if training else 0]
+            w = self.W[i]
+            if training:
+                a["x"].copy_(x) if x.data_ptr() != a["x"].data_ptr() else None
+                xin = a["x"]
+            else:
+                xin = x
+            ops.rmsnorm_fwd(xin, w["ln1"], cfg.rms_norm_eps, out=a["xn"])
+            ops.gemm_nt(a["xn"], w["qkv"], out=a["qkv"])
+            ops.norm_rope_fwd(a["qkv"], a["qk"], self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos, self.sin,
+                              eps=cfg.rms_norm_eps)
+            ops.attn_fwd(a["qk"][:, :self.nh * self.hd], a["qk"][:, self.nh * self.hd:], a["qkv"][:, self.nqk:], B, T,
+                         self.nh, self.nkv, self.hd, self.hd ** -0.5, True, kv_lo, kv_hi, out=a["attn"], lse=a["lse"])
+            ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=xin)
+            ops.rmsnorm_fwd(a["x2"], w["ln2"], cfg.rms_norm_eps, out=a["xn2"])
+            ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
+            ops.swiglu_fwd(a["gu"], out=a["act"])
+            nxt = self.A[i + 1]["x"] if (training and i + 1 < self.L) else self.x_out
+            ops.gemm_nt(a["act"], w["down"], out=nxt, res=a["x2"])
+            x = nxt
+        ops.rmsnorm_fwd(self.x_out, self.norm_w, cfg.rms_norm_eps, out=self.hn)
+        loss = None
+        logits_all = None
+        if return_logits:
+            logits_all = torch.empty(M, self.V, dtype=BF16, device=self.dev)
+            for c0 in range(0, M, self.C):
+                c1 = min(M, c0 + self.C)
+                ops.gemm_nt(self.hn[c0:c1], self.head, out=logits_all[c0:c1])
+        if labels_shifted is not None:
+            self.labels = labels_shifted
+            ops.count_valid(labels_shifted, self.scal[0:1], self.scal[1:2])
+            if not (training and self.G is not None):
+                # loss only (eval): logits chunk by chunk, no gradient written
+                for c0 in range(0, M, self.C):
+                    c1 = min(M, c0 + self.C)
+                    lg = logits_all[c0:c1] if logits_all is not None else ops.gemm_nt(self.hn[c0:c1], self.head,
+                                                                                       out=self.logits[:c1 - c0])
+                    ops.ce_fwd_bwd(lg, labels_shifted[c0:c1], self.row_loss[c0:c1], self.scal[0:1], write_grad=False)
+                ops.sum_f32(self.row_loss[:M], self.scal[2:3], scale=self.scal[0:1])
+                loss = self.scal[2]
+        return loss, logits_all
+
+    # ---- helpers ---------------------------------------------------------------------------------------------
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, scratch_a=None, ldp=None):
+        """dw[N,K] (+)= dy[M,N]^T x[M,K] as an NT GEMM over transposed copies (K-dim = tokens, zero-padded to 64)."""
+        M, N = dy.shape
+        K = x.shape[1]
+        ldp = ldp or self.Mp
+        ta = (scratch_a if scratch_a is not None else self.tA)[:N * ldp].view(N, ldp)
+        tb = self.tB[:K * ldp].view(K, ldp)
+        ops.transpose(dy, ta[:, :M])
+        ops.transpose(x, tb[:, :M])
+        ops.gemm_nt(ta, tb, out=dw, accumulate=accumulate)
+
+    # ---- fused lm-head + CE forward/backward, then the decoder backward ---------------------------------------
+    def loss_and_backward(self, accumulate: bool = False) -> torch.Tensor:
+        """Runs lm_head + shifted CE (forward AND backward, chunked so [M,V] logits never exist at once: the role
+        Liger's fused-linear-CE plays in the reference, src/train.py:130-132) and the whole decoder backward.
+        Weight gradients land in the flat grad buffer (`accumulate` = add to what is there: GA micro-steps > 0).
+        Returns d(inputs_embeds) [M, h]; the loss is in self.scal[2]."""
+        cfg, B, T = self.cfg, self.B_, self.T_
+        M = B * T
+        kv_lo, kv_hi = self.kv
+        wt = self._wt.views
+        dh = self.d_a
+        first = True
+        for c0 in range(0, M, self.C):
+            c1 = min(M, c0 + self.C)
+            n = c1 - c0
+            lg = self.logits[:n]
+            ops.gemm_nt(self.hn[c0:c1], self.head, out=lg)
+            ops.ce_fwd_bwd(lg, self.labels[c0:c1], self.row_loss[c0:c1], self.scal[0:1], write_grad=True)
+            ops.gemm_nt(lg, wt["head"], out=dh[c0:c1])                                # d(hn) = dlogits · E
+            # dE (+)= dlogits^T · hn   (tied embeddings: the gather-gradient is added later by the caller)
+            tl = self.tL[:self.V * self.Cp].view(self.V, self.Cp)
+            if n < self.Cp:
+                tl[:, n:].zero_()
+            ops.transpose(lg, tl[:, :n])
+            tb = self.tB[:self.h * self.Cp].view(self.h, self.Cp)
+            if n < self.Cp:
+                tb[:, n:].zero_()
+            ops.transpose(self.hn[c0:c1], tb[:, :n])
+            ops.gemm_nt(tl, tb, out=self.d_head, accumulate=accumulate or not first)
+            first = False
+        if self.C < M or self.Cp != self.Mp:
+            self.tB.zero_()                                                           # restore the zero-pad invariant
+        ops.sum_f32(self.row_loss[:M], self.scal[2:3], scale=self.scal[0:1])
+        # final norm backward
+        dx = self.d_b
+        ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, self.d_norm_w, cfg.rms_norm_eps, dx=dx, dw_accumulate=accumulate,
+                        workspace=self.ws)
+        spare = [self.d_a, self.d_c]
+        for i in reversed(range(self.L)):
+            a, w, g = self.A[i], self.W[i], self.dW[i]
+            # ---- MLP: x3 = x2 + down(silu(g)*u)
+            ops.gemm_nt(dx, wt[f"{i}.down"], out=self.d_act)
+            self._wgrad(dx, a["act"], g["down"], accumulate)
+            ops.swiglu_bwd(a["gu"], self.d_act, self.d_gu)
+            dxn2 = spare[0]
+            ops.gemm_nt(self.d_gu, wt[f"{i}.gu"], out=dxn2)
+            self._wgrad(self.d_gu, a["xn2"], g["gu"], accumulate)
+            dx2 = spare[1]
+            ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, g["ln2"], cfg.rms_norm_eps, dres=dx, dx=dx2,
+                            dw_accumulate=accumulate, workspace=self.ws)
+            # ---- attention: x2 = x + o_proj(attn)
+            ops.gemm_nt(dx2, wt[f"{i}.o"], out=self.d_attn)
+            self._wgrad(dx2, a["attn"], g["o"], accumulate)
+            nq = self.nh * self.hd
+            ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
+                         self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
+                         self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta)
+            ops.norm_rope_bwd(a["qkv"], self.d_qk, self.d_qkv, self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos,
+                              self.sin, g["qn"], g["kn"], eps=cfg.rms_norm_eps, dw_accumulate=accumulate,
+                              workspace=self.ws)
+            dxn = spare[0]
+            ops.gemm_nt(self.d_qkv, wt[f"{i}.qkv"], out=dxn)
+            self._wgrad(self.d_qkv, a["xn"], g["qkv"], accumulate)
+            ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, g["ln1"], cfg.rms_norm_eps, dres=dx2, dx=dx,
+                            dw_accumulate=accumulate, workspace=self.ws)
+        return dx
