@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training tokens/s of Molly-1.7B (Qwen3-1.7B + NT-500M + ESM2-650M), bf16, on N MI355X.
+
+One step = one pass of the hot path over one synthetic mixed protein/text batch: ESM-2 encoder forward -> projector ->
+injection -> Qwen3 forward -> fused lm_head+CE -> full backward -> ZeRO-2 step (reduce-scatter, clip, AdamW on the fp32
+shard, all-gather).  Nothing is skipped or cached inside the timed region.  Workload = BASELINE.json configs[1]
+(SURVEY.md §8d C2): seq_len 2048 text + one 512-residue protein span per sample, B samples per GPU, GA=1, LLM +
+projectors trainable, encoders frozen.  Weak scaling: per-GPU work is fixed as N grows.
+
+    python bench.py [--gpus N --steps K --warmup W]        # N>1: launched by torch.distributed.run, one rank per GPU
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (the bf16 MFMA
+GEMM) measured with HIP events inside the timed region, and `cpu_baseline` = the CPU oracle timed on the host cores.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def algorithmic_flops_per_token(cfg, T):
+    """F_llm = 2*P_mm + 4*L*nh*hd*(T/2) per token forward; training = 3x."""
+    h, hd, nh, nkv, ff, L, V = (cfg.hidden_size, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads,
+                                cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size)
+    p_mm = L * (h * nh * hd + 2 * h * nkv * hd + nh * hd * h + 3 * h * ff) + h * V
+    return 3 * (2 * p_mm + 4 * L * nh * hd * (T / 2))
+
+
+def enc_flops_per_token(cfg, K):
+    he, ffe, Le = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    return 2 * Le * (4 * he * he + 2 * he * ffe) + 4 * Le * he * K
+
+
+def cpu_baseline(seconds_budget=40.0):
+    """The CPU oracle (oracle/molly_ref.py, `kind: port`) on a bounded sample of the same workload: Molly-1.7B shapes in
+    fp32, B=1, T=256, one 64-residue protein span, fwd + bwd + AdamW; tokens/s of the 2nd step."""
+    from oracle import molly_ref as R
+    from molly_amd import config as C
+    from molly_amd.synth import synth_batch
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    llm_c, prot_c = C.qwen3("1.7b"), C.esm2_650m()
+    llm = R.LlmCfg(**{k: getattr(llm_c, k) for k in R.LlmCfg.__dataclass_fields__})
+    prot = R.EncCfg(**{k: getattr(prot_c, k) for k in R.EncCfg.__dataclass_fields__})
+    from molly_amd.params import enc_param_specs, llm_norm_specs, llm_param_specs
+    sd = {}
+    for n, shp in llm_param_specs(llm_c) + llm_norm_specs(llm_c):
+        t = torch.empty(shp)
+        t.fill_(1.0) if "norm" in n else t.normal_(0, 0.02)
+        sd[n] = t.requires_grad_(True)
+    for n, shp in enc_param_specs(prot_c, "protein_model."):
+        t = torch.empty(shp)
+        (t.fill_(1.0) if ("LayerNorm" in n or "layer_norm" in n) and n.endswith("weight") else
+         (t.zero_() if n.endswith("bias") else t.normal_(0, 0.02)))
+        sd[n] = t
+    sd["protein_projector.weight"] = torch.empty(llm_c.hidden_size, prot_c.hidden_size).normal_(0, 0.02).requires_grad_(True)
+    sd["protein_projector.bias"] = torch.zeros(llm_c.hidden_size, requires_grad=True)
+    T, K = 256, 64
+    batch = synth_batch(1, T, [("protein", K)], seed=42)
+    params = {n: p for n, p in sd.items() if p.requires_grad}
+    state = {n: (torch.zeros_like(p), torch.zeros_like(p)) for n, p in params.items()}
+    times = []
+    t_start = time.time()
+    for step in (1, 2):
+        t0 = time.time()
+        loss, _ = R.omics_forward(sd, llm, None, prot, batch, {"dna_rna": K, "protein": K})
+        loss.backward()
+        with torch.no_grad():
+            _, coef = R.clip_coef([p.grad for p in params.values()], 1.0)
+            for n, p in params.items():
+                R.adamw_step(p, p.grad * coef, state[n][0], state[n][1], step, 3e-5, 0.0 if R.is_no_decay(n) else 1e-2)
+                p.grad = None
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    dt = times[-1]
+    return {"value": round(T / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"Molly-1.7B shapes fp32, B=1 T={T} protein K={K}, fwd+bwd+AdamW, step {len(times)} of {len(times)} "
+                      f"({dt:.1f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU per step")
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--k-protein", type=int, default=512)
+    ap.add_argument("--model", default="1.7b")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import molly_amd
+    from molly_amd import config as C, ops
+    from molly_amd.synth import synth_batch
+    from molly_amd.trainer import Zero2Optimizer
+
+    cfg = C.molly(args.model, k_tokens=args.k_protein)
+    m = molly_amd.OmicsOne(cfg)
+    m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)
+    m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
+    m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
+    torch.manual_seed(1234)
+    m.prepare(dev, random_init_seed=1234)              # same seed on every rank: replicas start identical
+    rt = m._rt
+    opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0)
+
+    B, T, K = args.batch, args.seq, args.k_protein
+    batches = [synth_batch(B, T, [("protein", K)], seed=42 + rank + 1000 * i) for i in range(4)]
+
+    def step(i):
+        b = batches[i % len(batches)]
+        loss = m.forward_backward(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"], b["labels"])
+        opt.step(lr=3e-5)
+        rt.llm.refresh_transposed_weights()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.GEMM_PROFILE = []
+    step_ev = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+        loss = step(args.warmup + i)
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        step_ev.append((e0, e1))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        tokens = world * B * T * args.steps
+        gemm_ms = sum(a.elapsed_time(b) for a, b, _ in prof)
+        gemm_fl = sum(f for _, _, f in prof)
+        n_launch = len(prof)
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        step_ms = [a.elapsed_time(b) for a, b in step_ev]
+        flops_step = B * (T * algorithmic_flops_per_token(cfg.text_config, T) +
+                          K * (enc_flops_per_token(cfg.protein_config, K) + 3 * 2 * cfg.protein_config.hidden_size *
+                               cfg.text_config.hidden_size))
+        out = {
+            "metric": "training tokens/sec Molly-1.7B bf16", "value": round(tokens / dt, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Molly-{args.model.upper()} (Qwen3-{args.model.upper()} + NT-500M + ESM2-650M) train step, "
+                                   f"seq_len {T} text + {K}-residue protein span per sample, {B} samples/GPU, GA=1, "
+                                   f"LLM+projectors trainable, encoders frozen, ZeRO-2 dp{world}",
+                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
+            "step_ms_p50": round(statistics.median(step_ms), 2),
+            "model_tflops_per_gpu": round(flops_step / (dt / args.steps) / 1e12, 1),
+            "mfma_roofline_frac_step": round(flops_step / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "loss": round(loss_v, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)", "achieved": round(achieved, 1),
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
+                         "gemm_share_of_step": round(gemm_ms / sum(step_ms), 3)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -246,7 +246,8 @@ class OmicsOne(nn.Module):
                 setattr(self, f"{m}_{part}_token_id", tokenizer.convert_tokens_to_ids(f"<|{m}_{part}|>"))
 
     # ---- runtime --------------------------------------------------------------------------------------------
-    def prepare(self, device="cuda", train_llm=True, train_mlp=True, ce_chunk_rows=16384, rope_table_dtype=BF16):
+    def prepare(self, device="cuda", train_llm=True, train_mlp=True, ce_chunk_rows=16384, rope_table_dtype=BF16,
+                random_init_seed: Optional[int] = None):
         """Re-home all tensors into flat bf16 HBM buffers and build the HIP engines.  Trainable group = LLM + projectors
         (reference default `--train-llm --train-mlp`, encoders frozen: src/utils/tools.py:313-338)."""
         assert self.model is not None and self.dna_rna_model is not None and self.protein_model is not None, \
@@ -261,17 +262,37 @@ class OmicsOne(nn.Module):
         enc = {}
         for pre, cfg in (("dna_rna_model.", self.dna_rna_config), ("protein_model.", self.protein_config)):
             enc[pre] = FlatBuffer(enc_param_specs(cfg, pre), dev)
+        gen = None
         for buf in [P] + list(enc.values()):
             for n, v in buf.views.items():
-                v.copy_(sd[n].to(dev))
+                src = sd[n]
+                if src.is_meta:
+                    # un-materialised shell (== the reference's --no-load-pretrained, src/train.py:107-116):
+                    # initialise on the device, N(0, 0.02) matrices / unit gains / zero biases
+                    if random_init_seed is None:
+                        raise RuntimeError(f"parameter {n} has no value: load a checkpoint or pass random_init_seed")
+                    if gen is None:
+                        gen = torch.Generator(device=dev).manual_seed(random_init_seed)
+                    if is_no_decay(n) and n.endswith("weight"):
+                        v.fill_(1.0)
+                    elif n.endswith("bias"):
+                        v.zero_()
+                    else:
+                        v.normal_(0.0, 0.02, generator=gen)
+                else:
+                    v.copy_(src.to(dev))
         # re-point module parameters at the flat views (so state_dict()/save keep working and see updates)
         with torch.no_grad():
             named = dict(self.named_parameters(remove_duplicate=False))
-            named.update(dict(self.named_buffers()))
             for buf in [P] + list(enc.values()):
                 for n, v in buf.views.items():
-                    if n in named:
-                        named[n].data = v
+                    if n not in named:
+                        continue
+                    mod = self
+                    *path, leaf = n.split(".")
+                    for k in path:
+                        mod = mod[int(k)] if k.isdigit() else getattr(mod, k)
+                    setattr(mod, leaf, nn.Parameter(v, requires_grad=named[n].requires_grad and buf is P))
             if self.text_config.tie_word_embeddings:
                 self.model.lm_head.weight = self.model.model.embed_tokens.weight
         G = P.like() if (train_llm or train_mlp) else None

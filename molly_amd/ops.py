@@ -12,6 +12,10 @@ BF16 = torch.bfloat16
 GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32 = 1, 2, 4, 8, 16
 
 
+# optional per-launch timing of the dominant kernel (bench.py roofline): list of (start_event, end_event, flops)
+GEMM_PROFILE = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -50,8 +54,16 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         flags |= GEMM_OUT_F32
     elif out.dtype != BF16:
         raise TypeError("gemm_nt: out must be bf16 or fp32")
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     lib().call("molly_gemm_nt_bf16", _stream(), a, b, out, bias, res, M, N, K, a.stride(0), b.stride(0), out.stride(0),
                res.stride(0) if res is not None else 0, flags)
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K))
     return out
 
 

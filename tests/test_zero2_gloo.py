@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: the ZeRO-2 step's partitioning + collectives (reduce-scatter / all-reduce / all-gather) give
+the same parameters on every rank as a single-process AdamW over the averaged gradients.  The shard arithmetic is
+injected as a torch stand-in HERE (test-only): the product's arithmetic is the HIP kernels (tests/test_gpu_kernels.py)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import molly_ref as R
+
+
+class TorchKernels:
+    def sqnorm(self, g, out, accumulate):
+        s = g.float().pow(2).sum()
+        out[0] = out[0] + s if accumulate else s
+
+    def clip_coef(self, norm_sq, max_norm, pre_scale, norm_out, coef_out):
+        n = norm_sq[0].sqrt() * pre_scale
+        norm_out[0] = n
+        coef_out[0] = torch.clamp(max_norm / (n + 1e-6), max=1.0) * pre_scale
+
+    def adamw(self, master, m, v, grad, param_out, lr, b1, b2, eps, wd, step, gscale):
+        R.adamw_step(master, grad.float() * gscale[0], m, v, step, lr, wd, b1, b2, eps)
+        param_out.copy_(master.to(param_out.dtype))
+
+
+def _worker(rank, world, port, n, n_decay, chunk, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from molly_amd.trainer.zero2 import Zero2Optimizer
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    P = p0.clone().bfloat16()
+    grads = [torch.randn(n, generator=torch.Generator().manual_seed(10 + r)).bfloat16() for r in range(world)]
+    G = grads[rank].clone()
+    opt = Zero2Optimizer(P, G, n_decay, lr=1e-2, max_grad_norm=1.0, chunk_elems=chunk, kernels=TorchKernels())
+    for _ in range(2):
+        G.copy_(grads[rank])
+        norm = opt.step()
+    ret[rank] = (P.clone(), float(norm))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunk", [64, 1 << 20])
+def test_zero2_two_ranks_equals_single_process(chunk):
+    n, n_decay, world = 1024, 768, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29541 + (chunk % 7), n, n_decay, chunk, ret), nprocs=world, join=True)
+    P0, n0 = ret[0]
+    P1, n1 = ret[1]
+    assert torch.equal(P0, P1) and n0 == n1                      # replicas agree bit for bit after the all-gather
+    # single-process reference: AdamW on bf16(sum of rank grads)/world, clip 1.0
+    p = torch.randn(n, generator=torch.Generator().manual_seed(0)).bfloat16().float()
+    grads = [torch.randn(n, generator=torch.Generator().manual_seed(10 + r)).bfloat16() for r in range(world)]
+    gsum = (grads[0].float() + grads[1].float()).bfloat16().float()      # gloo reduces in bf16
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    for step in (1, 2):
+        gavg = gsum / world
+        total, coef = R.clip_coef([gavg], 1.0)
+        gg = gavg * coef
+        R.adamw_step(p[:n_decay], gg[:n_decay], m[:n_decay], v[:n_decay], step, 1e-2, 1e-2)
+        R.adamw_step(p[n_decay:], gg[n_decay:], m[n_decay:], v[n_decay:], step, 1e-2, 0.0)
+    assert abs(total.item() - n0) < 1e-3 * n0
+    # bf16 parameters: equal up to one bf16 ulp (the fp32 masters differ by reduction-order noise only)
+    ref = p.bfloat16().float()
+    assert bool(((P0.float() - ref).abs() <= 2 ** -7 * ref.abs() + 1e-6).all())
+    assert (P0.float() != ref).float().mean() < 0.05
+
+
+def test_bucket_partition_covers_buffer_once():
+    from molly_amd.trainer.zero2 import Zero2Optimizer
+    P = torch.zeros(4096, dtype=torch.bfloat16)
+    opt = Zero2Optimizer(P, P.clone(), 1000, chunk_elems=1000, kernels=TorchKernels())
+    assert sum(per * opt.world for _, per in opt.buckets) == 4096
+    assert all(per % 8 == 0 for _, per in opt.buckets)
