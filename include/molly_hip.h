@@ -41,6 +41,16 @@ enum {
 int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
                        int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags);
 
+/* General operand layouts: a_kmajor / b_kmajor = operand stored [K][rows] instead of [rows][K] (no HBM transposes):
+ *   dgrad  dx[M,K'] = dy[M,N'] W[N',K']      -> molly_gemm_bf16(A=dy, B=W, a_kmajor=0, b_kmajor=1)
+ *   wgrad  dW[N',K'] = dy[Mtok,N']^T x[Mtok,K'] -> molly_gemm_bf16(A=dy, B=x, a_kmajor=1, b_kmajor=1), K = Mtok (any value)
+ * Same epilogue flags as molly_gemm_nt_bf16 (which is the a_kmajor=b_kmajor=0 case). */
+int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N,
+                    int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor, int b_kmajor);
+
+/* tuning/test hook: 0 = heuristic tile choice, 128 / 256 = force that BM tile configuration of the GEMM kernel. */
+int molly_gemm_force_tile(int bm);
+
 /* out[C,R] = in[R,C]^T (bf16).  Used to keep W^T copies for dgrad and X^T / dY^T for wgrad. */
 int molly_transpose_bf16(void* stream, const void* in, void* out, int R, int C, int ld_in, int ld_out);
 

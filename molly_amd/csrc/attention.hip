@@ -18,6 +18,11 @@ namespace {
 constexpr int BQ = 128;   // query rows per block (4 waves x 32)
 constexpr int BKV = 64;   // keys per tile
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float RESCALE_THR = 8.0f;   // log2 domain: O/l are rescaled only when the running max grows by more than this
+                                      // (guide T13 "defer-max"); P then stays <= 2^8, far inside bf16/fp32 range
+
+// raw v_exp_f32 (2^x): inputs here are <= RESCALE_THR or -inf; no denormal range handling needed
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
@@ -156,22 +161,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 mx = fmaxf(mx, fmaxf(a, c));
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f(m_run - m_use);           // m_run=-inf -> 0
+            // deferred rescale (guide T13): keep the old reference max unless some row's max grew by > RESCALE_THR.
+            // The decision precedes every exponentiation of this tile (textbook order), so nothing is half-scaled.
+            if (!__all(mx - m_run <= RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = fast_exp2(m_run - m_use);       // m_run = -inf -> 0
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+            }
+            const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
             float rs = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                s0[e] = exp2f(s0[e] - m_use);
-                s1[e] = exp2f(s1[e] - m_use);
+                s0[e] = fast_exp2(s0[e] - m_ref);
+                s1[e] = fast_exp2(s1[e] - m_ref);
                 rs += s0[e] + s1[e];
             }
-            l_run = l_run * alpha + rs;                         // per-half partial; halves merged at the end
-            m_run = m_new;
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+            l_run += rs;                                            // per-half partial; halves merged at the end
             // ---- P^T -> bf16 B operands: k-step s' uses accumulator regs 8(s'&1)..+7 of s0 (s'<2) / s1
             bf16x8 pf[4];
 #pragma unroll
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
                 for (int e = 0; e < 16; ++e) {
                     const int key = k0 + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;
                     const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
-                    const float pr = ok ? exp2f(sT[e] * p.scale_log2 - lse) : 0.f;
+                    const float pr = ok ? fast_exp2(sT[e] * p.scale_log2 - lse) : 0.f;
                     sT[e] = pr * (dpT[e] - dlt);                    // dS^T (unscaled)
                 }
                 const bf16x8 f0 = acc_to_frag(sT, 0), f1 = acc_to_frag(sT, 8);
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
                     const int ql = 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;   // row inside the tile
                     const int q = qbase + ql;
                     const bool ok = key_ok && q < T && (!p.causal || key <= q);
-                    const float pr = ok ? exp2f(sA[e] * p.scale_log2 - sL[ql]) : 0.f;
+                    const float pr = ok ? fast_exp2(sA[e] * p.scale_log2 - sL[ql]) : 0.f;
                     pA[e] = pr;
                     sA[e] = pr * (dpA[e] - sL[64 + ql]);                        // dS (unscaled)
                 }

@@ -163,19 +163,29 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
 }
 
-// out[j] (+)= sum_b part[b][j]  — deterministic column reduce of block partials
+// out[j] (+)= sum_b part[b][j]  — deterministic column reduce of block partials.
+// block = 32 columns x 8 row groups (fixed summation tree), grid = H/32 blocks
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nb, int H, int row_stride,
                                                      void* out, int out_f32, int accumulate) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= H) return;
+    __shared__ float red[8][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += part[(size_t)b * row_stride + j];
-    if (out_f32) {
-        float* o = reinterpret_cast<float*>(out);
-        o[j] = accumulate ? o[j] + s : s;
-    } else {
-        bf16_t* o = reinterpret_cast<bf16_t*>(out);
-        o[j] = f2bf(accumulate ? bf2f(o[j]) + s : s);
+    if (j < H)
+        for (int b = rg; b < nb; b += 8) s += part[(size_t)b * row_stride + j];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && j < H) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][c];
+        if (out_f32) {
+            float* o = reinterpret_cast<float*>(out);
+            o[j] = accumulate ? o[j] + t : t;
+        } else {
+            bf16_t* o = reinterpret_cast<bf16_t*>(out);
+            o[j] = f2bf(accumulate ? bf2f(o[j]) + t : t);
+        }
     }
 }
 
@@ -766,7 +776,7 @@ extern "C" int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, con
     NC_DISPATCH(H, RMS_BWD);
 #undef RMS_BWD
     MOLLY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, ST, workspace, nb, H, H, dw, dw_f32, dw_accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 32)), dim3(256), 0, ST, workspace, nb, H, H, dw, dw_f32, dw_accumulate);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }
@@ -807,9 +817,9 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
     MOLLY_LAUNCH_CHECK();
     if (q_norm_w) {
         MOLLY_CHECK(dq_w && dk_w, "norm_rope_bwd: gain gradients requested without output pointers");
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 256)), dim3(256), 0, ST, workspace, nb, head_dim, 2 * head_dim,
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 32)), dim3(256), 0, ST, workspace, nb, head_dim, 2 * head_dim,
                            dq_w, dw_f32, dw_accumulate);
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 256)), dim3(256), 0, ST, workspace + head_dim, nb, head_dim,
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 32)), dim3(256), 0, ST, workspace + head_dim, nb, head_dim,
                            2 * head_dim, dk_w, dw_f32, dw_accumulate);
         MOLLY_LAUNCH_CHECK();
     }
@@ -942,7 +952,7 @@ extern "C" int molly_colsum_bf16(void* stream, const void* x, int rows, int H, i
     const int rpp = cdiv(rows, np);
     hipLaunchKernelGGL(colsum_bf16_part_kernel, dim3(cdiv(H, 256), np), dim3(256), 0, ST, (const bf16_t*)x, rows, H, ld,
                        workspace, rpp);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, ST, workspace, np, H, H, out, out_f32, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 32)), dim3(256), 0, ST, workspace, np, H, H, out, out_f32, accumulate);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -1,22 +1,28 @@
-// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] · B[N,K]^T  (+bias[N]) (GELU) (+res[M,N]) (+= C)
+// bf16 MFMA GEMM for gfx950:  C[M,N] = op(A)[M,K] · op(B)[K,N]  (+bias[N]) (GELU) (+res[M,N]) (+= C)
 //
-// Both operands are K-contiguous ("NT").  This is the shape of every Linear forward on Molly's hot path
-// (HF nn.Linear: y = x W^T; reference call sites src/model/omics_one.py:75-91,175) and — because the
-// runtime keeps a transposed bf16 copy of each weight and transposes activations for wgrad — of every
-// dgrad / wgrad as well (see DESIGN.md "GEMM forms").
+// Operand layouts (template flags AT / BT): an operand is either "k-contiguous" (stored [rows][K]: A as [M][K], B as
+// [N][K]) or "k-major" (stored [K][rows]: A as [K][M], B as [K][N]).  The three forms on Molly's hot path:
+//   forward  y  = x W^T      : A=x [M][K] k-contig,  B=W  [N][K] k-contig            (AT=0, BT=0, "NT")
+//   dgrad    dx = dy W       : A=dy[M][N'] k-contig, B=W  [N'][K'] = [K][N] k-major   (AT=0, BT=1, "NN")
+//   wgrad    dW = dy^T x     : A=dy[Mtok][N'] = [K][M] k-major, B=x [Mtok][K'] = [K][N] k-major (AT=1, BT=1, "TN")
+// (HF nn.Linear: y = x W^T; reference call sites src/model/omics_one.py:75-91,175 and the autograd of those).
+// k-major tiles are staged row-major [64 k][cols] and their MFMA fragments are gathered with ds_read_b64_tr_b16
+// (guide T10), so no operand is ever transposed in HBM.
 //
-// v1 structure (guide §5 "minimum 2-phase"): 128x128x64 tile, 4 waves (2x2, 64x64 each),
-// mfma_f32_16x16x32_bf16, A/B tiles staged HBM->LDS by global_load_lds (16 B/lane, 1 KiB per wave
-// instruction), double-buffered LDS (64 KiB -> 2 blocks/CU), XOR-swizzled 16-B chunks (conflict-free
-// ds_read_b128), XCD-aware tile order.  MFMA operands are passed swapped (B-tile fragment as the A
-// operand) so every lane owns 4 CONSECUTIVE n of one row m -> 8-byte bf16 stores / 16-byte fp32 stores.
+// Two tile configurations of one kernel template:
+//   <BM=256, 3 stages>  8 waves (4x2, 64x64 each), 144 KiB LDS ring, ONE raw s_barrier per K-step, tiles t+1 and t+2
+//                       in flight behind a COUNTED s_waitcnt vmcnt(6) (guide §5 "Pipelining across barriers": LDS-DMA
+//                       spans the barrier, never drained to 0 in the loop).  Used when the grid fills the chip.
+//   <BM=128, 2 stages>  4 waves (2x2), 64 KiB LDS, 2 blocks/CU — small / skinny problems.
+// Common: mfma_f32_16x16x32_bf16, global_load_lds 16 B/lane staging with the swizzle on the SOURCE address (LDS image
+// is lane-linear), XOR-swizzled chunks (conflict-free ds_read_b128 / tr reads), XCD-aware tile order, MFMA operands
+// passed swapped so every lane owns 4 CONSECUTIVE n of one row m (8-byte bf16 / 16-byte fp32 stores).
 #include "common.h"
 #include "molly_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_ELEMS = BM * BK;          // 8192 bf16 = 16 KiB per operand per stage
+constexpr int BN = 128;
 
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; void* C;
@@ -24,45 +30,94 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc, ldres;
     int flags;
     int tiles_m, tiles_n;
+    const bf16_t* zeros;      // >= 16 bytes of zeros: source of k-rows beyond K for k-major operands
 };
 
-// stage one 128x64 bf16 tile: 16 wave-instructions of 1 KiB; wave w issues instructions w*4 .. w*4+3
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int rows_total, int k0,
-                                           bf16_t* lds_tile, int wave, int lane) {
-    const int r_in = lane >> 3;                 // row inside the 8-row group
-    const int c_src = (lane & 7) ^ r_in;        // swizzle on the SOURCE address (LDS dest is lane-linear)
+// ---- k-contiguous operand: tile [ROWS][64] bf16 (128-B LDS rows); one wave-instruction = 8 rows (1 KiB).
+// chunk swizzle: ch ^ (row & 7)
+template <int ROWS, int NW, int BK>
+__device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, int row0, int rows_total, int k0,
+                                         bf16_t* lds_tile, int wave, int lane) {
+    constexpr int CPR = BK / 8;                   // chunks per row (8: 128-B rows, 4: 64-B rows)
+    constexpr int RPI = 64 / CPR;                 // rows per wave-instruction
+    constexpr int PER = ROWS / RPI / NW;
+    const int r_in = lane / CPR;
+    // swizzle on the SOURCE chunk: BK=64: ch ^ (row&7) ; BK=32: ch ^ ((row>>2)&3)   (row = inst*RPI + r_in)
+    const int c_src = BK == 64 ? ((lane & 7) ^ r_in) : ((lane & 3) ^ ((r_in >> 2) & 3));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = wave * 4 + i;
-        int row = row0 + inst * 8 + r_in;
+    for (int i = 0; i < PER; ++i) {
+        const int inst = wave * PER + i;
+        int row = row0 + inst * RPI + r_in;
         row = row < rows_total ? row : rows_total - 1;     // clamp: OOB rows re-read a valid row, masked at store
         const bf16_t* src = g + (size_t)row * ld + k0 + c_src * 8;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
     }
 }
 
-__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* lds_tile, int row, int chunk) {
-    const int phys = chunk ^ (row & 7);
+template <int BK>
+__device__ __forceinline__ bf16x8 frag_kc(const bf16_t* lds_tile, int row, int chunk) {
+    const int phys = BK == 64 ? (chunk ^ (row & 7)) : (chunk ^ ((row >> 2) & 3));
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * BK + phys * 8);
+}
+
+// ---- k-major operand: tile [64 k][COLS] bf16; chunk swizzle inside every 128-column (256-B = one bank row) segment:
+// ch ^ (((k&3)<<2) | ((k>>2)&3))  — conflict-free for the 4-row x 16-col transposed-read blocks.
+__device__ __forceinline__ int kswz(int k, int ch) { return ch ^ (((k & 3) << 2) | ((k >> 2) & 3)); }
+
+template <int COLS, int NW, int BK>
+__device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, int col0, int cols_total, int k0, int k_total,
+                                         const bf16_t* zeros, bf16_t* lds_tile, int wave, int lane) {
+    constexpr int CPR = COLS / 8;                 // 16-byte chunks per k row
+    constexpr int RPI = 64 / CPR;                 // k rows per wave-instruction
+    constexpr int PER = (BK / RPI) / NW;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int inst = wave * PER + i;
+        const int kr = inst * RPI + lane / CPR;
+        const int pos = lane % CPR;
+        const int csrc = (pos & ~15) | kswz(kr, pos & 15);
+        int col = col0 + csrc * 8;
+        col = col <= cols_total - 8 ? col : cols_total - 8;  // clamp: OOB columns duplicate valid data, masked at store
+        const int k = k0 + kr;
+        const bf16_t* src = (k < k_total) ? g + (size_t)k * ld + col : zeros;   // rows past K contribute exact zeros
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+    }
+}
+
+// fragment for mfma_16x16x32: lane (i = lane&15, g = lane>>4) gets tile[k = 32*kk + 8g + j][col16 + i], j = 0..7
+template <int COLS>
+__device__ __forceinline__ bf16x8 frag_km(const bf16_t* lds_tile, int kk, int col16, int lane) {
+    const int g = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3;
+    const int col = col16 + 4 * pp;
+    const int seg = col & ~127, cc = col & 127;
+    const int ka = 32 * kk + 8 * g + q, kb = ka + 4;
+    const bf16_t* pa = lds_tile + ka * COLS + seg + kswz(ka, cc >> 3) * 8 + (cc & 7);
+    const bf16_t* pb = lds_tile + kb * COLS + seg + kswz(kb, cc >> 3) * 8 + (cc & 7);
+    const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
+    const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
+    return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+template <bool AT, bool BT, int BM, int NSTAGE, int BK>
+__global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
+    constexpr int NW = BM / 32;                       // waves: (BM/64) x 2, each 64x64
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int NLOAD = (BM + BN) * BK * 2 / 1024 / NW;     // LDS-DMA instructions per wave per stage (both layouts)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
-    // layout: [stage][A|B][128*64]
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);          // [stage][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (L2); give each XCD a contiguous
-    // chunk of the tile list, and walk tiles in groups of 8 M-tiles per N sweep so neighbours share B.
+    // ---- XCD-aware tile mapping: blocks b and b+8 share an XCD (L2); give each XCD a contiguous chunk of the tile
+    // list, and walk tiles in groups of GROUP_M M-tiles per N sweep so neighbours share operand panels.
     const int nwg = gridDim.x;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = BM == 256 ? 4 : 8;
     const int per_group = GROUP_M * p.tiles_n;
     const int grp = swz / per_group;
     const int first_m = grp * GROUP_M;
@@ -77,37 +132,76 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    stage_tile(p.A, p.lda, m0, p.M, 0, smem, wave, lane);
-    stage_tile(p.B, p.ldb, n0, p.N, 0, smem + TILE_ELEMS, wave, lane);
-    __syncthreads();   // hipcc emits s_waitcnt vmcnt(0) ahead of the barrier while LDS-DMA is in flight
-
+    const int nk = (p.K + BK - 1) / BK;
+    auto stage = [&](int t, bf16_t* dst) {
+        if (AT) stage_km<BM, NW, BK>(p.A, p.lda, m0, p.M, t * BK, p.K, p.zeros, dst, wave, lane);
+        else stage_kc<BM, NW, BK>(p.A, p.lda, m0, p.M, t * BK, dst, wave, lane);
+        if (BT) stage_km<BN, NW, BK>(p.B, p.ldb, n0, p.N, t * BK, p.K, p.zeros, dst + A_ELEMS, wave, lane);
+        else stage_kc<BN, NW, BK>(p.B, p.ldb, n0, p.N, t * BK, dst + A_ELEMS, wave, lane);
+    };
     const int fr = lane & 15, fq = lane >> 4;
-    int cur = 0;
-    for (int t = 0; t < nk; ++t) {
-        bf16_t* sA = smem + cur * 2 * TILE_ELEMS;
-        bf16_t* sB = sA + TILE_ELEMS;
-        if (t + 1 < nk) {
-            bf16_t* nA = smem + (cur ^ 1) * 2 * TILE_ELEMS;
-            stage_tile(p.A, p.lda, m0, p.M, (t + 1) * BK, nA, wave, lane);
-            stage_tile(p.B, p.ldb, n0, p.N, (t + 1) * BK, nA + TILE_ELEMS, wave, lane);
+    auto read_frags = [&](const bf16_t* sA, int kk, bf16x8 (&af)[4], bf16x8 (&bfr)[4]) {
+        const bf16_t* sB = sA + A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = AT ? frag_km<BM>(sA, kk, wm * 64 + i * 16, lane) : frag_kc<BK>(sA, wm * 64 + i * 16 + fr, kk * 4 + fq);
+            bfr[i] = BT ? frag_km<BN>(sB, kk, wn * 64 + i * 16, lane) : frag_kc<BK>(sB, wn * 64 + i * 16 + fr, kk * 4 + fq);
         }
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfr[4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = lds_frag(sA, wm * 64 + i * 16 + fr, kk * 4 + fq);
-                bfr[i] = lds_frag(sB, wn * 64 + i * 16 + fr, kk * 4 + fq);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    };
+
+    if constexpr (NSTAGE == 2) {
+        stage(0, smem);
+        __syncthreads();   // hipcc emits s_waitcnt vmcnt(0) ahead of the barrier while LDS-DMA is in flight
+        int cur = 0;
+        for (int t = 0; t < nk; ++t) {
+            if (t + 1 < nk) stage(t + 1, smem + (cur ^ 1) * STAGE);
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 af[4], bfr[4];
+                read_frags(smem + cur * STAGE, kk, af, bfr);
+                mma(af, bfr);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
-        cur ^= 1;
+    } else {
+        // 3-stage LDS ring (tiles t+1, t+2 in flight behind a COUNTED vmcnt, raw barrier: guide §5 "Pipelining across
+        // barriers") + register double-buffering of the MFMA fragments: the reads of the next 32-deep sub-step are
+        // issued before the MFMAs of the current one, so the matrix pipe only idles across the one barrier per K-step.
+        static_assert(NLOAD == 6 && BK == 64, "vmcnt immediates below assume 6 LDS-DMA instructions per wave per stage");
+        stage(0, smem);
+        if (nk > 1) stage(1, smem + STAGE);
+        if (nk > 2) stage(2, smem + 2 * STAGE);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bf16x8 a0[4], b0[4], a1[4], b1[4];
+        read_frags(smem, 0, a0, b0);
+        int s_cur = 0;
+        for (int t = 0; t < nk; ++t) {
+            const bf16_t* cur = smem + s_cur * STAGE;
+            const int s_nxt = s_cur == 2 ? 0 : s_cur + 1;
+            read_frags(cur, 1, a1, b1);
+            mma(a0, b0);
+            if (t + 1 < nk) {
+                // every read of tile t must have returned before any wave may overwrite its stage (tile t+3)
+                if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 3 < nk) stage(t + 3, smem + s_cur * STAGE);
+                read_frags(smem + s_nxt * STAGE, 0, a0, b0);
+            }
+            mma(a1, b1);
+            s_cur = s_nxt;
+        }
     }
 
     // ---- epilogue: lane owns C[m = .. + fr][n = .. + fq*4 + 0..3]
@@ -154,14 +248,247 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-}  // namespace
 
-extern "C" int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias,
-                                  const void* res, int M, int N, int K, int lda, int ldb, int ldc, int ldres,
-                                  int flags) {
+// ================================================================================================
+// 256x256x64 tile, 8 waves (2 x 4, each 128x64), 128 KiB LDS = 2 buffers x {A0,A1,B0,B1} half-tiles of 16 KiB.
+// Structure (after guide §5 "The 256² 8-phase template", own schedule):
+//  * each K-tile is 4 PHASES = the 4 quadrants (64x32) of the wave's output; a phase = LOAD segment (ds_read of the
+//    operand sub-tiles it needs + ONE half-tile LDS-DMA prefetch) | barrier | COMPUTE segment (16 MFMAs) | barrier;
+//  * the two wave groups (waves 0-3 / 4-7, one of each per SIMD) are STAGGERED by one barrier, so one group's MFMA
+//    segment always runs beside the other's LDS/DMA segment (matrix pipe beside memory pipe on every SIMD);
+//  * half-tile prefetch order makes every restage >= 2 phases after the slot's last ds_read (WAR) and every first read
+//    >= 1 phase after the counted s_waitcnt vmcnt that retires it, behind a barrier both groups have passed (RAW):
+//      K-tile T (buffer T&1):  P0 reads B(n0) A(m0), issues B1(T+1) | P1 reads B(n1), issues A0(T+1)
+//                              P2 reads A(m1), issues A1(T+1)       | P3 issues B0(T+2), waits vmcnt(2) => T+1 landed
+//    B slots die after P1 -> restaged at P3 (B0) and next P0 (B1); A slots die after P2 -> restaged at next P1/P2.
+// Arithmetic intensity 128 flop/B of L2->LDS traffic (2x the 128² tile): the per-CU vector-memory path (64 B/clk) and
+// the matrix pipe are no longer at a 1:1 ridge.
+// ================================================================================================
+template <bool AT, bool BT>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);   // [buf][A0|A1|B0|B1][HT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * p.tiles_n;
+    const int grp = swz / per_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (swz % per_group) % gsz;
+    const int tn = (swz % per_group) / gsz;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+    auto issue = [&](int kt, int which) {
+        bf16_t* dst = smem + ((kt & 1) * 4 + which) * HT;
+        if (which < 2) {
+            if (AT) stage_km<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, p.K, p.zeros, dst, wave, lane);
+            else stage_kc<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, dst, wave, lane);
+        } else {
+            if (BT) stage_km<128, 8, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, p.K, p.zeros, dst, wave, lane);
+            else stage_kc<128, 8, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, dst, wave, lane);
+        }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    auto readA = [&](int buf, int mh, bf16x8 (&af)[2][4]) {
+        const bf16_t* t = smem + (buf * 4 + wr) * HT;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[kk][i] = AT ? frag_km<128>(t, kk, mh * 64 + i * 16, lane) : frag_kc<BK>(t, mh * 64 + i * 16 + fr, kk * 4 + fq);
+    };
+    auto readB = [&](int buf, int nh, bf16x8 (&bfr)[2][2]) {
+        const bf16_t* t = smem + (buf * 4 + 2 + (wc >> 1)) * HT;
+        const int c0 = (wc & 1) * 64 + nh * 32;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[kk][j] = BT ? frag_km<128>(t, kk, c0 + j * 16, lane) : frag_kc<BK>(t, c0 + j * 16 + fr, kk * 4 + fq);
+    };
+#define MMA_QUAD(MH, NH, AF, BF)                                                                            \
+    do {                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            acc[(MH) * 4 + i][(NH) * 2 + j] =                                                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[kk][j], AF[kk][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    } while (0)
+#define SEG_BARRIER()                          \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+    // ---- prologue: K-tile 0 complete + B0 of K-tile 1
+    issue(0, 2); issue(0, 3); issue(0, 0); issue(0, 1);
+    if (nk > 1) {
+        issue(1, 2);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    SEG_BARRIER();
+    if (wr == 1) SEG_BARRIER();               // stagger: group 1 runs one segment behind group 0
+
+    bf16x8 af[2][4], b0[2][2], b1[2][2];
+    for (int T = 0; T < nk; ++T) {
+        const int buf = T & 1;
+        // ---- P0: quadrant (m0,n0)
+        readB(buf, 0, b0);
+        readA(buf, 0, af);
+        if (T + 1 < nk) issue(T + 1, 3);
+        SEG_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MMA_QUAD(0, 0, af, b0);
+        SEG_BARRIER();
+        // ---- P1: quadrant (m0,n1)
+        readB(buf, 1, b1);
+        if (T + 1 < nk) issue(T + 1, 0);
+        SEG_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MMA_QUAD(0, 1, af, b1);
+        SEG_BARRIER();
+        // ---- P2: quadrant (m1,n1)
+        readA(buf, 1, af);
+        if (T + 1 < nk) issue(T + 1, 1);
+        SEG_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MMA_QUAD(1, 1, af, b1);
+        SEG_BARRIER();
+        // ---- P3: quadrant (m1,n0); retire K-tile T+1 (all but the B0(T+2) pieces just issued)
+        if (T + 2 < nk) {
+            issue(T + 2, 2);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        SEG_BARRIER();
+        MMA_QUAD(1, 0, af, b0);
+        SEG_BARRIER();
+    }
+    if (wr == 0) SEG_BARRIER();               // balance the stagger barrier
+#undef MMA_QUAD
+#undef SEG_BARRIER
+
+    // ---- epilogue: lane owns C[m = .. + fr][n = .. + fq*4 + 0..3]
+    const bool has_bias = p.flags & MOLLY_GEMM_BIAS, has_res = p.flags & MOLLY_GEMM_RESIDUAL;
+    const bool gelu = p.flags & MOLLY_GEMM_GELU, accum = p.flags & MOLLY_GEMM_ACCUMULATE;
+    const bool out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (has_bias) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+                v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+            }
+            if (gelu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (has_res) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldres + n);
+                v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+            }
+            if (out_f32) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                if (accum) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(c);
+                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                }
+                *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+                if (accum) {
+                    const u32x2 o = *reinterpret_cast<const u32x2*>(c);
+                    v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+                }
+                *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            }
+        }
+    }
+}
+
+__device__ bf16_t g_zero_page[64];      // zero-initialised device memory (k-rows beyond K)
+
+template <bool AT, bool BT>
+int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
+    // force_tile: 0 heuristic | 128 = <128,2 stages,BK64> | 256 = <256,3 stages,BK64> | 32 = <128,2 stages,BK32>
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 256, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * (256 + BN) * 64 * 2);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 128, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * (128 + BN) * 64 * 2);
+        attr_set = true;
+    }
+    // heuristic: the 256x256 ping-pong kernel when its grid fills the 256 CUs without a long tail, else 128x128
+    if (force_tile == 0) {
+        const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256);
+        const long rounds = (t256 + 255) / 256;
+        const double eff = (double)t256 / (double)(rounds * 256);
+        force_tile = (t256 >= 200 && eff >= 0.8) ? 512 : 128;
+    }
+    if (force_tile == 512) {
+        static bool a2 = false;
+        if (!a2) {
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            a2 = true;
+        }
+        p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
+        hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(p.tiles_m * p.tiles_n), dim3(512), 131072, st, p);
+    } else if (force_tile == 256) {
+        p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, BN);
+        hipLaunchKernelGGL((gemm_kernel<AT, BT, 256, 3, 64>), dim3(p.tiles_m * p.tiles_n), dim3(512),
+                           3 * (256 + BN) * 64 * sizeof(bf16_t), st, p);
+    } else if (force_tile == 32) {
+        p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, BN);
+        hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 32>), dim3(p.tiles_m * p.tiles_n), dim3(256),
+                           2 * (128 + BN) * 32 * sizeof(bf16_t), st, p);
+    } else {
+        p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, BN);
+        hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
+                           2 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
+    }
+    return 0;
+}
+
+int g_force_tile = 0;
+
+int launch_gemm(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
+                int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
     MOLLY_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
-    MOLLY_CHECK(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
+    MOLLY_CHECK((at && bt) || K % 64 == 0, "gemm: K=%d must be a multiple of %d when an operand is k-contiguous", K, 64);
     MOLLY_CHECK(N % 4 == 0, "gemm: N=%d must be a multiple of 4", N);
+    MOLLY_CHECK(!at || M % 8 == 0, "gemm: k-major A needs M %% 8 == 0 (M=%d)", M);
+    MOLLY_CHECK(!bt || N % 8 == 0, "gemm: k-major B needs N %% 8 == 0 (N=%d)", N);
     MOLLY_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm: lda/ldb must be multiples of 8, ldc of 4");
     MOLLY_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
@@ -171,15 +498,45 @@ extern "C" int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, vo
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)res;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres; p.flags = flags;
-    p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-    const int grid = p.tiles_m * p.tiles_n;
-    const size_t lds = 2 * 2 * TILE_ELEMS * sizeof(bf16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    static const bf16_t* zeros = nullptr;
+    if (!zeros) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) {
+            molly_set_error("gemm: cannot resolve the zero page");
+            return 3;
+        }
+        zeros = (const bf16_t*)zp;
     }
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    p.zeros = zeros;
+    hipStream_t st = (hipStream_t)stream;
+    if (!at && !bt) launch_cfg<false, false>(st, p, g_force_tile);
+    else if (!at && bt) launch_cfg<false, true>(st, p, g_force_tile);
+    else if (at && bt) launch_cfg<true, true>(st, p, g_force_tile);
+    else {
+        molly_set_error("gemm: the (k-major A, k-contiguous B) form is not on the hot path and not built");
+        return 1;
+    }
     MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias,
+                                  const void* res, int M, int N, int K, int lda, int ldb, int ldc, int ldres,
+                                  int flags) {
+    return launch_gemm(stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, false, false);
+}
+
+extern "C" int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
+                               int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor,
+                               int b_kmajor) {
+    return launch_gemm(stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, a_kmajor != 0, b_kmajor != 0);
+}
+
+// tuning/test hook: 0 = heuristic, 128 or 256 = force that BM tile configuration
+extern "C" int molly_gemm_force_tile(int bm) {
+    MOLLY_CHECK(bm == 0 || bm == 128 || bm == 256 || bm == 32 || bm == 512, "gemm_force_tile: %d not in {0,32,128,256,512}", bm);
+    g_force_tile = bm;
     return 0;
 }

@@ -389,12 +389,8 @@ class OmicsOne(nn.Module):
                 N = enc_out.shape[0]
                 d_emb = torch.zeros(N, self.text_config.hidden_size, dtype=BF16, device=rt.dev)
                 ops.copy_rows(d_hs, d_emb, N, src_idx32=dst_dev)
-                Np = (N + 63) // 64 * 64
-                ta = torch.zeros(d_emb.shape[1], Np, dtype=BF16, device=rt.dev)
-                tb = torch.zeros(enc_out.shape[1], Np, dtype=BF16, device=rt.dev)
-                ops.transpose(d_emb, ta[:, :N])
-                ops.transpose(enc_out, tb[:, :N])
-                ops.gemm_nt(ta, tb, out=rt.G.views[proj + ".weight"], accumulate=accumulate)
+                ops.gemm(d_emb, enc_out, out=rt.G.views[proj + ".weight"], accumulate=accumulate, a_kmajor=True,
+                         b_kmajor=True)
                 ops.colsum(d_emb, rt.G.views[proj + ".bias"], accumulate=accumulate)
         if not accumulate:
             # projector of a modality absent from this batch still owns grad slots: they must read as zero

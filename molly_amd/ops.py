@@ -29,14 +29,19 @@ def _chk(t: torch.Tensor, dtype=None, name="tensor"):
         raise ValueError(f"molly_amd: {name} must be contiguous in its last dimension")
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
-            res: Optional[torch.Tensor] = None, gelu: bool = False, accumulate: bool = False,
-            out_dtype=BF16) -> torch.Tensor:
+def gemm_nt(a, b, out=None, bias=None, res=None, gelu=False, accumulate=False, out_dtype=BF16):
     """out[M,N] = a[M,K] @ b[N,K]^T (+bias) (gelu) (+res) (+= out).  2-D views with arbitrary row stride."""
+    return gemm(a, b, out, bias, res, gelu, accumulate, out_dtype, False, False)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+         res: Optional[torch.Tensor] = None, gelu: bool = False, accumulate: bool = False, out_dtype=BF16,
+         a_kmajor: bool = False, b_kmajor: bool = False) -> torch.Tensor:
+    """out[M,N] = op(a) @ op(b): a is [M,K] (or [K,M] when a_kmajor), b is [N,K] (or [K,N] when b_kmajor)."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
-    M, K = a.shape
-    N, K2 = b.shape
-    assert K == K2, (a.shape, b.shape)
+    K, M = (a.shape if a_kmajor else a.shape[::-1])
+    K2, N = (b.shape if b_kmajor else b.shape[::-1])
+    assert K == K2, (a.shape, b.shape, a_kmajor, b_kmajor)
     if out is None:
         assert not accumulate
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
@@ -58,8 +63,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    lib().call("molly_gemm_nt_bf16", _stream(), a, b, out, bias, res, M, N, K, a.stride(0), b.stride(0), out.stride(0),
-               res.stride(0) if res is not None else 0, flags)
+    lib().call("molly_gemm_bf16", _stream(), a, b, out, bias, res, M, N, K, a.stride(0), b.stride(0), out.stride(0),
+               res.stride(0) if res is not None else 0, flags, int(a_kmajor), int(b_kmajor))
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()

@@ -6,9 +6,9 @@ HF:models/qwen3/modeling_qwen3.py:294-323 (layer), :240-281 (attention), :76-83 
 :448-507 + HF:loss/loss_utils.py:49-71 (lm_head + shifted CE).  The backward is hand-scheduled: there is no
 autograd graph and no tracing; every saved activation lives in a pre-allocated HBM slab.
 
-GEMM forms: forward  y = x W^T          -> NT on (x, W)
-                        dgrad    dx = dy W           -> NT on (dy, W^T copy)       [W^T refreshed after each optimizer step]
-                        wgrad    dW = dy^T x         -> NT on (dy^T, x^T)          [transposed on the fly]
+GEMM forms: forward  y = x W^T          -> A=x k-contiguous, B=W k-contiguous
+                        dgrad    dx = dy W           -> A=dy k-contiguous, B=W k-major        (no W^T copy)
+                        wgrad    dW = dy^T x         -> A=dy k-major, B=x k-major, K = tokens (no activation transposes)
 """
 from __future__ import annotations
 
@@ -49,7 +49,6 @@ class Qwen3Engine:
         self.ce_chunk_rows = ce_chunk_rows
         self.rope_table_dtype = rope_table_dtype
         self.cap = 0
-        self._wt: Optional[FlatBuffer] = None
         self._views()
 
     # ---- weight views ---------------------------------------------------------------------------------------
@@ -76,18 +75,8 @@ class Qwen3Engine:
             self.d_norm_w = self.G.views[self.pre + "model.norm.weight"]
 
     def refresh_transposed_weights(self):
-        """W^T copies used by the dgrad GEMMs; call after every optimizer step (weights changed)."""
-        if self._wt is None:
-            specs = []
-            for i in range(self.L):
-                specs += [(f"{i}.qkv", (self.h, self.nqkv)), (f"{i}.o", (self.nh * self.hd, self.h)),
-                          (f"{i}.gu", (self.h, 2 * self.ff)), (f"{i}.down", (self.ff, self.h))]
-            specs.append(("head", (self.h, self.V)))
-            self._wt = FlatBuffer(specs, self.dev)
-        for i, w in enumerate(self.W):
-            for k in ("qkv", "o", "gu", "down"):
-                ops.transpose(w[k], self._wt.views[f"{i}.{k}"])
-        ops.transpose(self.head, self._wt.views["head"])
+        """kept for API stability: the dgrad GEMMs read W in place (k-major operand), nothing to refresh."""
+        return
 
     # ---- activation slabs -----------------------------------------------------------------------------------
     def reserve(self, M: int, B: int, T: int, training: bool):
@@ -110,12 +99,6 @@ class Qwen3Engine:
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)   # [0]=1/n_valid [1]=n_valid [2]=loss
         self.cos, self.sin = rope_tables(T, self.hd, self.cfg.rope_theta, dev, self.rope_table_dtype)
         if training:
-            Mp = _ceil(M, 64)
-            Cp = _ceil(self.C, 64)
-            widest = max(2 * ff, self.nqkv, self.nh * self.hd, h)
-            self.tA = torch.zeros(widest * Mp, dtype=BF16, device=dev)      # dy^T scratch (zero pad columns stay zero)
-            self.tB = torch.zeros(max(ff, h, self.nh * self.hd) * Mp, dtype=BF16, device=dev)   # x^T scratch
-            self.tL = torch.zeros(self.V * Cp, dtype=BF16, device=dev)      # dlogits^T scratch
             self.d_a = e(M, h); self.d_b = e(M, h); self.d_c = e(M, h)      # residual-stream gradients (ping-pong)
             self.d_act = e(M, ff); self.d_gu = e(M, 2 * ff)
             self.d_attn = e(M, self.nh * self.hd); self.d_qkv = e(M, self.nqkv); self.d_qk = e(M, self.nqk)
@@ -123,7 +106,6 @@ class Qwen3Engine:
             nb1 = ops.lib().query("molly_rmsnorm_bwd_blocks", M)
             nb2 = ops.lib().query("molly_norm_rope_bwd_blocks")
             self.ws = torch.empty(max(nb1 * h, nb2 * 2 * self.hd), dtype=torch.float32, device=dev)
-            self.Mp, self.Cp = Mp, Cp
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward(self, inputs_embeds: torch.Tensor, B: int, T: int, kv_lo=None, kv_hi=None,
@@ -179,16 +161,15 @@ class Qwen3Engine:
         return loss, logits_all
 
     # ---- helpers ---------------------------------------------------------------------------------------------
-    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, scratch_a=None, ldp=None):
-        """dw[N,K] (+)= dy[M,N]^T x[M,K] as an NT GEMM over transposed copies (K-dim = tokens, zero-padded to 64)."""
-        M, N = dy.shape
-        K = x.shape[1]
-        ldp = ldp or self.Mp
-        ta = (scratch_a if scratch_a is not None else self.tA)[:N * ldp].view(N, ldp)
-        tb = self.tB[:K * ldp].view(K, ldp)
-        ops.transpose(dy, ta[:, :M])
-        ops.transpose(x, tb[:, :M])
-        ops.gemm_nt(ta, tb, out=dw, accumulate=accumulate)
+    @staticmethod
+    def _wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
+        """dw[N,K] (+)= dy[M,N]^T x[M,K]: both operands k-major (contraction over the token rows)."""
+        ops.gemm(dy, x, out=dw, accumulate=accumulate, a_kmajor=True, b_kmajor=True)
+
+    @staticmethod
+    def _dgrad(dy: torch.Tensor, w: torch.Tensor, out: torch.Tensor):
+        """out[M,K] = dy[M,N] w[N,K]: w read in place as the k-major B operand."""
+        ops.gemm(dy, w, out=out, b_kmajor=True)
 
     # ---- fused lm-head + CE forward/backward, then the decoder backward ---------------------------------------
     def loss_and_backward(self, accumulate: bool = False) -> torch.Tensor:
@@ -199,7 +180,6 @@ class Qwen3Engine:
         cfg, B, T = self.cfg, self.B_, self.T_
         M = B * T
         kv_lo, kv_hi = self.kv
-        wt = self._wt.views
         dh = self.d_a
         first = True
         for c0 in range(0, M, self.C):
@@ -208,20 +188,10 @@ class Qwen3Engine:
             lg = self.logits[:n]
             ops.gemm_nt(self.hn[c0:c1], self.head, out=lg)
             ops.ce_fwd_bwd(lg, self.labels[c0:c1], self.row_loss[c0:c1], self.scal[0:1], write_grad=True)
-            ops.gemm_nt(lg, wt["head"], out=dh[c0:c1])                                # d(hn) = dlogits · E
+            self._dgrad(lg, self.head, dh[c0:c1])                                     # d(hn) = dlogits · E
             # dE (+)= dlogits^T · hn   (tied embeddings: the gather-gradient is added later by the caller)
-            tl = self.tL[:self.V * self.Cp].view(self.V, self.Cp)
-            if n < self.Cp:
-                tl[:, n:].zero_()
-            ops.transpose(lg, tl[:, :n])
-            tb = self.tB[:self.h * self.Cp].view(self.h, self.Cp)
-            if n < self.Cp:
-                tb[:, n:].zero_()
-            ops.transpose(self.hn[c0:c1], tb[:, :n])
-            ops.gemm_nt(tl, tb, out=self.d_head, accumulate=accumulate or not first)
+            self._wgrad(lg, self.hn[c0:c1], self.d_head, accumulate or not first)
             first = False
-        if self.C < M or self.Cp != self.Mp:
-            self.tB.zero_()                                                           # restore the zero-pad invariant
         ops.sum_f32(self.row_loss[:M], self.scal[2:3], scale=self.scal[0:1])
         # final norm backward
         dx = self.d_b
@@ -231,17 +201,17 @@ class Qwen3Engine:
         for i in reversed(range(self.L)):
             a, w, g = self.A[i], self.W[i], self.dW[i]
             # ---- MLP: x3 = x2 + down(silu(g)*u)
-            ops.gemm_nt(dx, wt[f"{i}.down"], out=self.d_act)
+            self._dgrad(dx, w["down"], self.d_act)
             self._wgrad(dx, a["act"], g["down"], accumulate)
             ops.swiglu_bwd(a["gu"], self.d_act, self.d_gu)
             dxn2 = spare[0]
-            ops.gemm_nt(self.d_gu, wt[f"{i}.gu"], out=dxn2)
+            self._dgrad(self.d_gu, w["gu"], dxn2)
             self._wgrad(self.d_gu, a["xn2"], g["gu"], accumulate)
             dx2 = spare[1]
             ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, g["ln2"], cfg.rms_norm_eps, dres=dx, dx=dx2,
                             dw_accumulate=accumulate, workspace=self.ws)
             # ---- attention: x2 = x + o_proj(attn)
-            ops.gemm_nt(dx2, wt[f"{i}.o"], out=self.d_attn)
+            self._dgrad(dx2, w["o"], self.d_attn)
             self._wgrad(dx2, a["attn"], g["o"], accumulate)
             nq = self.nh * self.hd
             ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
@@ -251,7 +221,7 @@ class Qwen3Engine:
                               self.sin, g["qn"], g["kn"], eps=cfg.rms_norm_eps, dw_accumulate=accumulate,
                               workspace=self.ws)
             dxn = spare[0]
-            ops.gemm_nt(self.d_qkv, wt[f"{i}.qkv"], out=dxn)
+            self._dgrad(self.d_qkv, w["qkv"], dxn)
             self._wgrad(self.d_qkv, a["xn"], g["qkv"], accumulate)
             ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, g["ln1"], cfg.rms_norm_eps, dres=dx2, dx=dx,
                             dw_accumulate=accumulate, workspace=self.ws)

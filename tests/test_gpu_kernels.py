@@ -383,3 +383,72 @@ def test_esm_embed(absolute, token_dropout):
     _close(out.view(n, K, H).cpu(), ref, 2e-2, 1e-2, "esm embeddings")
     assert torch.equal(pos.cpu().long(), R.esm_position_ids(ids, 1))        # index outputs: bit-exact
     assert klen.cpu().tolist() == [30, K, K]
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 384, 512), (300, 200, 128), (2048, 1024, 2048)])
+def test_gemm_nn_dgrad_form(M, N, K):
+    """out[M,N] = a[M,K] @ w[K,N] with w read in place as the k-major B operand."""
+    a = _rand(M, K, seed=50).to(BF)
+    w = _rand(K, N, seed=51).to(BF)
+    out = ops.gemm(a, w, b_kmajor=True)
+    _close(out, a.float() @ w.float(), atol=2e-2 * math.sqrt(K / 64), rtol=8e-3, what=f"gemm NN {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("Mtok,N,K", [(256, 384, 512), (200, 264, 136), (4096, 1024, 512), (77 * 8, 128, 256)])
+def test_gemm_tn_wgrad_form(Mtok, N, K):
+    """dW[N,K] = dy[Mtok,N]^T @ x[Mtok,K]: both operands k-major, contraction length = tokens (any value)."""
+    dy = _rand(Mtok, N, seed=52).to(BF)
+    x = _rand(Mtok, K, seed=53).to(BF)
+    ref = dy.float().T @ x.float()
+    out = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    _close(out, ref, atol=1e-3 * math.sqrt(Mtok), rtol=1e-4, what=f"gemm TN {Mtok}x{N}x{K}")
+    acc = _rand(N, K, seed=54).to(BF)
+    base = acc.clone()
+    ops.gemm(dy, x, out=acc, accumulate=True, a_kmajor=True, b_kmajor=True)
+    _close(acc, ref + base.float(), atol=3e-2 * math.sqrt(Mtok / 64), rtol=8e-3, what="gemm TN accumulate")
+
+
+def test_gemm_tn_exact_small_integers():
+    g = torch.Generator().manual_seed(55)
+    dy = torch.randint(-2, 3, (192, 136), generator=g).float()
+    x = torch.randint(-2, 3, (192, 72), generator=g).float()
+    out = ops.gemm(dy.to(DEV, BF), x.to(DEV, BF), a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    assert torch.equal(out.cpu(), dy.T @ x)
+
+
+@pytest.mark.parametrize("tile", [32, 128, 256, 512])
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+def test_gemm_both_tile_configs_all_forms(tile, form):
+    """Each tile configuration (BM=128 2-stage, BM=256 3-stage ring with counted vmcnt) forced explicitly, ragged M/N."""
+    M, N, K = 520, 392, 640
+    try:
+        lib().call("molly_gemm_force_tile", tile)
+        if form == "nt":
+            a, b = _rand(M, K, seed=60).to(BF), _rand(N, K, seed=61).to(BF)
+            out, ref = ops.gemm(a, b), a.float() @ b.float().T
+        elif form == "nn":
+            a, b = _rand(M, K, seed=62).to(BF), _rand(K, N, seed=63).to(BF)
+            out, ref = ops.gemm(a, b, b_kmajor=True), a.float() @ b.float()
+        else:
+            Kt = 600                                       # token-count contraction, not a multiple of 64
+            a, b = _rand(Kt, M, seed=64).to(BF), _rand(Kt, N, seed=65).to(BF)
+            out, ref = ops.gemm(a, b, a_kmajor=True, b_kmajor=True), a.float().T @ b.float()
+        _close(out, ref, atol=8e-2, rtol=8e-3, what=f"gemm {form} tile {tile}")
+    finally:
+        lib().call("molly_gemm_force_tile", 0)
+
+
+@pytest.mark.parametrize("tile", [256, 512])
+def test_gemm_256_tile_many_k_steps_race_screen(tile):
+    """Long K (many ring revolutions) repeated: the pipelined kernels must give identical results run to run."""
+    M, N, K = 1024, 768, 8192
+    a, b = _rand(M, K, seed=66).to(BF), _rand(N, K, seed=67).to(BF)
+    try:
+        lib().call("molly_gemm_force_tile", tile)
+        first = ops.gemm(a, b, out_dtype=torch.float32).clone()
+        for _ in range(20):
+            assert torch.equal(ops.gemm(a, b, out_dtype=torch.float32), first)
+        lib().call("molly_gemm_force_tile", 128)
+        _close(first, ops.gemm(a, b, out_dtype=torch.float32), 1e-2, 1e-4, "256 vs 128 tile")
+    finally:
+        lib().call("molly_gemm_force_tile", 0)

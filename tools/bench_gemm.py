@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark on the shapes of Molly-1.7B's train step (random data, HIP events, interleaved rounds in one
+process — guide §5.4 rules 24/25).  python tools/bench_gemm.py [--tiles 128 256]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from molly_amd import ops  # noqa: E402
+from molly_amd._lib import lib  # noqa: E402
+
+M = 16384
+SHAPES = [  # (name, form, M, N, K)
+    ("qkv fwd", "nt", M, 4096, 2048), ("o fwd", "nt", M, 2048, 2048), ("gate|up fwd", "nt", M, 12288, 2048),
+    ("down fwd", "nt", M, 2048, 6144), ("lm_head fwd", "nt", M, 151936, 2048),
+    ("qkv dgrad", "nn", M, 2048, 4096), ("gate|up dgrad", "nn", M, 2048, 12288), ("down dgrad", "nn", M, 6144, 2048),
+    ("lm_head dgrad", "nn", M, 2048, 151936),
+    ("qkv wgrad", "tn", 4096, 2048, M), ("gate|up wgrad", "tn", 12288, 2048, M), ("down wgrad", "tn", 2048, 6144, M),
+    ("lm_head wgrad", "tn", 151936, 2048, M),
+    ("esm qkv", "nt", 4096, 3840, 1280), ("esm ffn1", "nt", 4096, 5120, 1280), ("esm ffn2", "nt", 4096, 1280, 5120),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, nargs="+", default=[128, 256])
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
+    print(f"{'shape':16s} {'form':4s} {'M':>7s} {'N':>7s} {'K':>7s} " + " ".join(f"{'BM' + str(t) + ' TF/s':>12s}" for t in args.tiles))
+    for name, form, m, n, k in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        if form == "nt":
+            a, b = rnd(m, k), rnd(n, k)
+            kw = {}
+        elif form == "nn":
+            a, b = rnd(m, k), rnd(k, n)
+            kw = dict(b_kmajor=True)
+        else:
+            a, b = rnd(k, m), rnd(k, n)
+            kw = dict(a_kmajor=True, b_kmajor=True)
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        best = {t: 1e9 for t in args.tiles}
+        for r in range(args.rounds):
+            for t in args.tiles:
+                lib().call("molly_gemm_force_tile", t)
+                ops.gemm(a, b, out=out, **kw)              # warm
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    ops.gemm(a, b, out=out, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                best[t] = min(best[t], e0.elapsed_time(e1) / 3)
+        lib().call("molly_gemm_force_tile", 0)
+        fl = 2.0 * m * n * k
+        print(f"{name:16s} {form:4s} {m:7d} {n:7d} {k:7d} " + " ".join(f"{fl / (best[t] * 1e-3) / 1e12:12.1f}" for t in args.tiles))
+        del a, b, out
+
+
+if __name__ == "__main__":
+    main()
