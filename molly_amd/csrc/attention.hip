@@ -32,40 +32,80 @@ struct AttnArgs {
     int causal;
 };
 
-// One LDS image serves row reads (ds_read_b128, MFMA operand with the tile row on the lane) AND transposed reads
-// (ds_read_b64_tr_b16, tile row as the contraction index) — guide T10 "One image for row reads AND transposed reads".
-// 16-byte chunk `ch` of row `row` is stored at chunk position dswz(row, ch):
-//   HD=128 (256-B rows = one bank row):  ch ^ (((row&3)<<2) | ((row>>2)&3))
-//   HD=64  (128-B rows, two per bank row): ch ^ ((((row>>1)&1)<<2) | ((row>>2)&3))
-// Both are conflict-free for the b128 row reads of 16 rows distinct mod 16 and for the 4-row x 16-column tr blocks.
-template <int HD> __device__ __forceinline__ int dswz(int row, int ch) {
-    return HD == 128 ? (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) : (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)));
+// One LDS image serves row reads (ds_read_b128: tile row on the lane) AND transposed reads (ds_read_b64_tr_b16: tile
+// row = contraction index) — guide T10.  The image is SUB-TILED: blocks of 4 rows x 16 columns (128 B, row pitch 32 B),
+// block (rowblk, colblk) stored at block index  rowblk*NCB + (colblk ^ (rowblk&1)),  NCB = HD/16, and inside a block the
+// two 16-byte halves of a row are swapped when (rowblk>>1)&1.  Consequences:
+//  * a transposed read (4 rows x 16 cols per 16-lane group, two adjacent column blocks per half-wave) touches 256
+//    CONTIGUOUS bytes -> conflict-free; a b128 row read of 16 rows distinct mod 16 hits 16 distinct 16-B slots ->
+//    conflict-free (the two swaps spread the four row-blocks of a lane group over the bank row);
+//  * every address is  lane_base + compile-time constant  (the swaps only involve lane bits), so the unrolled reads
+//    share a couple of base VGPRs and use DS immediate offsets instead of one hoisted address register each.
+template <int HD> __device__ __forceinline__ int img_off(int row, int col) {      // element offset of (row, col..col+3)
+    constexpr int NCB = HD / 16;
+    const int rowblk = row >> 2, q = row & 3, b0 = rowblk & 1, b1 = (rowblk >> 1) & 1;
+    const int colblk = col >> 4, half = (col >> 3) & 1;
+    return (rowblk * NCB + (colblk ^ b0)) * 64 + (q * 2 + (half ^ b1)) * 8 + (col & 7);
 }
-template <int HD> __device__ __forceinline__ int k_swz(int row, int ch) { return dswz<HD>(row, ch); }
-template <int HD> __device__ __forceinline__ int v_swz(int row, int ch) { return dswz<HD>(row, ch); }
 
-// stage a [64 keys][HD] tile with global_load_lds; LDS image is lane-linear, swizzle applied to the SOURCE chunk.
+// stage a [64 rows][HD] tile with global_load_lds; LDS image is lane-linear, so each lane decodes which (row, col chunk)
+// its 16-byte destination slot holds and fetches that from global memory.
 template <int HD, bool IS_V>
 __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, int key0, int T, bf16_t* lds, int wave,
                                          int lane) {
-    constexpr int CPR = HD / 8;                  // chunks per row
-    constexpr int RPI = 64 / CPR;                // rows per wave-instruction (1 KiB)
-    constexpr int NINST = BKV / RPI;             // instructions per tile
+    constexpr int NCB = HD / 16;
+    constexpr int NINST = BKV * HD * 2 / 1024;   // 1 KiB per wave-instruction
 #pragma unroll
     for (int i = 0; i < NINST / 4; ++i) {
         const int inst = wave * (NINST / 4) + i;
-        const int row = inst * RPI + lane / CPR;
-        const int cpos = lane % CPR;
-        const int csrc = IS_V ? v_swz<HD>(row, cpos) : k_swz<HD>(row, cpos);
+        const int P = inst * 64 + lane;            // destination 16-byte slot
+        const int blk = P >> 3, cin = P & 7;
+        const int rowblk = blk / NCB, cbs = blk % NCB;
+        const int b0 = rowblk & 1, b1 = (rowblk >> 1) & 1;
+        const int row = rowblk * 4 + (cin >> 1);
+        const int col = ((cbs ^ b0) << 4) + (((cin & 1) ^ b1) << 3);
         int key = key0 + row;
-        key = key < T ? key : T - 1;             // clamp; out-of-range keys are masked by index
-        const bf16_t* src = g + (size_t)key * ld + csrc * 8;
+        key = key < T ? key : T - 1;             // clamp; out-of-range rows are masked by index
+        const bf16_t* src = g + (size_t)key * ld + col;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 512), 16, 0, 0);
     }
 }
 
+// row-read fragment: tile[row][16*s + 8*h .. +7]   (row = 32*sub + (lane&31); s is a compile-time constant at call sites)
 template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t* tile, int row, int s, int h) {
+    constexpr int NCB = HD / 16;
+    const int rowblk = row >> 2, q = row & 3, b0 = rowblk & 1, b1 = (rowblk >> 1) & 1;
+    // colblk = s, half = h:  (s ^ b0) written as (s & ~1) + ((s & 1) ^ b0) so that only the parity term is per-lane
+    const int off = (rowblk * NCB + ((s & 1) ^ b0)) * 64 + (q * 2 + (h ^ b1)) * 8 + (s & ~1) * 64;
+    return *reinterpret_cast<const bf16x8*>(tile + off);
+}
+
+// A operand (row index = column d of the tile, contraction = tile row) of a 32x32x16 MFMA via ds_read_b64_tr_b16:
+// returns tile[row0 + 16*sp + perm(j,h)][32*dt + (lane&31)], j = 0..7, perm = the accumulator-as-operand k order
+// (16 sp + 8 (j>>2) + 4 h + (j&3)).  row0 must be a multiple of 32.
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int row0, int sp, int dt, int lane) {
+    constexpr int NCB = HD / 16;
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+    // rows 16sp + 4h + gq (+8): rowblk = row0/4 + 4sp + h (+2) -> b0 = h, b1 = 0 (+8: 1); colblk = 2dt + g1, half = gp>>1
+    const int base_a = (h * NCB + (g1 ^ h)) * 64 + (gq * 2 + (gp >> 1)) * 8 + (gp & 1) * 4;
+    const int base_b = ((h + 2) * NCB + (g1 ^ h)) * 64 + (gq * 2 + ((gp >> 1) ^ 1)) * 8 + (gp & 1) * 4;
+    const int cst = ((row0 >> 2) + 4 * sp) * NCB * 64 + dt * 128;
+    const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + base_a + cst));
+    const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + base_b + cst));
+    return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+}
+
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int base) {
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pack_bf2(a[base + 2 * j], a[base + 2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);        // [2 stages][K tile | V tile]
     constexpr int TILE = BKV * HD;
@@ -105,19 +145,89 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // key tiles this BLOCK needs: [first_tile, last_tile]
+    // key tiles this BLOCK needs: [t_first, t_last]; this WAVE computes tiles up to tw_last (causal diagonal)
     const int blk_q_last = min(qb * BQ + BQ - 1, T - 1);
-    int kv_end = p.causal ? min(blk_q_last + 1, hi) : hi;       // exclusive
-    int kv_begin = lo;
-    const int t_first = kv_begin / BKV;
-    const int t_last = kv_end > kv_begin ? (kv_end - 1) / BKV : t_first - 1;
+    const int kv_end = p.causal ? min(blk_q_last + 1, hi) : hi;       // exclusive
+    const int t_first = lo / BKV;
+    const int t_last = kv_end > lo ? (kv_end - 1) / BKV : t_first - 1;
+    const int tw_last = p.causal ? min(t_last, (q0 + 31) / BKV) : t_last;
+    const int qi = q0 + r;
 
+    // S^T(32 keys x 32 queries) of one half tile
+    auto qk_half = [&](const bf16_t* sK, int sub) {
+        bf16x8 kf[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kf[s] = row_frag<HD>(sK, 32 * sub + r, s, h);
+        f32x16 sc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sc, 0, 0, 0);
+        return sc;
+    };
+    auto v_half = [&](const bf16_t* sV, int sub, bf16x8 (&vf)[2][ND]) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) vf[sp][d] = tr_frag<HD>(sV, 32 * sub, sp, d, lane);
+    };
+    // online softmax of one half (keys kbase .. kbase+31) + O^T += V^T P^T
+    auto softmax_pv = [&](f32x16& sc, int kbase, const bf16x8 (&vf)[2][ND]) {
+        const bool need_mask = (p.causal && (kbase + 31 > q0)) || (kbase < lo) || (kbase + 32 > hi);
+        float mx = -INFINITY;
+        if (need_mask) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;      // accumulator row -> key index
+                const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
+                sc[e] = ok ? sc[e] * p.scale_log2 : -INFINITY;
+                mx = fmaxf(mx, sc[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sc[e] *= p.scale_log2;
+                mx = fmaxf(mx, sc[e]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // deferred rescale (guide T13): keep the old reference max unless some row's max grew by > RESCALE_THR.  The
+        // decision precedes every exponentiation of this half (textbook order), so nothing is ever half-scaled.
+        if (!__all(mx - m_run <= RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - m_use);               // m_run = -inf -> 0
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        }
+        const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
+        float rs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sc[e] = fast_exp2(sc[e] - m_ref);
+            rs += sc[e];
+        }
+        l_run += rs;                                                    // per-half-wave partial; merged at the end
+        const bf16x8 p0 = acc_to_frag(sc, 0), p1 = acc_to_frag(sc, 8);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][d], p0, o[d], 0, 0, 0);
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][d], p1, o[d], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: double-buffered K/V tiles (64 keys), two 32-key halves per tile.  Two waves per SIMD (<= 256
+    // registers) provide the matrix-pipe / VALU overlap; a source-level software pipeline (QK^T of the next half issued
+    // before the softmax of the current one) was measured slower here — it needs > 256 registers at hd 128.
     if (t_last >= t_first) {
         stage_kv<HD, false>(Kb, p.ldk, t_first * BKV, T, smem, wave, lane);
         stage_kv<HD, true>(Vb, p.ldv, t_first * BKV, T, smem + TILE, wave, lane);
     }
     __syncthreads();
-
     int cur = 0;
     for (int t = t_first; t <= t_last; ++t) {
         const bf16_t* sK = smem + cur * 2 * TILE;
@@ -128,90 +238,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             stage_kv<HD, true>(Vb, p.ldv, (t + 1) * BKV, T, nK + TILE, wave, lane);
         }
         const int k0 = t * BKV;
-        // wave-level skip: tile entirely above this wave's causal diagonal
-        const bool skip = p.causal && (k0 > q0 + 31);
-        if (!skip) {
-            // ---- S^T = K Q^T : two 32x32 accumulators (keys k0..k0+31, k0+32..k0+63)
-            f32x16 s0, s1;
+        if (t <= tw_last) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int ch = 2 * s + h;
-                const bf16x8 ka = *reinterpret_cast<const bf16x8*>(sK + r * HD + k_swz<HD>(r, ch) * 8);
-                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(sK + (r + 32) * HD + k_swz<HD>(r + 32, ch) * 8);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
-            }
-            // ---- scale + mask.  reg e of half h is key row (e&3) + 8*(e>>2) + 4h
-            const int qi = q0 + r;
-            const bool need_mask = (p.causal && (k0 + BKV - 1 > q0)) || (k0 < lo) || (k0 + BKV > hi);
-            float mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float a = s0[e] * p.scale_log2, c = s1[e] * p.scale_log2;
-                if (need_mask) {
-                    const int ka_ = k0 + (e & 3) + 8 * (e >> 2) + 4 * h, kc_ = ka_ + 32;
-                    const bool oka = ka_ >= lo && ka_ < hi && (!p.causal || ka_ <= qi);
-                    const bool okc = kc_ >= lo && kc_ < hi && (!p.causal || kc_ <= qi);
-                    a = oka ? a : -INFINITY;
-                    c = okc ? c : -INFINITY;
-                }
-                s0[e] = a; s1[e] = c;
-                mx = fmaxf(mx, fmaxf(a, c));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // deferred rescale (guide T13): keep the old reference max unless some row's max grew by > RESCALE_THR.
-            // The decision precedes every exponentiation of this tile (textbook order), so nothing is half-scaled.
-            if (!__all(mx - m_run <= RESCALE_THR)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = fast_exp2(m_run - m_use);       // m_run = -inf -> 0
-                l_run *= alpha;
-                m_run = m_new;
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-            }
-            const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
-            float rs = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s0[e] = fast_exp2(s0[e] - m_ref);
-                s1[e] = fast_exp2(s1[e] - m_ref);
-                rs += s0[e] + s1[e];
-            }
-            l_run += rs;                                            // per-half partial; halves merged at the end
-            // ---- P^T -> bf16 B operands: k-step s' uses accumulator regs 8(s'&1)..+7 of s0 (s'<2) / s1
-            bf16x8 pf[4];
-#pragma unroll
-            for (int sp = 0; sp < 4; ++sp) {
-                const f32x16& src = sp < 2 ? s0 : s1;
-                const int base = 8 * (sp & 1);
-                u32x4 w;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = pack_bf2(src[base + 2 * j], src[base + 2 * j + 1]);
-                pf[sp] = __builtin_bit_cast(bf16x8, w);
-            }
-            // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads.
-            // lane group g = lane>>4: d column block 16*(g&1), key sub-block 4*(g>>1) == 4h ; lane 4q+pp of the group
-            // supplies row q, columns 4pp..4pp+3 of the 4x16 block.
-            const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
-#pragma unroll
-            for (int sp = 0; sp < 4; ++sp) {
-#pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    const int col = 32 * d + gcol + 4 * gp;          // element column of this lane's address
-                    const int rowa = 16 * sp + 4 * h + gq;            // keys for elements 0..3
-                    const int rowb = rowa + 8;                        // keys for elements 4..7
-                    const bf16_t* pa = sV + rowa * HD + v_swz<HD>(rowa, col >> 3) * 8 + (col & 7);
-                    const bf16_t* pb = sV + rowb * HD + v_swz<HD>(rowb, col >> 3) * 8 + (col & 7);
-                    const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
-                    const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
-                    const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], o[d], 0, 0, 0);
-                }
+            for (int sub = 0; sub < 2; ++sub) {
+                if (p.causal && (k0 + 32 * sub > q0 + 31)) continue;      // half entirely above the diagonal (uniform)
+                f32x16 sc = qk_half(sK, sub);
+                bf16x8 vf[2][ND];
+                v_half(sV, sub, vf);
+                softmax_pv(sc, k0 + 32 * sub, vf);
             }
         }
         __syncthreads();
@@ -221,7 +255,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     // ---- epilogue: O[q][d] = o / l ; LSE2 = m + log2(l)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    const int qi = q0 + r;
     if (qi < T) {
         bf16_t* op = p.O + ((size_t)b * T + qi) * p.ldo + head * HD;
 #pragma unroll
@@ -284,33 +317,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     }
 }
 
-// A operand (row index = d, contraction = tile row) of a 32x32x16 MFMA from a row-major [rows][HD] LDS tile via
-// ds_read_b64_tr_b16: returns tile[row0 + 16*sp + perm(j,h)][32*dt + (lane&31)] for j = 0..7.
-template <int HD>
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int row0, int sp, int dt, int lane) {
-    const int h = lane >> 5, gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = 16 * ((lane >> 4) & 1);
-    const int col = 32 * dt + gcol + 4 * gp;
-    const int rowa = row0 + 16 * sp + 4 * h + gq, rowb = rowa + 8;
-    const bf16_t* pa = tile + rowa * HD + dswz<HD>(rowa, col >> 3) * 8 + (col & 7);
-    const bf16_t* pb = tile + rowb * HD + dswz<HD>(rowb, col >> 3) * 8 + (col & 7);
-    const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
-    const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
-    return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-}
-// row-read fragment: tile[row][16*s + 8*h .. +7]
-template <int HD>
-__device__ __forceinline__ bf16x8 row_frag(const bf16_t* tile, int row, int s, int h) {
-    return *reinterpret_cast<const bf16x8*>(tile + row * HD + dswz<HD>(row, 2 * s + h) * 8);
-}
-__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int base) {
-    u32x4 w;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = pack_bf2(a[base + 2 * j], a[base + 2 * j + 1]);
-    return __builtin_bit_cast(bf16x8, w);
-}
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);        // [2 stages][K tile | V tile]
     constexpr int TILE = BKV * HD;
