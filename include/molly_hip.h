@@ -48,6 +48,9 @@ int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, cons
 int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N,
                     int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor, int b_kmajor);
 
+/* fp32 scratch the GEMM may use for split-K partial slabs (wgrad shapes whose 256x256 grid would not fill the chip);
+ * caller-owned device memory, stays valid until replaced; NULL / 0 disables split-K. */
+int molly_gemm_set_workspace(void* ptr, long bytes);
 /* tuning/test hook: 0 = heuristic tile choice, 128 / 256 = force that BM tile configuration of the GEMM kernel. */
 int molly_gemm_force_tile(int bm);
 

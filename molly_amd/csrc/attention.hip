@@ -115,9 +115,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int nqb = gridDim.x;
-    const int qb = nqb - 1 - blockIdx.x;                       // heaviest (latest) causal blocks first
-    const int head = blockIdx.y, b = blockIdx.z;
+    // grid: x = head + n_heads*batch (fastest), y = query-block slot.  The dispatcher hands out blocks in linear order,
+    // so the heaviest causal blocks (largest query index) all start first and the light ones fill the tail (LPT).
+    const int nqb = gridDim.y;
+    const int qb = nqb - 1 - blockIdx.y;
+    const int head = blockIdx.x % p.nh, b = blockIdx.x / p.nh;
     const int kvh = head / (p.nh / p.nkv);
     const int q0 = qb * BQ + wave * 32;                        // this wave's first query row
     const int T = p.T;
@@ -327,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int qb = gridDim.x - 1 - blockIdx.x;
-    const int head = blockIdx.y, b = blockIdx.z;
+    const int qb = gridDim.y - 1 - blockIdx.y;                 // heaviest first (see attn_fwd_kernel)
+    const int head = blockIdx.x % p.nh, b = blockIdx.x / p.nh;
     const int kvh = head / (p.nh / p.nkv);
     const int q0 = qb * BQ + wave * 32;
     const int T = p.T;
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int kb = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    // causal: key block 0 sees every query tile (heaviest) -> slot order = key-block order already is heaviest-first
+    const int kb = blockIdx.y, kvh = blockIdx.x % p.nkv, b = blockIdx.x / p.nkv;
     const int group = p.nh / p.nkv;
     const int T = p.T;
     const int lo = p.kv_lo ? p.kv_lo[b] : 0;
@@ -473,14 +476,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
         bf16_t* sQ = smem + stg * 2 * TILE;
         stage_kv<HD, false>(Qb, p.ldq, qt * BKV, T, sQ, wave, lane);
         stage_kv<HD, false>(Db, p.ldo, qt * BKV, T, sQ + TILE, wave, lane);
-        if (tid < 128) {
-            const int j = tid & 63;
-            int q = qt * BKV + j;
+        // row statistics through LDS-DMA as well (4 B/lane): an ordinary global_load here would make hipcc drain
+        // vmcnt(0) — i.e. the whole tile prefetch — at its first use (guide §5 "Three .s-level traps" (b))
+        if (wave < 2) {
+            int q = qt * BKV + lane;
             q = q < T ? q : T - 1;
             const size_t idx = ((size_t)b * p.nh + head) * T + q;
-            float v = tid < 64 ? p.LSE[idx] : p.delta[idx];
-            if (tid < 64 && v == -INFINITY) v = 0.f;
-            sStat[stg * 128 + tid] = v;
+            const float* src = wave == 0 ? p.LSE + idx : p.delta + idx;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sStat + stg * 128 + wave * 64), 4, 0, 0);
         }
     };
     if (total > 0) stage(0, 0);
@@ -558,7 +561,7 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     MOLLY_CHECK(B > 0 && T > 0, "attn_fwd: empty problem");
     AttnArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, lse2, kv_lo, kv_hi, T, n_heads,
                n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal};
-    dim3 grid(cdiv(T, BQ), n_heads, B);
+    dim3 grid(n_heads * B, cdiv(T, BQ));
     const size_t lds = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -603,7 +606,7 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
         attr_set = true;
     }
-    dim3 gq(cdiv(T, BQ), n_heads, B), gk(cdiv(T, 128), n_kv_heads, B);
+    dim3 gq(n_heads * B, cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(256), lds_dkv, st, p);

@@ -204,43 +204,65 @@ struct RopeArgs {
     float eps, q_scale;
 };
 
+// each thread owns 4 consecutive (i, i+hd/2) pairs -> 8-byte loads/stores; hd/8 threads per head
 __global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
     const int half = p.hd >> 1;
-    const int heads_per_blk = 256 / half;
-    const int i = threadIdx.x % half;
-    const long item = (long)blockIdx.x * heads_per_blk + threadIdx.x / half;
+    const int tph = half >> 2;                          // threads per head
+    const int heads_per_blk = 256 / tph;
+    const int i = (threadIdx.x % tph) * 4;
+    const long item = (long)blockIdx.x * heads_per_blk + threadIdx.x / tph;
     const int nh = p.nq + p.nk;
     const long total = (long)p.M * nh;
     const bool live = item < total;
     const int m = live ? (int)(item / nh) : 0, head = live ? (int)(item % nh) : 0;
     const bf16_t* s = p.src + (size_t)m * p.ld_src + head * p.hd;
-    float x1 = live ? bf2f(s[i]) : 0.f, x2 = live ? bf2f(s[i + half]) : 0.f;
+    float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+    if (live) {
+        const u32x2 a = *reinterpret_cast<const u32x2*>(s + i), b = *reinterpret_cast<const u32x2*>(s + i + half);
+        x1[0] = bflo(a[0]); x1[1] = bfhi(a[0]); x1[2] = bflo(a[1]); x1[3] = bfhi(a[1]);
+        x2[0] = bflo(b[0]); x2[1] = bfhi(b[0]); x2[2] = bflo(b[1]); x2[3] = bfhi(b[1]);
+    }
     const bool isq = head < p.nq;
     const bf16_t* w = isq ? p.qw : p.kw;
     if (w) {
-        float ss = x1 * x1 + x2 * x2;
-        for (int o = half >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
+        for (int o = tph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         const float rstd = rsqrtf(ss / (float)p.hd + p.eps);
-        x1 = bf2f(f2bf(x1 * rstd)) * bf2f(w[i]);
-        x2 = bf2f(f2bf(x2 * rstd)) * bf2f(w[i + half]);
-        x1 = bf2f(f2bf(x1));
-        x2 = bf2f(f2bf(x2));
+        const u32x2 wa = *reinterpret_cast<const u32x2*>(w + i), wb = *reinterpret_cast<const u32x2*>(w + i + half);
+        const float w1[4] = {bflo(wa[0]), bfhi(wa[0]), bflo(wa[1]), bfhi(wa[1])};
+        const float w2[4] = {bflo(wb[0]), bfhi(wb[0]), bflo(wb[1]), bfhi(wb[1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x1[e] = bf2f(f2bf(bf2f(f2bf(x1[e] * rstd)) * w1[e]));      // HF: bf16(x*rstd) then * gain (bf16)
+            x2[e] = bf2f(f2bf(bf2f(f2bf(x2[e] * rstd)) * w2[e]));
+        }
     }
     if (isq && p.q_scale != 1.0f) {
-        x1 = bf2f(f2bf(x1 * p.q_scale));
-        x2 = bf2f(f2bf(x2 * p.q_scale));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x1[e] = bf2f(f2bf(x1[e] * p.q_scale));
+            x2[e] = bf2f(f2bf(x2[e] * p.q_scale));
+        }
     }
-    float y1 = x1, y2 = x2;
+    float y1[4], y2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
     if (p.cos) {
         const int pos = p.pos ? p.pos[m] : (m % p.T);
-        const float c = p.cos[(size_t)pos * half + i], sn = p.sin[(size_t)pos * half + i];
-        y1 = x1 * c - x2 * sn;
-        y2 = x2 * c + x1 * sn;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)pos * half + i);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sin + (size_t)pos * half + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y1[e] = x1[e] * c[e] - x2[e] * sn[e];
+            y2[e] = x2[e] * c[e] + x1[e] * sn[e];
+        }
     }
     if (live) {
         bf16_t* d = p.dst + (size_t)m * p.ld_dst + head * p.hd;
-        d[i] = f2bf(y1);
-        d[i + half] = f2bf(y2);
+        *reinterpret_cast<u32x2*>(d + i) = u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])};
+        *reinterpret_cast<u32x2*>(d + i + half) = u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
     }
 }
 
@@ -261,13 +283,14 @@ __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char sm_raw[];
     float* sdw = reinterpret_cast<float*>(sm_raw);          // [2][hd]
     const int half = p.hd >> 1;
-    const int heads_per_it = 256 / half;
-    const int i = threadIdx.x % half, sub = threadIdx.x / half;
+    const int tph = half >> 2;
+    const int heads_per_it = 256 / tph;
+    const int i = (threadIdx.x % tph) * 4, sub = threadIdx.x / tph;
     const int nh = p.nq + p.nk;
     const long total = (long)p.M * nh;
     for (int t = threadIdx.x; t < 2 * p.hd; t += 256) sdw[t] = 0.f;
     __syncthreads();
-    float dwq1 = 0.f, dwq2 = 0.f, dwk1 = 0.f, dwk2 = 0.f;
+    float dwq1[4] = {0, 0, 0, 0}, dwq2[4] = {0, 0, 0, 0}, dwk1[4] = {0, 0, 0, 0}, dwk2[4] = {0, 0, 0, 0};
     const long begin = (long)blockIdx.x * p.items_per_blk;
     const long end = min(begin + p.items_per_blk, total);
     for (long base = begin; base < end; base += heads_per_it) {
@@ -277,43 +300,68 @@ __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
         const bool isq = head < p.nq;
         const bf16_t* s = p.src + (size_t)m * p.ld_src + head * p.hd;
         const bf16_t* gg = p.g + (size_t)m * p.ld_g + head * p.hd;
-        const float x1 = live ? bf2f(s[i]) : 0.f, x2 = live ? bf2f(s[i + half]) : 0.f;
-        float g1 = live ? bf2f(gg[i]) : 0.f, g2 = live ? bf2f(gg[i + half]) : 0.f;
+        float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0}, g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
+        if (live) {
+            const u32x2 a = *reinterpret_cast<const u32x2*>(s + i), b = *reinterpret_cast<const u32x2*>(s + i + half);
+            const u32x2 c = *reinterpret_cast<const u32x2*>(gg + i), d = *reinterpret_cast<const u32x2*>(gg + i + half);
+            x1[0] = bflo(a[0]); x1[1] = bfhi(a[0]); x1[2] = bflo(a[1]); x1[3] = bfhi(a[1]);
+            x2[0] = bflo(b[0]); x2[1] = bfhi(b[0]); x2[2] = bflo(b[1]); x2[3] = bfhi(b[1]);
+            g1[0] = bflo(c[0]); g1[1] = bfhi(c[0]); g1[2] = bflo(c[1]); g1[3] = bfhi(c[1]);
+            g2[0] = bflo(d[0]); g2[1] = bfhi(d[0]); g2[2] = bflo(d[1]); g2[3] = bfhi(d[1]);
+        }
         if (p.cos) {
             const int pos = p.pos ? p.pos[m] : (m % p.T);
-            const float c = p.cos[(size_t)pos * half + i], sn = p.sin[(size_t)pos * half + i];
-            const float t1 = g1 * c + g2 * sn, t2 = g2 * c - g1 * sn;
-            g1 = t1; g2 = t2;
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)pos * half + i);
+            const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sin + (size_t)pos * half + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t1 = g1[e] * c[e] + g2[e] * sn[e], t2 = g2[e] * c[e] - g1[e] * sn[e];
+                g1[e] = t1; g2[e] = t2;
+            }
         }
         const bf16_t* w = isq ? p.qw : p.kw;
-        float d1 = g1, d2 = g2;
+        float d1[4], d2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d1[e] = g1[e]; d2[e] = g2[e]; }
         if (w) {
-            const float w1 = bf2f(w[i]), w2 = bf2f(w[i + half]);
-            float ss = x1 * x1 + x2 * x2;
-            float dot = g1 * w1 * x1 + g2 * w2 * x2;
-            for (int o = half >> 1; o > 0; o >>= 1) {
+            const u32x2 wa = *reinterpret_cast<const u32x2*>(w + i), wb = *reinterpret_cast<const u32x2*>(w + i + half);
+            const float w1[4] = {bflo(wa[0]), bfhi(wa[0]), bflo(wa[1]), bfhi(wa[1])};
+            const float w2[4] = {bflo(wb[0]), bfhi(wb[0]), bflo(wb[1]), bfhi(wb[1])};
+            float ss = 0.f, dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += x1[e] * x1[e] + x2[e] * x2[e];
+                dot += g1[e] * w1[e] * x1[e] + g2[e] * w2[e] * x2[e];
+            }
+            for (int o = tph >> 1; o > 0; o >>= 1) {
                 ss += __shfl_xor(ss, o, 64);
                 dot += __shfl_xor(dot, o, 64);
             }
             const float rstd = rsqrtf(ss / (float)p.hd + p.eps);
             const float coef = dot * rstd * rstd * rstd / (float)p.hd;
-            d1 = g1 * w1 * rstd - x1 * coef;
-            d2 = g2 * w2 * rstd - x2 * coef;
-            if (live) {
-                if (isq) { dwq1 += g1 * x1 * rstd; dwq2 += g2 * x2 * rstd; }
-                else     { dwk1 += g1 * x1 * rstd; dwk2 += g2 * x2 * rstd; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                d1[e] = g1[e] * w1[e] * rstd - x1[e] * coef;
+                d2[e] = g2[e] * w2[e] * rstd - x2[e] * coef;
+                if (live) {
+                    if (isq) { dwq1[e] += g1[e] * x1[e] * rstd; dwq2[e] += g2[e] * x2[e] * rstd; }
+                    else     { dwk1[e] += g1[e] * x1[e] * rstd; dwk2[e] += g2[e] * x2[e] * rstd; }
+                }
             }
         }
         if (live) {
             bf16_t* d = p.dsrc + (size_t)m * p.ld_out + head * p.hd;
-            d[i] = f2bf(d1);
-            d[i + half] = f2bf(d2);
+            *reinterpret_cast<u32x2*>(d + i) = u32x2{pack_bf2(d1[0], d1[1]), pack_bf2(d1[2], d1[3])};
+            *reinterpret_cast<u32x2*>(d + i + half) = u32x2{pack_bf2(d2[0], d2[1]), pack_bf2(d2[2], d2[3])};
         }
     }
-    atomicAdd(&sdw[i], dwq1);
-    atomicAdd(&sdw[i + half], dwq2);
-    atomicAdd(&sdw[p.hd + i], dwk1);
-    atomicAdd(&sdw[p.hd + i + half], dwk2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        atomicAdd(&sdw[i + e], dwq1[e]);
+        atomicAdd(&sdw[i + e + half], dwq2[e]);
+        atomicAdd(&sdw[p.hd + i + e], dwk1[e]);
+        atomicAdd(&sdw[p.hd + i + e + half], dwk2[e]);
+    }
     __syncthreads();
     for (int t = threadIdx.x; t < 2 * p.hd; t += 256) p.dw_part[(size_t)blockIdx.x * 2 * p.hd + t] = sdw[t];
 }
@@ -785,12 +833,13 @@ extern "C" int molly_norm_rope_fwd(void* stream, const void* src, void* dst, con
                                    const float* cos, const float* sin, const int* positions, int M, int T, int n_q_heads,
                                    int n_k_heads, int head_dim, int ld_src, int ld_dst, float eps, float q_scale) {
     MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0, "norm_rope: head_dim=%d", head_dim);
+    MOLLY_CHECK(ld_src % 4 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 8) == 0, "norm_rope: 8-byte alignment required");
     MOLLY_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr), "norm_rope: give both norm gains or neither");
     MOLLY_CHECK((cos == nullptr) == (sin == nullptr), "norm_rope: give both cos and sin or neither");
     RopeArgs p{(const bf16_t*)src, (bf16_t*)dst, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, cos, sin, positions,
                M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_dst, eps, q_scale};
     const long items = (long)M * (n_q_heads + n_k_heads);
-    const int hpb = 256 / (head_dim / 2);
+    const int hpb = 256 / (head_dim / 8);
     hipLaunchKernelGGL(norm_rope_fwd_kernel, dim3((unsigned)((items + hpb - 1) / hpb)), dim3(256), 0, ST, p);
     MOLLY_LAUNCH_CHECK();
     return 0;
@@ -808,7 +857,7 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
     MOLLY_CHECK(workspace, "norm_rope_bwd: workspace of molly_norm_rope_bwd_blocks()*2*head_dim floats required");
     const int nb = molly_norm_rope_bwd_blocks();
     const long items = (long)M * (n_q_heads + n_k_heads);
-    const int hpi = 256 / (head_dim / 2);
+    const int hpi = 256 / (head_dim / 8);
     long ipb = (items + nb - 1) / nb;
     ipb = (ipb + hpi - 1) / hpi * hpi;
     RopeBwdArgs p{(const bf16_t*)src, (const bf16_t*)g, (bf16_t*)dsrc, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w,

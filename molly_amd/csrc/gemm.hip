@@ -31,6 +31,8 @@ struct GemmArgs {
     int flags;
     int tiles_m, tiles_n;
     const bf16_t* zeros;      // >= 16 bytes of zeros: source of k-rows beyond K for k-major operands
+    int splits;               // split-K factor of the 256x256 kernel (1 = none)
+    float* ws;                // fp32 partial slabs [splits][M][N] when splits > 1
 };
 
 // ---- k-contiguous operand: tile [ROWS][64] bf16 (128-B LDS rows); one wave-instruction = 8 rows (1 KiB).
@@ -275,7 +277,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int split = work % p.splits;        // slices of one tile are adjacent work items (same XCD under round-robin)
+    const int swz = work / p.splits;
     constexpr int GROUP_M = 4;
     const int per_group = GROUP_M * p.tiles_n;
     const int grp = swz / per_group;
@@ -291,10 +295,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
-    // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1
-    auto issue = [&](int kt, int which) {
-        bf16_t* dst = smem + ((kt & 1) * 4 + which) * HT;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = (int)((long)nk_all * split / p.splits), kt1 = (int)((long)nk_all * (split + 1) / p.splits);
+    const int nk = kt1 - kt0;                 // K-tiles of this slice
+    // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; kt is slice-local
+    auto issue = [&](int ktl, int which) {
+        const int kt = kt0 + ktl;
+        bf16_t* dst = smem + ((ktl & 1) * 4 + which) * HT;
         if (which < 2) {
             if (AT) stage_km<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, p.K, p.zeros, dst, wave, lane);
             else stage_kc<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, dst, wave, lane);
@@ -392,6 +399,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #undef MMA_QUAD
 #undef SEG_BARRIER
 
+    if (p.splits > 1) {
+        // split-K: plain fp32 partial slab of this slice; molly's splitk_reduce kernel sums the slabs (launch-boundary
+        // reduce: cheaper than an in-launch combine at these slab sizes, guide §5 "Projection GEMM" item 2)
+        float* slab = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                if (n >= p.N) continue;
+                *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: lane owns C[m = .. + fr][n = .. + fq*4 + 0..3]
     const bool has_bias = p.flags & MOLLY_GEMM_BIAS, has_res = p.flags & MOLLY_GEMM_RESIDUAL;
     const bool gelu = p.flags & MOLLY_GEMM_GELU, accum = p.flags & MOLLY_GEMM_ACCUMULATE;
@@ -436,6 +461,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
 }
 
+// out[m,n] (+)= sum_s slab[s][m][n]   (split-K combine; 4 elements per thread)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long MN, int M, int N,
+                                                            void* C, int ldc, int out_f32, int accumulate) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long)gridDim.x * 1024) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
+        for (int s = 1; s < splits; ++s) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(ws + (size_t)s * MN + i);
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        const long m = i / N;
+        const int n = (int)(i % N);
+        if (out_f32) {
+            float* c = reinterpret_cast<float*>(C) + m * ldc + n;
+            if (accumulate) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(c);
+                a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3];
+            }
+            *reinterpret_cast<f32x4*>(c) = a;
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(C) + m * ldc + n;
+            if (accumulate) {
+                const u32x2 o = *reinterpret_cast<const u32x2*>(c);
+                a[0] += bflo(o[0]); a[1] += bfhi(o[0]); a[2] += bflo(o[1]); a[3] += bfhi(o[1]);
+            }
+            *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+        }
+    }
+}
+
+float* g_ws = nullptr;
+size_t g_ws_bytes = 0;
+
 __device__ bf16_t g_zero_page[64];      // zero-initialised device memory (k-rows beyond K)
 
 template <bool AT, bool BT>
@@ -449,12 +506,32 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
                                   2 * (128 + BN) * 64 * 2);
         attr_set = true;
     }
-    // heuristic: the 256x256 ping-pong kernel when its grid fills the 256 CUs without a long tail, else 128x128
+    // heuristic: the 256x256 ping-pong kernel when its grid fills the 256 CUs without a long tail; if it does not and K
+    // is long (wgrad: K = tokens), split K so that tiles x splits does (fp32 slabs + a reduce launch); else 128x128.
+    p.splits = 1;
+    p.ws = nullptr;
     if (force_tile == 0) {
         const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256);
-        const long rounds = (t256 + 255) / 256;
-        const double eff = (double)t256 / (double)(rounds * 256);
-        force_tile = (t256 >= 200 && eff >= 0.8) ? 512 : 128;
+        auto eff = [](long items) { return (double)items / (double)(((items + 255) / 256) * 256); };
+        if (t256 >= 200 && eff(t256) >= 0.8) {
+            force_tile = 512;
+        } else {
+            const int nk = cdiv(p.K, 64);
+            const bool plain_epilogue = !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_GELU | MOLLY_GEMM_RESIDUAL));
+            int best = 0;
+            for (int sp : {2, 3, 4, 6, 8}) {
+                if (nk / sp < 16) break;                                   // keep >= 1024-deep slices
+                if ((size_t)sp * p.M * p.N * sizeof(float) > g_ws_bytes) break;
+                if (t256 * sp >= 200 && eff(t256 * sp) >= 0.85) { best = sp; break; }
+            }
+            if (best && plain_epilogue && p.N % 4 == 0 && p.M >= 256 && p.N >= 256) {
+                force_tile = 512;
+                p.splits = best;
+                p.ws = g_ws;
+            } else {
+                force_tile = 128;
+            }
+        }
     }
     if (force_tile == 512) {
         static bool a2 = false;
@@ -463,7 +540,13 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             a2 = true;
         }
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
-        hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(p.tiles_m * p.tiles_n), dim3(512), 131072, st, p);
+        hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), 131072, st, p);
+        if (p.splits > 1) {
+            const long MN = (long)p.M * p.N;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, p.ws,
+                               p.splits, MN, p.M, p.N, p.C, p.ldc, (p.flags & MOLLY_GEMM_OUT_F32) ? 1 : 0,
+                               (p.flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0);
+        }
     } else if (force_tile == 256) {
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, BN);
         hipLaunchKernelGGL((gemm_kernel<AT, BT, 256, 3, 64>), dim3(p.tiles_m * p.tiles_n), dim3(512),
@@ -532,6 +615,14 @@ extern "C" int molly_gemm_bf16(void* stream, const void* A, const void* B, void*
                                int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor,
                                int b_kmajor) {
     return launch_gemm(stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, a_kmajor != 0, b_kmajor != 0);
+}
+
+// fp32 scratch for split-K partial slabs (caller-owned device memory; NULL/0 disables split-K)
+extern "C" int molly_gemm_set_workspace(void* ptr, long bytes) {
+    MOLLY_CHECK(bytes >= 0 && ((uintptr_t)ptr % 16) == 0, "gemm_set_workspace: pointer must be 16-byte aligned");
+    g_ws = (float*)ptr;
+    g_ws_bytes = ptr ? (size_t)bytes : 0;
+    return 0;
 }
 
 // tuning/test hook: 0 = heuristic, 128 or 256 = force that BM tile configuration

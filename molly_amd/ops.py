@@ -29,6 +29,18 @@ def _chk(t: torch.Tensor, dtype=None, name="tensor"):
         raise ValueError(f"molly_amd: {name} must be contiguous in its last dimension")
 
 
+_GEMM_WS = None
+
+
+def ensure_gemm_workspace(nbytes: int = 512 << 20, device="cuda"):
+    """Register an fp32 scratch slab for split-K partials (idempotent; grows only)."""
+    global _GEMM_WS
+    if _GEMM_WS is None or _GEMM_WS.numel() * 4 < nbytes:
+        _GEMM_WS = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        lib().call("molly_gemm_set_workspace", _GEMM_WS, _GEMM_WS.numel() * 4)
+    return _GEMM_WS
+
+
 def gemm_nt(a, b, out=None, bias=None, res=None, gelu=False, accumulate=False, out_dtype=BF16):
     """out[M,N] = a[M,K] @ b[N,K]^T (+bias) (gelu) (+res) (+= out).  2-D views with arbitrary row stride."""
     return gemm(a, b, out, bias, res, gelu, accumulate, out_dtype, False, False)

@@ -103,6 +103,8 @@ class Qwen3Engine:
             self.d_act = e(M, ff); self.d_gu = e(M, 2 * ff)
             self.d_attn = e(M, self.nh * self.hd); self.d_qkv = e(M, self.nqkv); self.d_qk = e(M, self.nqk)
             self.delta = e(B, self.nh, T, dt=torch.float32)
+            # split-K scratch for the wgrad GEMMs: 8 slabs of the largest per-layer weight
+            ops.ensure_gemm_workspace(8 * 4 * max(2 * ff * h, self.nqkv * h), dev)
             nb1 = ops.lib().query("molly_rmsnorm_bwd_blocks", M)
             nb2 = ops.lib().query("molly_norm_rope_bwd_blocks")
             self.ws = torch.empty(max(nb1 * h, nb2 * 2 * self.hd), dtype=torch.float32, device=dev)

@@ -452,3 +452,20 @@ def test_gemm_256_tile_many_k_steps_race_screen(tile):
         _close(first, ops.gemm(a, b, out_dtype=torch.float32), 1e-2, 1e-4, "256 vs 128 tile")
     finally:
         lib().call("molly_gemm_force_tile", 0)
+
+
+def test_gemm_splitk_wgrad_path():
+    """wgrad-shaped problem whose 256x256 grid is small: the heuristic splits K into fp32 slabs + reduce."""
+    ops.ensure_gemm_workspace(256 << 20)
+    Mtok, N, K = 8192, 1024, 768
+    dy, x = _rand(Mtok, N, seed=70).to(BF), _rand(Mtok, K, seed=71).to(BF)
+    ref = dy.float().T @ x.float()
+    out = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    _close(out, ref, atol=1e-3 * math.sqrt(Mtok), rtol=1e-4, what="split-K wgrad fp32")
+    acc = _rand(N, K, seed=72).to(BF)
+    base = acc.clone()
+    ops.gemm(dy, x, out=acc, accumulate=True, a_kmajor=True, b_kmajor=True)
+    _close(acc, ref + base.float(), atol=0.5, rtol=8e-3, what="split-K wgrad bf16 accumulate")
+    first = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32).clone()
+    for _ in range(5):
+        assert torch.equal(ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32), first)
