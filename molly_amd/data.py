@@ -80,8 +80,16 @@ class OmicsDataset(torch.utils.data.Dataset):
         self.system_prompt_ids = t.encode(SYSTEM_PROMPT, add_special_tokens=False)
         self.assistant_start_ids = t.encode(ASSISTANT_START, add_special_tokens=False)
         if isinstance(rows, str):
-            import pandas as pd
-            rows = pd.read_parquet(rows)
+            if rows.endswith((".jsonl", ".json")):    # same schema, one JSON object per line (no parquet engine needed)
+                import json as _json
+                with open(rows) as f:
+                    rows = [_json.loads(l) for l in f if l.strip()]
+                if shuffle:
+                    import pandas as pd
+                    rows = pd.DataFrame(rows)
+            else:
+                import pandas as pd
+                rows = pd.read_parquet(rows)
         if hasattr(rows, "to_dict"):          # DataFrame: same head()/shuffle semantics as the reference (:96-105)
             df = rows
             if read_nums:

@@ -1,0 +1,141 @@
+"""Training loop of the hot path — the step semantics the reference inherits from HF Trainer 4.53 + DeepSpeed
+(spec = the pasted loop, reference src/trainer/domain_loss.py:565-770, 881-1024, 844-873):
+
+  * gradient accumulation windows of `gradient_accumulation_steps` micro-batches; the micro-batch loss is the token mean
+    of THAT micro-batch and is NOT divided by the accumulation count (the model's forward has **kwargs, :1011-1013;
+    SURVEY.md §0.4-4) -> gradients are SUMMED over the window;
+  * per window: reduce-scatter -> global-norm clip (max_grad_norm) -> AdamW -> LR scheduler step -> zero grads (:676-724);
+  * linear warmup (warmup_ratio) then linear decay (HF `linear` schedule); lr of optimizer step k uses k scheduler steps;
+  * logged loss = sum of the window's micro losses, averaged over the optimizer steps since the last log and over ranks
+    (:856-861) — i.e. GA x larger than a per-micro-batch mean, exactly like upstream;
+  * non-finite micro losses are replaced by the running average in the LOG only (:655-661);
+  * checkpoints: `checkpoint-N/pytorch_model.bin` = torch pickle of the full state dict incl. frozen encoders
+    (src/trainer/omics_trainer.py:105), rotated by save_total_limit.
+Batches are dealt to ranks round-robin (rank r takes micro-batches r, r+DP, ... of one seeded permutation), the
+partitioning accelerate's BatchSamplerShard applies in the reference.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import shutil
+import time
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .zero2 import Zero2Optimizer, linear_warmup_lr
+
+
+@dataclass
+class TrainArgs:
+    output_dir: str = "out"
+    per_device_train_batch_size: int = 1
+    gradient_accumulation_steps: int = 1
+    num_train_epochs: float = 1.0
+    max_steps: int = -1
+    learning_rate: float = 3e-5
+    weight_decay: float = 1e-2
+    warmup_ratio: float = 0.1
+    max_grad_norm: float = 1.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    logging_steps: int = 20
+    save_steps: int = 0
+    save_total_limit: Optional[int] = None
+    seed: int = 42
+
+
+def save_model(model, output_dir: str):
+    """reference: OmicsTrainer.save_model -> `pytorch_model.bin` with the reference's keys."""
+    os.makedirs(output_dir, exist_ok=True)
+    sd = {k: v.detach().to("cpu").clone() for k, v in model.state_dict().items()}
+    torch.save(sd, os.path.join(output_dir, "pytorch_model.bin"))
+    # the projectors on their own as well (what the LoRA branch of the reference writes and inference_lora.py reads)
+    for name in ("dna_rna_projector", "protein_projector"):
+        torch.save({k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")},
+                   os.path.join(output_dir, f"{name}.bin"))
+
+
+class Trainer:
+    def __init__(self, model, train_dataset, collate_fn: Callable, args: TrainArgs, log_fn: Callable = print):
+        self.model, self.ds, self.collate, self.args, self.log = model, train_dataset, collate_fn, args, log_fn
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        rt = model._runtime()
+        self.opt = Zero2Optimizer(rt.P.flat, rt.G.flat, model.n_decay, lr=args.learning_rate,
+                                  betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
+                                  weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm)
+        self.history: List[dict] = []
+
+    def _micro_batches(self, epoch: int):
+        a = self.args
+        g = torch.Generator().manual_seed(a.seed + epoch)
+        perm = torch.randperm(len(self.ds), generator=g).tolist()
+        B = a.per_device_train_batch_size
+        n_micro = len(perm) // B                                   # drop_last=False upstream; the tail batch is dealt too
+        if len(perm) % B:
+            n_micro += 1
+        for mb in range(self.rank, n_micro - (n_micro % self.world if self.world > 1 else 0), self.world):
+            idx = perm[mb * B:(mb + 1) * B]
+            yield self.collate([self.ds[i] for i in idx])
+
+    def train(self):
+        a, m = self.args, self.model
+        B, GA = a.per_device_train_batch_size, a.gradient_accumulation_steps
+        micro_per_epoch = math.ceil(len(self.ds) / B) // self.world
+        steps_per_epoch = max(micro_per_epoch // GA, 1)
+        total = a.max_steps if a.max_steps > 0 else math.ceil(a.num_train_epochs * steps_per_epoch)
+        warmup = math.ceil(total * a.warmup_ratio)
+        step, epoch = 0, 0
+        window_loss = torch.zeros((), dtype=torch.float32, device=m._rt.dev)
+        log_acc, last_logged, t0 = 0.0, 0, time.time()
+        while step < total:
+            micro = 0
+            for batch in self._micro_batches(epoch):
+                loss = m.forward_backward(batch["input_ids"], batch["attention_mask"], batch["omic_ids"],
+                                          batch["omic_info_list"], batch["labels"], accumulate=micro > 0)
+                window_loss += loss
+                micro += 1
+                if micro < GA:
+                    continue
+                lr = linear_warmup_lr(step, a.learning_rate, warmup, total)
+                gnorm = self.opt.step(lr=lr)
+                step += 1
+                micro = 0
+                if step % a.logging_steps == 0 or step == total:
+                    wl = window_loss.clone()
+                    if self.world > 1:
+                        dist.all_reduce(wl)
+                        wl /= self.world
+                    v = float(wl.item())
+                    if not math.isfinite(v):                        # reference: NaN/Inf filter for the LOG only
+                        v = log_acc / max(last_logged, 1)
+                    rec = {"step": step, "loss": round(v / (step - last_logged), 4), "grad_norm": float(gnorm.item()),
+                           "learning_rate": lr, "epoch": round(epoch + micro / max(micro_per_epoch, 1), 4),
+                           "elapsed_s": round(time.time() - t0, 2)}
+                    log_acc += v
+                    last_logged = step
+                    window_loss.zero_()
+                    self.history.append(rec)
+                    if self.rank == 0:
+                        self.log(json.dumps(rec))
+                if a.save_steps and step % a.save_steps == 0 and self.rank == 0:
+                    self._save_checkpoint(step)
+                if step >= total:
+                    break
+            epoch += 1
+        return self.history
+
+    def _save_checkpoint(self, step: int):
+        a = self.args
+        d = os.path.join(a.output_dir, f"checkpoint-{step}")
+        save_model(self.model, d)
+        if a.save_total_limit:
+            ck = sorted((int(x.split("-")[1]), x) for x in os.listdir(a.output_dir) if x.startswith("checkpoint-"))
+            for _, old in ck[:-a.save_total_limit]:
+                shutil.rmtree(os.path.join(a.output_dir, old), ignore_errors=True)
