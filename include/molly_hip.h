@@ -150,6 +150,12 @@ int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, co
                    int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv, int ldo, int lddo,
                    int lddq, int lddk, int lddv, float scale, int causal);
 
+/* single-query attention over a KV cache — the decode step of HF `generate` with DynamicCache that the reference runs
+ * for inference (reference src/model/omics_one.py:220-232).  q [B, ldq] (heads at column h*hd), out [B, n_heads*hd]; k/v cache [B, Tmax, n_kv_heads*hd];
+ * keys kv_lo[b] <= key < kv_hi[b] (kv_lo NULL = 0).  Tmax <= 16384. */
+int molly_attn_decode(void* stream, const void* q, const void* kcache, const void* vcache, void* out, const int* kv_lo,
+                      const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim, int ldq, float scale);
+
 /* ------------------------------------------------------------------------------------------------
  * layout / instruction probes (used by tests/test_gpu_probes.py to pin the gfx950 operand maps the
  * kernels rely on; not part of the product path) */

@@ -1,0 +1,170 @@
+"""Prefill + KV-cache decode for `OmicsOne.generate` (reference: src/model/omics_one.py:187-233 -> HF `generate` with
+`inputs_embeds`, DynamicCache, sampling processors).  Prefill reuses the training forward kernels (flash attention over the
+left-padded prompt, positions = cumsum(mask)-1 as HF does: HF:generation/utils.py:751-773) and writes every layer's
+post-RoPE K and V into a token-major cache; each decode step is M = batch GEMMs + one `molly_attn_decode` per layer.
+Token selection (temperature / top-k / top-p / repetition penalty, HF logits processors) runs on the [B, V] logits with
+torch ops — a few KB of work per step, not a kernel target.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+class GenerationSession:
+    def __init__(self, model, max_new_tokens: int):
+        self.m = model
+        self.rt = model._runtime()
+        self.eng = self.rt.llm
+        self.max_new = max_new_tokens
+
+    # ---- prefill -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def prefill(self, input_ids, attention_mask, omic_ids, omic_info_list) -> torch.Tensor:
+        """Returns the logits of the last prompt position [B, V] (fp32)."""
+        m, rt, e = self.m, self.rt, self.eng
+        B, T = input_ids.shape
+        dev = rt.dev
+        self.B, self.T = B, T
+        self.Tmax = T + self.max_new
+        lo, hi = m._kv_range(attention_mask, B, T, dev)
+        mask = attention_mask.cpu().long() if attention_mask is not None else torch.ones(B, T, dtype=torch.long)
+        pos = (mask.cumsum(1) - 1).clamp(min=0)                              # HF: position_ids = cumsum(mask)-1, pads -> 0/1
+        self.lo = lo if lo is not None else torch.zeros(B, dtype=torch.int32, device=dev)
+        self.n_valid = mask.sum(1).to(torch.int32).to(dev)                    # next position id per sample
+        hs, _, _ = m._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, False)
+        e.reserve(B * T, B, T, training=False)
+        # rope tables must cover prompt + generated positions
+        from .qwen3 import rope_tables
+        self.cos, self.sin = rope_tables(self.Tmax, e.hd, e.cfg.rope_theta, dev, e.rope_table_dtype)
+        positions = pos.reshape(-1).to(torch.int32).to(dev)
+        L, nkvd = e.L, e.nkv * e.hd
+        self.kc = torch.zeros(L, B, self.Tmax, nkvd, dtype=BF16, device=dev)
+        self.vc = torch.zeros(L, B, self.Tmax, nkvd, dtype=BF16, device=dev)
+        rows = (torch.arange(B)[:, None] * self.Tmax + torch.arange(T)[None, :]).reshape(-1).to(torch.int32).to(dev)
+        a = e.A[0]
+        x = hs
+        nq = e.nh * e.hd
+        for i in range(L):
+            w = e.W[i]
+            ops.rmsnorm_fwd(x, w["ln1"], e.cfg.rms_norm_eps, out=a["xn"])
+            ops.gemm_nt(a["xn"], w["qkv"], out=a["qkv"])
+            ops.norm_rope_fwd(a["qkv"], a["qk"], e.nh, e.nkv, e.hd, T, w["qn"], w["kn"], self.cos, self.sin,
+                              positions=positions, eps=e.cfg.rms_norm_eps)
+            ops.copy_rows(a["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B * T, dst_idx32=rows)
+            ops.copy_rows(a["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B * T, dst_idx32=rows)
+            ops.attn_fwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, e.nqk:], B, T, e.nh, e.nkv, e.hd, e.hd ** -0.5, True,
+                         lo, hi, out=a["attn"], lse=False)
+            ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=x)
+            ops.rmsnorm_fwd(a["x2"], w["ln2"], e.cfg.rms_norm_eps, out=a["xn2"])
+            ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
+            ops.swiglu_fwd(a["gu"], out=a["act"])
+            ops.gemm_nt(a["act"], w["down"], out=e.x_out, res=a["x2"])
+            x = e.x_out
+        last = x.view(B, T, e.h)[:, T - 1, :].contiguous()                    # left-padded prompts end at T-1
+        self.cur_len = T
+        self._alloc_step(B)
+        return self._head(last)
+
+    def _alloc_step(self, B):
+        e, dev = self.eng, self.rt.dev
+        z = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
+        self.s = dict(x=z(B, e.h), xn=z(B, e.h), qkv=z(B, e.nqkv), qk=z(B, e.nqk), attn=z(B, e.nh * e.hd), x2=z(B, e.h),
+                      xn2=z(B, e.h), gu=z(B, 2 * e.ff), act=z(B, e.ff), hn=z(B, e.h))
+        self.hi = torch.empty(B, dtype=torch.int32, device=dev)
+
+    def _head(self, x):
+        e = self.eng
+        hn = ops.rmsnorm_fwd(x, e.norm_w, e.cfg.rms_norm_eps)
+        return ops.gemm_nt(hn, e.head, out_dtype=torch.float32)
+
+    # ---- one decode step ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, token_ids: torch.Tensor) -> torch.Tensor:
+        """token_ids int64 [B] (the tokens chosen from the previous logits).  Returns next-token logits [B, V] fp32."""
+        e, s, B = self.eng, self.s, self.B
+        dev = self.rt.dev
+        t = self.cur_len                                                       # cache slot of this token
+        assert t < self.Tmax, "generation budget exhausted"
+        ops.copy_rows(e.embed, s["x"], B, src_idx64=token_ids.to(dev))
+        positions = self.n_valid.clone()                                       # position id = number of valid tokens so far
+        self.n_valid += 1
+        self.hi.fill_(t + 1)
+        slot = (torch.arange(B, device=dev, dtype=torch.int32) * self.Tmax + t)
+        nq, nkvd = e.nh * e.hd, e.nkv * e.hd
+        x = s["x"]
+        for i in range(e.L):
+            w = e.W[i]
+            ops.rmsnorm_fwd(x, w["ln1"], e.cfg.rms_norm_eps, out=s["xn"])
+            ops.gemm_nt(s["xn"], w["qkv"], out=s["qkv"])
+            ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin,
+                              positions=positions, eps=e.cfg.rms_norm_eps)
+            ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=slot)
+            ops.copy_rows(s["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B, dst_idx32=slot)
+            ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
+                            e.hd ** -0.5)
+            ops.gemm_nt(s["attn"], w["o"], out=s["x2"], res=x)
+            ops.rmsnorm_fwd(s["x2"], w["ln2"], e.cfg.rms_norm_eps, out=s["xn2"])
+            ops.gemm_nt(s["xn2"], w["gu"], out=s["gu"])
+            ops.swiglu_fwd(s["gu"], out=s["act"])
+            ops.gemm_nt(s["act"], w["down"], out=s["x"], res=s["x2"])
+            x = s["x"]
+        self.cur_len += 1
+        return self._head(x)
+
+
+def _process_logits(logits, generated, temperature, top_k, top_p, repetition_penalty):
+    """HF logits processors in HF's order: repetition penalty, temperature, top-k, top-p."""
+    if repetition_penalty and repetition_penalty != 1.0 and generated.shape[1] > 0:
+        score = torch.gather(logits, 1, generated)
+        score = torch.where(score < 0, score * repetition_penalty, score / repetition_penalty)
+        logits = logits.scatter(1, generated, score)
+    if temperature and temperature != 1.0:
+        logits = logits / temperature
+    if top_k:
+        kth = torch.topk(logits, min(top_k, logits.shape[-1]))[0][..., -1, None]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sl, si = torch.sort(logits, descending=False)
+        cp = sl.softmax(-1).cumsum(-1)
+        remove = cp <= (1 - top_p)
+        remove[..., -1:] = False
+        logits = logits.masked_fill(remove.scatter(1, si, remove), float("-inf"))
+    return logits
+
+
+@torch.no_grad()
+def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_list=None, max_new_tokens=3072, do_sample=True,
+             temperature=0.8, top_p=0.95, top_k=None, repetition_penalty=None, pad_token_id=None, eos_token_id=None,
+             generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """Returns the NEW tokens only, int64 [B, n_new] (what HF returns when called with inputs_embeds and no input_ids)."""
+    sess = GenerationSession(model, max_new_tokens)
+    logits = sess.prefill(input_ids, attention_mask, omic_ids, omic_info_list)
+    B = input_ids.shape[0]
+    dev = logits.device
+    eos = None if eos_token_id is None else torch.as_tensor(eos_token_id, device=dev).reshape(-1)
+    pad = pad_token_id if pad_token_id is not None else (int(eos[0]) if eos is not None else 0)
+    out = torch.empty(B, 0, dtype=torch.int64, device=dev)
+    unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+    for _ in range(max_new_tokens):
+        lg = _process_logits(logits, out, temperature if do_sample else None, top_k if do_sample else None,
+                             top_p if do_sample else None, repetition_penalty)
+        if do_sample:
+            nxt = torch.multinomial(lg.softmax(-1), 1, generator=generator).squeeze(1)
+        else:
+            nxt = lg.argmax(-1)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+        out = torch.cat([out, nxt[:, None]], 1)
+        if eos is not None:
+            unfinished = unfinished & ~torch.isin(nxt, eos)
+            if not bool(unfinished.any()):
+                break
+        if out.shape[1] == max_new_tokens:
+            break
+        logits = sess.step(nxt)
+    return out

@@ -243,3 +243,9 @@ def colsum(x, out, accumulate=False, workspace=None):
     lib().call("molly_colsum_bf16", _stream(), x, rows, H, x.stride(0), out, int(out.dtype == torch.float32),
                int(accumulate), workspace)
     return out
+
+
+def attn_decode(q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, scale):
+    lib().call("molly_attn_decode", _stream(), q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, q.stride(0),
+               float(scale))
+    return out

@@ -1,0 +1,91 @@
+"""GPU: prefill + KV-cache decode (OmicsOne.generate) against the oracle run as a full re-forward on the grown sequence
+(teacher forcing, so bf16 argmax ties cannot derail the comparison), left-padded batch like the reference's Test collate."""
+import pytest
+import torch
+
+from conftest import tiny_state_dict
+from test_gpu_model import build_tiny
+
+pytestmark = pytest.mark.gpu
+
+
+def _left_padded_batch(meta):
+    from molly_amd.synth import synth_batch
+    c = meta["config"]
+    sp = {k: tuple(v) for k, v in c["special_ids"].items()}
+    b = synth_batch(2, 192, [("protein", 64)], seed=11, text_vocab=1000, special_ids=sp, pad_id=1000)
+    # make sample 1 shorter and LEFT-pad it (reference Test mode: omics_dataset.py:384-391 shifts the span start too)
+    pad = 37
+    ids, mask = b["input_ids"].clone(), b["attention_mask"].clone()
+    ids[1] = torch.cat([torch.full((pad,), 1000), b["input_ids"][1, :-pad]])
+    mask[1] = torch.cat([torch.zeros(pad, dtype=torch.long), torch.ones(192 - pad, dtype=torch.long)])
+    info = [[dict(d) for d in row] for row in b["omic_info_list"]]
+    info[1][0]["start"] += pad
+    return ids, mask, b["omic_ids"], info
+
+
+def test_decode_logits_match_oracle_reforward(tiny_meta):
+    from molly_amd.generate import GenerationSession
+    from oracle import molly_ref as R
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)
+    sess = GenerationSession(m, max_new_tokens=6)
+    logits = sess.prefill(ids, mask, omic, info)
+    c = tiny_meta["config"]
+    llm, dna, prot = R.cfgs_from_meta(c)
+    sd = tiny_state_dict(tiny_meta)
+
+    def oracle_last_logits(new_tokens):
+        """full forward over prompt + new tokens with HF generate's position ids (cumsum(mask)-1)."""
+        B = ids.shape[0]
+        hs = R.omics_inputs_embeds(sd, llm, dna, prot, {"input_ids": ids, "omic_ids": omic, "omic_info_list": info},
+                                   {"dna_rna": c["K"], "protein": c["K"]})
+        full_mask = mask
+        if new_tokens.shape[1]:
+            hs = torch.cat([hs, torch.nn.functional.embedding(new_tokens, sd["model.model.embed_tokens.weight"])], 1)
+            full_mask = torch.cat([mask, torch.ones(B, new_tokens.shape[1], dtype=torch.long)], 1)
+        T = hs.shape[1]
+        pos = (full_mask.cumsum(1) - 1).clamp(min=0)
+        outs = []
+        for b in range(B):                       # per-sample positions: run each sample with its own rope table
+            cos, sin = R.rope_cos_sin(pos[b], llm.head_dim, llm.rope_theta)
+            bias = R.causal_pad_bias(full_mask[b:b + 1], 1, T, torch.float32)
+            h = hs[b:b + 1]
+            for i in range(llm.num_hidden_layers):
+                lp = f"model.model.layers.{i}."
+                r_ = h
+                h = R.rmsnorm(h, sd[lp + "input_layernorm.weight"], llm.rms_norm_eps)
+                h = r_ + R.qwen3_attention(sd, lp + "self_attn.", llm, h, cos, sin, bias)
+                r_ = h
+                h = R.rmsnorm(h, sd[lp + "post_attention_layernorm.weight"], llm.rms_norm_eps)
+                h = r_ + R.qwen3_mlp(sd, lp + "mlp.", h)
+            h = R.rmsnorm(h, sd["model.model.norm.weight"], llm.rms_norm_eps)
+            outs.append(torch.nn.functional.linear(h[:, -1], sd["model.model.embed_tokens.weight"]))
+        return torch.cat(outs, 0)
+
+    new = torch.empty(2, 0, dtype=torch.long)
+    for step in range(5):
+        ref = oracle_last_logits(new)
+        err = (logits.float().cpu() - ref).abs().max().item()
+        assert err <= 3e-2 * ref.abs().max().item(), (step, err)
+        nxt = ref.argmax(-1)                     # teacher forcing with the oracle's choice
+        new = torch.cat([new, nxt[:, None]], 1)
+        logits = sess.step(nxt)
+
+
+def test_generate_api_returns_new_tokens_only_and_stops_at_eos(tiny_meta):
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)
+    out = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=7)
+    assert out.shape == (2, 7) and out.dtype == torch.int64
+    # greedy is deterministic
+    assert torch.equal(out, m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=7))
+    # eos handling: declare the first generated token of sample 0 to be EOS -> that row is padded afterwards
+    m.text_config.eos_token_id = int(out[0, 0])
+    m.text_config.pad_token_id = 1000
+    out2 = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=7)
+    assert out2[0, 0] == out[0, 0] and bool((out2[0, 1:] == 1000).all())
+    g = torch.Generator(device="cuda").manual_seed(0)
+    s1 = m.generate(ids, mask, omic, info, do_sample=True, temperature=0.8, top_p=0.95, top_k=20, repetition_penalty=1.1,
+                    max_new_tokens=5, generator=g)
+    assert s1.shape[0] == 2 and s1.shape[1] <= 5
