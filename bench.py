@@ -159,6 +159,7 @@ def main():
     m.prepare(dev, random_init_seed=1234)              # same seed on every rank: replicas start identical
     rt = m._rt
     opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0)
+    m.attach_optimizer(opt)
 
     B, T, K = args.batch, args.seq, args.k_protein
     batches = [synth_batch(B, T, [("protein", K)], seed=42 + rank + 1000 * i) for i in range(4)]

@@ -317,6 +317,8 @@ class OmicsOne(nn.Module):
         rt = self._rt
         h = self.text_config.hidden_size
         M = B * T
+        if not keep_for_backward and getattr(rt, "opt", None) is not None:
+            rt.opt.wait_all_params()              # inference entry points: every parameter must have been published
         rt.llm.reserve(M, B, T, training=keep_for_backward)
         hs = rt.llm.A[0]["x"] if keep_for_backward else rt.llm.x_out
         ids_dev = input_ids.reshape(-1).to(rt.dev, non_blocking=True)
@@ -365,19 +367,36 @@ class OmicsOne(nn.Module):
             raise NotImplementedError("attention_mask must be one contiguous run of ones per sample (right- or left-padded)")
         return lo.to(torch.int32).to(dev), hi.to(torch.int32).to(dev)
 
-    def forward_backward(self, input_ids, attention_mask, omic_ids, omic_info_list, labels, accumulate=False):
+    def attach_optimizer(self, opt):
+        """Wire a Zero2Optimizer's overlap hooks into the engines (no-ops when the optimizer does not overlap)."""
+        rt = self._runtime()
+        rt.opt = opt
+        opt.hooked = True
+        rt.llm.grads_final_hook = opt.on_grads_final
+        rt.llm.wait_params_hook = opt.wait_params
+
+    def forward_backward(self, input_ids, attention_mask, omic_ids, omic_info_list, labels, accumulate=False,
+                         final_micro=True):
         """One training micro-step on the native path: forward + loss + full backward into the flat grad buffer.
         Returns the loss as a device scalar (no host sync).  Loss semantics = per-micro-batch token mean
         (HF:loss/loss_utils.py:49-71 with num_items_in_batch=None: the reference swallows it)."""
         rt = self._runtime()
         B, T = input_ids.shape
         M = B * T
+        opt = getattr(rt, "opt", None)
+        if opt is not None:
+            # parameters read before the decoder layers: gains/biases (tail region), projectors, embedding (= tied head)
+            opt.wait_params(self.n_decay, rt.P.numel)
+            opt.wait_params(0, rt.llm.layer_lo[0])
+            opt.wait_params(rt.llm.layers_hi, self.n_decay)
         lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
         hs, overwritten, saved = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, True)
         shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
         shifted = shifted.to(rt.dev, non_blocking=True)
         rt.llm.forward(hs, B, T, lo, hi, labels_shifted=shifted, training=True)
-        d_hs = rt.llm.loss_and_backward(accumulate=accumulate)
+        if opt is not None:
+            opt.wait_all_params()
+        d_hs = rt.llm.loss_and_backward(accumulate=accumulate, final_micro=final_micro)
         # ---- gradient of the input embeddings: text rows -> embed_tokens, omic rows -> projector
         if rt.train_llm:
             order, seg, uid = embed_backward_index(input_ids.reshape(-1).cpu().numpy(), overwritten)

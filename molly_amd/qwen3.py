@@ -49,7 +49,12 @@ class Qwen3Engine:
         self.ce_chunk_rows = ce_chunk_rows
         self.rope_table_dtype = rope_table_dtype
         self.cap = 0
+        self.grads_final_hook = None      # callable(lo, hi): flat-offset range of gradients that became final (ZeRO overlap)
+        self.wait_params_hook = None      # callable(lo, hi): block the stream until those parameters are all-gathered
         self._views()
+        lp0, lpl = f"{prefix}model.layers.0.", f"{prefix}model.layers.{self.L - 1}."
+        self.layer_lo = [params.offsets[f"{prefix}model.layers.{i}.self_attn.q_proj.weight"] for i in range(self.L)]
+        self.layers_hi = params.offsets[lpl + "mlp.down_proj.weight"] + params.views[lpl + "mlp.down_proj.weight"].numel()
 
     # ---- weight views ---------------------------------------------------------------------------------------
     def _layer_views(self, buf: FlatBuffer, i: int):
@@ -122,6 +127,8 @@ class Qwen3Engine:
         for i in range(self.L):
             a = self.A[i if training else 0]
             w = self.W[i]
+            if self.wait_params_hook is not None:
+                self.wait_params_hook(self.layer_lo[i], self.layer_lo[i + 1] if i + 1 < self.L else self.layers_hi)
             if training:
                 a["x"].copy_(x) if x.data_ptr() != a["x"].data_ptr() else None
                 xin = a["x"]
@@ -174,7 +181,7 @@ class Qwen3Engine:
         ops.gemm(dy, w, out=out, b_kmajor=True)
 
     # ---- fused lm-head + CE forward/backward, then the decoder backward ---------------------------------------
-    def loss_and_backward(self, accumulate: bool = False) -> torch.Tensor:
+    def loss_and_backward(self, accumulate: bool = False, final_micro: bool = True) -> torch.Tensor:
         """Runs lm_head + shifted CE (forward AND backward, chunked so [M,V] logits never exist at once: the role
         Liger's fused-linear-CE plays in the reference, src/train.py:130-132) and the whole decoder backward.
         Weight gradients land in the flat grad buffer (`accumulate` = add to what is there: GA micro-steps > 0).
@@ -227,4 +234,6 @@ class Qwen3Engine:
             self._wgrad(self.d_qkv, a["xn"], g["qkv"], accumulate)
             ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, g["ln1"], cfg.rms_norm_eps, dres=dx2, dx=dx,
                             dw_accumulate=accumulate, workspace=self.ws)
+            if final_micro and self.grads_final_hook is not None:
+                self.grads_final_hook(self.layer_lo[i], self.layers_hi)       # matrices of layers i..L-1 are final
         return dx

@@ -70,6 +70,7 @@ class Trainer:
         self.opt = Zero2Optimizer(rt.P.flat, rt.G.flat, model.n_decay, lr=args.learning_rate,
                                   betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
                                   weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm)
+        model.attach_optimizer(self.opt)
         self.history: List[dict] = []
 
     def _micro_batches(self, epoch: int):
@@ -98,7 +99,8 @@ class Trainer:
             micro = 0
             for batch in self._micro_batches(epoch):
                 loss = m.forward_backward(batch["input_ids"], batch["attention_mask"], batch["omic_ids"],
-                                          batch["omic_info_list"], batch["labels"], accumulate=micro > 0)
+                                          batch["omic_info_list"], batch["labels"], accumulate=micro > 0,
+                                          final_micro=micro == GA - 1)
                 window_loss += loss
                 micro += 1
                 if micro < GA:

@@ -11,6 +11,13 @@ owns chunk r.  Each bucket is therefore ONE in-place `reduce_scatter_tensor` / `
 region (no staging copies), and on the fully connected 8-GPU xGMI mesh each of those moves `chunk` elements over each
 of the 7 links concurrently.  Default chunk = 16 Mi elements (32 MiB bf16 per link per bucket).
 World size 1 skips the collectives and keeps the same code path.
+
+Overlap (default on for world > 1): collectives run on a dedicated communication stream.
+  * reduce-scatter: the backward reports "gradients in [lo, hi) are final" layer by layer (engine hook); every bucket that
+    is fully covered is reduce-scattered immediately, beside the backward of the earlier layers.  The reference's
+    DeepSpeed config has overlap_comm:false; overlapping changes no value (each bucket's reduction is independent).
+  * all-gather: launched bucket by bucket right after the shard AdamW (no-decay/gain region first, then in flat order =
+    the order the next forward consumes parameters); the forward waits per bucket (`wait_params`) just before first use.
 """
 from __future__ import annotations
 
@@ -26,6 +33,22 @@ def linear_warmup_lr(step: int, base_lr: float, warmup: int, total: int) -> floa
     if step < warmup:
         return base_lr * step / max(1, warmup)
     return base_lr * max(0.0, (total - step) / max(1, total - warmup))
+
+
+class _DistComm:
+    """torch.distributed collectives (RCCL on ROCm); in-place on contiguous bucket regions."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def reduce_scatter(self, out_chunk, region):
+        dist.reduce_scatter_tensor(out_chunk, region, group=self.group)
+
+    def all_gather(self, region, chunk):
+        dist.all_gather_into_tensor(region, chunk, group=self.group)
+
+    def all_reduce(self, t):
+        dist.all_reduce(t, group=self.group)
 
 
 class _HipKernels:
@@ -49,7 +72,8 @@ class _HipKernels:
 class Zero2Optimizer:
     def __init__(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, n_decay: int, lr: float = 3e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_grad_norm: float = 1.0,
-                 group=None, chunk_elems: int = 16 * 1024 * 1024, kernels=None):
+                 group=None, chunk_elems: int = 16 * 1024 * 1024, kernels=None, overlap: Optional[bool] = None,
+                 comm=None):
         self.P, self.G = flat_params, flat_grads
         self.n = flat_params.numel()
         self.n_decay = n_decay
@@ -83,21 +107,86 @@ class Zero2Optimizer:
         self.scal = torch.zeros(4, dtype=torch.float32, device=dev)       # [0]=norm^2 [1]=norm [2]=coef
         self.k = kernels if kernels is not None else _HipKernels(dev)
         self.t = 0
+        # ---- overlap machinery -------------------------------------------------------------------------------
+        self.comm = comm if comm is not None else _DistComm(group)
+        self.overlap = (self.world > 1) if overlap is None else overlap
+        self.overlap = self.overlap and flat_params.is_cuda
+        self.P_out = flat_params                # AdamW writes here; the all-gather publishes into P (same buffer in production)
+        self.hooked = False                     # set by OmicsOne.attach_optimizer: somebody will call wait_params()
+        if self.overlap:
+            self.cstream = torch.cuda.Stream(device=dev)
+            self._rs_done = [False] * len(self.buckets)
+            self._ag_events = [None] * len(self.buckets)
+            self._ag_waited = [True] * len(self.buckets)
+
+    # ---- hooks the engines call -------------------------------------------------------------------------------
+    def on_grads_final(self, lo: int, hi: int):
+        """Gradients with flat offsets in [lo, hi) will not change any more in this optimizer step."""
+        if not self.overlap:
+            return
+        ev = None
+        for b, (start, per) in enumerate(self.buckets):
+            if self._rs_done[b] or start < lo or start + per * self.world > hi:
+                continue
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.cstream.wait_event(ev)
+            with torch.cuda.stream(self.cstream):
+                region = self.G[start:start + per * self.world]
+                self.comm.reduce_scatter(region[self.rank * per:(self.rank + 1) * per], region)
+            self._rs_done[b] = True
+
+    def wait_params(self, lo: int, hi: int):
+        """Make the current stream wait until parameters with flat offsets in [lo, hi) have been all-gathered."""
+        if not self.overlap:
+            return
+        for b, (start, per) in enumerate(self.buckets):
+            if self._ag_waited[b] or start >= hi or start + per * self.world <= lo:
+                continue
+            torch.cuda.current_stream().wait_event(self._ag_events[b])
+            self._ag_waited[b] = True
+
+    def wait_all_params(self):
+        self.wait_params(0, self.n)
 
     # ---- pieces (also used by the multi-process CPU tests) ---------------------------------------------------
     def reduce_scatter_grads(self):
+        if self.overlap:
+            self.on_grads_final(0, self.n)                     # whatever the backward did not cover yet
+            torch.cuda.current_stream().wait_stream(self.cstream)
+            self._rs_done = [False] * len(self.buckets)
+            return
         if self.world == 1:
             return
         for start, per in self.buckets:
             region = self.G[start:start + per * self.world]
-            dist.reduce_scatter_tensor(region[self.rank * per:(self.rank + 1) * per], region, group=self.group)
+            self.comm.reduce_scatter(region[self.rank * per:(self.rank + 1) * per], region)
 
     def all_gather_params(self):
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.cstream.wait_event(ev)
+            # gains/biases (tail of the flat buffer) are needed by the very first kernel of the next forward: publish first
+            order = [len(self.buckets) - 1] + list(range(len(self.buckets) - 1))
+            with torch.cuda.stream(self.cstream):
+                for b in order:
+                    start, per = self.buckets[b]
+                    self.comm.all_gather(self.P[start:start + per * self.world],
+                                         self.P_out[start + self.rank * per:start + (self.rank + 1) * per])
+                    e = torch.cuda.Event()
+                    e.record(self.cstream)
+                    self._ag_events[b] = e
+                    self._ag_waited[b] = False
+            if not self.hooked:                                # nobody will wait per bucket: stay correct, lose the overlap
+                self.wait_all_params()
+            return
         if self.world == 1:
             return
         for start, per in self.buckets:
             region = self.P[start:start + per * self.world]
-            dist.all_gather_into_tensor(region, region[self.rank * per:(self.rank + 1) * per], group=self.group)
+            self.comm.all_gather(region, region[self.rank * per:(self.rank + 1) * per])
 
     def grad_norm_and_clip(self):
         first = True
@@ -106,7 +195,7 @@ class Zero2Optimizer:
             self.k.sqnorm(self.G[lo:lo + per], self.scal[0:1], accumulate=not first)
             first = False
         if self.world > 1:
-            dist.all_reduce(self.scal[0:1], group=self.group)
+            self.comm.all_reduce(self.scal[0:1])
         # gradients were SUMMED over ranks; DeepSpeed averages them: fold 1/world into the scale
         self.k.clip_coef(self.scal[0:1], self.max_norm, 1.0 / self.world, self.scal[1:2], self.scal[2:3])
 
@@ -124,7 +213,7 @@ class Zero2Optimizer:
                 if b > a:
                     s = pos + (a - lo)
                     self.k.adamw(self.master[s:s + b - a], self.m[s:s + b - a], self.v[s:s + b - a], self.G[a:b],
-                                 self.P[a:b], lr, self.betas[0], self.betas[1], self.eps, wd, self.t, self.scal[2:3])
+                                 self.P_out[a:b], lr, self.betas[0], self.betas[1], self.eps, wd, self.t, self.scal[2:3])
             pos += per
         self.all_gather_params()
         return self.scal[1]

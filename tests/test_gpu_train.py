@@ -107,3 +107,51 @@ def test_checkpoint_roundtrip_reference_layout(tiny_meta, tiny_gold, tmp_path):
     with torch.no_grad():
         again = m2(**kw).logits
     assert torch.equal(again, ref)
+
+
+class _LoopbackComm:
+    """World-1 stand-in that makes ORDERING observable on one GPU: the 'reduce-scatter' round-trips the bucket through a
+    temporary (launched too early it would resurrect stale gradients), the 'all-gather' is the only thing that publishes
+    the AdamW output (a forward that does not wait for it reads stale parameters)."""
+
+    def reduce_scatter(self, out_chunk, region):
+        tmp = region.clone()
+        region.copy_(tmp)
+
+    def all_gather(self, region, chunk):
+        region.copy_(chunk)
+
+    def all_reduce(self, t):
+        pass
+
+
+def test_overlapped_comm_schedule_equals_synchronous(tiny_meta, tiny_gold):
+    from molly_amd.trainer import Zero2Optimizer
+    batch = tiny_batch(tiny_gold, tiny_meta)
+    args = (batch["input_ids"], batch["attention_mask"], batch["omic_ids"], batch["omic_info_list"], batch["labels"])
+
+    def run(overlap):
+        m = build_tiny(tiny_meta)
+        rt = m._rt
+        kw = dict(lr=1e-3, chunk_elems=32768)
+        if overlap:
+            opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, overlap=True, comm=_LoopbackComm(), **kw)
+            opt.P_out = rt.P.flat.clone()                      # AdamW output is invisible until the 'all-gather' runs
+            assert len(opt.buckets) > 8
+        else:
+            opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, overlap=False, **kw)
+        m.attach_optimizer(opt)
+        losses = []
+        for step in range(4):
+            for micro in range(2):                             # GA = 2: hooks may only fire on the last micro-step
+                loss = m.forward_backward(*args, accumulate=micro > 0, final_micro=micro == 1)
+            losses.append(loss.clone())                 # the returned loss is a view of a reused device scalar
+            opt.step()
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), rt.P.flat.clone().cpu()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1)
+    assert l0[-1] < l0[0]
