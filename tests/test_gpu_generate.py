@@ -89,3 +89,42 @@ def test_generate_api_returns_new_tokens_only_and_stops_at_eos(tiny_meta):
     s1 = m.generate(ids, mask, omic, info, do_sample=True, temperature=0.8, top_p=0.95, top_k=20, repetition_penalty=1.1,
                     max_new_tokens=5, generator=g)
     assert s1.shape[0] == 2 and s1.shape[1] <= 5
+
+
+def test_lora_adapter_merge_peft_layout(tiny_meta, tiny_gold, tmp_path):
+    """A synthetic adapter in PEFT's file layout, merged at load; logits must equal the oracle run on W + (alpha/r) B A."""
+    import json
+    from safetensors.torch import save_file
+    from conftest import tiny_batch
+    from molly_amd.lora import TARGETS, merge_lora_adapter
+    from oracle import molly_ref as R
+    m = build_tiny(tiny_meta)
+    sd = tiny_state_dict(tiny_meta)
+    r, alpha = 8, 64
+    g = torch.Generator().manual_seed(5)
+    tens = {}
+    for i in range(tiny_meta["config"]["text"]["num_hidden_layers"]):
+        for t in TARGETS:
+            sub = "self_attn" if t in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp"
+            w = sd[f"model.model.layers.{i}.{sub}.{t}.weight"]
+            A = torch.randn(r, w.shape[1], generator=g) * 0.02
+            Bm = torch.randn(w.shape[0], r, generator=g) * 0.02
+            tens[f"base_model.model.model.layers.{i}.{sub}.{t}.lora_A.weight"] = A
+            tens[f"base_model.model.model.layers.{i}.{sub}.{t}.lora_B.weight"] = Bm
+            sd[f"model.model.layers.{i}.{sub}.{t}.weight"] = w + (alpha / r) * (Bm @ A)
+    save_file(tens, str(tmp_path / "adapter_model.safetensors"))
+    json.dump({"r": r, "lora_alpha": alpha, "target_modules": list(TARGETS), "peft_type": "LORA"},
+              open(tmp_path / "adapter_config.json", "w"))
+    torch.save({"weight": sd["protein_projector.weight"] * 1.5, "bias": sd["protein_projector.bias"]},
+               tmp_path / "protein_projector.bin")
+    sd["protein_projector.weight"] = sd["protein_projector.weight"] * 1.5
+    assert merge_lora_adapter(m, str(tmp_path)) == 14
+    batch = tiny_batch(tiny_gold, tiny_meta)
+    with torch.no_grad():
+        out = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], omic_ids=batch["omic_ids"],
+                omic_info_list=batch["omic_info_list"])
+        llm, dna, prot = R.cfgs_from_meta(tiny_meta["config"])
+        _, ref = R.omics_forward(sd, llm, dna, prot, {k: v for k, v in batch.items() if k != "labels"}, {"dna_rna": 64, "protein": 64})
+    valid = batch["attention_mask"].bool()
+    err = (out.logits.float().cpu() - ref)[valid].abs().max().item()
+    assert err <= 3e-2 * ref.abs().max().item(), err
