@@ -51,6 +51,8 @@ int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const v
 /* fp32 scratch the GEMM may use for split-K partial slabs (wgrad shapes whose 256x256 grid would not fill the chip);
  * caller-owned device memory, stays valid until replaced; NULL / 0 disables split-K. */
 int molly_gemm_set_workspace(void* ptr, long bytes);
+/* configuration the most recent GEMM call used: 128 | 256 | 512 (= the 256x256 ping-pong kernel) + 1000 * split-K factor */
+int molly_gemm_last_config(void);
 /* tuning/test hook: 0 = heuristic tile choice, 128 / 256 = force that BM tile configuration of the GEMM kernel. */
 int molly_gemm_force_tile(int bm);
 

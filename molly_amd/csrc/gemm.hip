@@ -62,23 +62,25 @@ __device__ __forceinline__ bf16x8 frag_kc(const bf16_t* lds_tile, int row, int c
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * BK + phys * 8);
 }
 
-// ---- k-major operand: tile [64 k][COLS] bf16; chunk swizzle inside every 128-column (256-B = one bank row) segment:
-// ch ^ (((k&3)<<2) | ((k>>2)&3))  — conflict-free for the 4-row x 16-col transposed-read blocks.
-__device__ __forceinline__ int kswz(int k, int ch) { return ch ^ (((k & 3) << 2) | ((k >> 2) & 3)); }
-
+// ---- k-major operand: tile [BK k][COLS] bf16, stored SUB-TILED for the transposed reads: blocks of 4 k-rows x 16
+// columns (128 B, row pitch 32 B); block (kblk = k>>2, cblk = col>>4) sits at block index kblk*NCB + (cblk ^ ((kblk>>1)&1)),
+// NCB = COLS/16.  A ds_read_b64_tr_b16 of the 16x16x32 operand (half-wave = k-blocks 2g and 2g' of ONE column block)
+// then touches two ADJACENT 128-byte blocks = 256 contiguous bytes (conflict-free), and every address is
+// lane_base + compile-time constant (the XOR only involves lane bits), so the unrolled reads use DS immediates.
 template <int COLS, int NW, int BK>
 __device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, int col0, int cols_total, int k0, int k_total,
                                          const bf16_t* zeros, bf16_t* lds_tile, int wave, int lane) {
-    constexpr int CPR = COLS / 8;                 // 16-byte chunks per k row
-    constexpr int RPI = 64 / CPR;                 // k rows per wave-instruction
-    constexpr int PER = (BK / RPI) / NW;
+    constexpr int NCB = COLS / 16;
+    constexpr int NINST = BK * COLS * 2 / 1024;   // 1 KiB per wave-instruction = 8 blocks
+    constexpr int PER = NINST / NW;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int inst = wave * PER + i;
-        const int kr = inst * RPI + lane / CPR;
-        const int pos = lane % CPR;
-        const int csrc = (pos & ~15) | kswz(kr, pos & 15);
-        int col = col0 + csrc * 8;
+        const int P = inst * 64 + lane;            // destination 16-byte slot
+        const int blk = P >> 3, cin = P & 7;
+        const int kblk = blk / NCB, cbs = blk % NCB;
+        const int kr = kblk * 4 + (cin >> 1);
+        int col = col0 + ((cbs ^ ((kblk >> 1) & 1)) << 4) + ((cin & 1) << 3);
         col = col <= cols_total - 8 ? col : cols_total - 8;  // clamp: OOB columns duplicate valid data, masked at store
         const int k = k0 + kr;
         const bf16_t* src = (k < k_total) ? g + (size_t)k * ld + col : zeros;   // rows past K contribute exact zeros
@@ -87,14 +89,19 @@ __device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, i
 }
 
 // fragment for mfma_16x16x32: lane (i = lane&15, g = lane>>4) gets tile[k = 32*kk + 8g + j][col16 + i], j = 0..7
+// (col16 a multiple of 16; kk, col16 compile-time / wave-uniform at the call sites)
 template <int COLS>
 __device__ __forceinline__ bf16x8 frag_km(const bf16_t* lds_tile, int kk, int col16, int lane) {
+    constexpr int NCB = COLS / 16;
     const int g = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3;
-    const int col = col16 + 4 * pp;
-    const int seg = col & ~127, cc = col & 127;
-    const int ka = 32 * kk + 8 * g + q, kb = ka + 4;
-    const bf16_t* pa = lds_tile + ka * COLS + seg + kswz(ka, cc >> 3) * 8 + (cc & 7);
-    const bf16_t* pb = lds_tile + kb * COLS + seg + kswz(kb, cc >> 3) * 8 + (cc & 7);
+    // rows 32kk + 8g + q (+4): kblk = 8kk + 2g (+1) -> (kblk>>1)&1 = g&1 for both reads
+    const int cblk = col16 >> 4;
+    const int lane_off = (2 * g * NCB) * 64 + q * 16 + (pp >> 1) * 8 + (pp & 1) * 4;
+    const int cst = (8 * kk * NCB) * 64;
+    // (cblk ^ (g&1)) written as (cblk & ~1) + ((cblk & 1) ^ (g & 1)): only the parity term is per-lane
+    const int cb = ((cblk & ~1) + ((cblk & 1) ^ (g & 1))) * 64;
+    const bf16_t* pa = lds_tile + lane_off + cst + cb;
+    const bf16_t* pb = pa + NCB * 64;
     const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
     const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
     return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 
 
 // ================================================================================================
-// 256x256x64 tile, 8 waves (2 x 4, each 128x64), 128 KiB LDS = 2 buffers x {A0,A1,B0,B1} half-tiles of 16 KiB.
+// 256x256x64 tile, 8 waves (2 x 4, each 128x64), all 160 KiB of LDS = 10 half-tile slots of 16 KiB (A x3, B x2 buffers).
 // Structure (after guide §5 "The 256² 8-phase template", own schedule):
 //  * each K-tile is 4 PHASES = the 4 quadrants (64x32) of the wave's output; a phase = LOAD segment (ds_read of the
 //    operand sub-tiles it needs + ONE half-tile LDS-DMA prefetch) | barrier | COMPUTE segment (16 MFMAs) | barrier;
@@ -260,9 +267,8 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 //    segment always runs beside the other's LDS/DMA segment (matrix pipe beside memory pipe on every SIMD);
 //  * half-tile prefetch order makes every restage >= 2 phases after the slot's last ds_read (WAR) and every first read
 //    >= 1 phase after the counted s_waitcnt vmcnt that retires it, behind a barrier both groups have passed (RAW):
-//      K-tile T (buffer T&1):  P0 reads B(n0) A(m0), issues B1(T+1) | P1 reads B(n1), issues A0(T+1)
-//                              P2 reads A(m1), issues A1(T+1)       | P3 issues B0(T+2), waits vmcnt(2) => T+1 landed
-//    B slots die after P1 -> restaged at P3 (B0) and next P0 (B1); A slots die after P2 -> restaged at next P1/P2.
+//      K-tile T:  P0 reads B(n0) A(m0), issues nothing | P1 reads B(n1), issues A0(T+2) | P2 reads A(m1), issues A1(T+2)
+//                 P3 issues B0,B1(T+2), waits vmcnt(8) => K-tile T+1 landed   (every piece is >= 4 phases ahead of its use)
 // Arithmetic intensity 128 flop/B of L2->LDS traffic (2x the 128² tile): the per-CU vector-memory path (64 B/clk) and
 // the matrix pipe are no longer at a 1:1 ridge.
 // ================================================================================================
@@ -278,8 +284,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int split = work % p.splits;        // slices of one tile are adjacent work items (same XCD under round-robin)
-    const int swz = work / p.splits;
+    // K-slice is the SLOWEST index: the work items that run side by side on one XCD then belong to one slice and keep
+    // sharing operand panels through its L2 (slices of one tile share nothing: they read different K ranges)
+    const int ntile = p.tiles_m * p.tiles_n;
+    const int split = work / ntile;
+    const int swz = work - split * ntile;
     constexpr int GROUP_M = 4;
     const int per_group = GROUP_M * p.tiles_n;
     const int grp = swz / per_group;
@@ -298,10 +307,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int nk_all = (p.K + BK - 1) / BK;
     const int kt0 = (int)((long)nk_all * split / p.splits), kt1 = (int)((long)nk_all * (split + 1) / p.splits);
     const int nk = kt1 - kt0;                 // K-tiles of this slice
-    // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; kt is slice-local
+    // LDS = 10 half-tile slots (all 160 KiB): A triple-buffered [3][A0|A1], then B double-buffered [2][B0|B1]
+    // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; ktl is slice-local
     auto issue = [&](int ktl, int which) {
         const int kt = kt0 + ktl;
-        bf16_t* dst = smem + ((ktl & 1) * 4 + which) * HT;
+        bf16_t* dst = which < 2 ? smem + ((ktl % 3) * 2 + which) * HT : smem + (6 + (ktl & 1) * 2 + (which - 2)) * HT;
         if (which < 2) {
             if (AT) stage_km<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, p.K, p.zeros, dst, wave, lane);
             else stage_kc<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, dst, wave, lane);
@@ -311,16 +321,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
     };
     const int fr = lane & 15, fq = lane >> 4;
-    auto readA = [&](int buf, int mh, bf16x8 (&af)[2][4]) {
-        const bf16_t* t = smem + (buf * 4 + wr) * HT;
+    auto readA = [&](int abuf, int mh, bf16x8 (&af)[2][4]) {
+        const bf16_t* t = smem + (abuf * 2 + wr) * HT;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 af[kk][i] = AT ? frag_km<128>(t, kk, mh * 64 + i * 16, lane) : frag_kc<BK>(t, mh * 64 + i * 16 + fr, kk * 4 + fq);
     };
-    auto readB = [&](int buf, int nh, bf16x8 (&bfr)[2][2]) {
-        const bf16_t* t = smem + (buf * 4 + 2 + (wc >> 1)) * HT;
+    auto readB = [&](int bbuf, int nh, bf16x8 (&bfr)[2][2]) {
+        const bf16_t* t = smem + (6 + bbuf * 2 + (wc >> 1)) * HT;
         const int c0 = (wc & 1) * 64 + nh * 32;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -345,55 +355,62 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
-    // ---- prologue: K-tile 0 complete + B0 of K-tile 1
-    issue(0, 2); issue(0, 3); issue(0, 0); issue(0, 1);
+    // ---- prologue: K-tiles 0 and 1 issued; wait for K-tile 0 only
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
     if (nk > 1) {
-        issue(1, 2);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     SEG_BARRIER();
     if (wr == 1) SEG_BARRIER();               // stagger: group 1 runs one segment behind group 0
 
+    // LDS-DMA schedule (one K-tile = 4 half-tiles = 8 instructions per wave), every piece >= 4 phases ahead of its use:
+    //   P0 (most operand reads) issues nothing | P1 -> A0(T+2) | P2 -> A1(T+2) | P3 (no reads) -> B0(T+2), B1(T+2)
+    //   A lives in 3 buffers (T%3): buffer of T+2 = buffer of T-1, last read at P2(T-1), restaged at P1(T): 3 phases later;
+    //   B lives in 2 buffers (T&1): slots die after P1(T), restaged at P3(T): 2 phases later.
+    // The only in-loop wait is P3's counted vmcnt(8): everything older than K-tile T+2's eight pieces — i.e. all of
+    // K-tile T+1 — has landed; its first ds_read happens in the next phase, behind a barrier both groups have passed.
     bf16x8 af[2][4], b0[2][2], b1[2][2];
+    int abuf = 0;
     for (int T = 0; T < nk; ++T) {
-        const int buf = T & 1;
+        const int bbuf = T & 1;
         // ---- P0: quadrant (m0,n0)
-        readB(buf, 0, b0);
-        readA(buf, 0, af);
-        if (T + 1 < nk) issue(T + 1, 3);
+        readB(bbuf, 0, b0);
+        readA(abuf, 0, af);
         SEG_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         MMA_QUAD(0, 0, af, b0);
         SEG_BARRIER();
         // ---- P1: quadrant (m0,n1)
-        readB(buf, 1, b1);
-        if (T + 1 < nk) issue(T + 1, 0);
+        readB(bbuf, 1, b1);
+        if (T + 2 < nk) issue(T + 2, 0);
         SEG_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         MMA_QUAD(0, 1, af, b1);
         SEG_BARRIER();
         // ---- P2: quadrant (m1,n1)
-        readA(buf, 1, af);
-        if (T + 1 < nk) issue(T + 1, 1);
+        readA(abuf, 1, af);
+        if (T + 2 < nk) issue(T + 2, 1);
         SEG_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         MMA_QUAD(1, 1, af, b1);
         SEG_BARRIER();
-        // ---- P3: quadrant (m1,n0); retire K-tile T+1 (all but the B0(T+2) pieces just issued)
+        // ---- P3: quadrant (m1,n0); retire K-tile T+1
         if (T + 2 < nk) {
-            issue(T + 2, 2);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            issue(T + 2, 2); issue(T + 2, 3);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         SEG_BARRIER();
         MMA_QUAD(1, 0, af, b0);
         SEG_BARRIER();
+        abuf = abuf == 2 ? 0 : abuf + 1;
     }
     if (wr == 0) SEG_BARRIER();               // balance the stagger barrier
 #undef MMA_QUAD
@@ -533,14 +550,15 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             }
         }
     }
+    g_last_cfg = force_tile + 1000 * p.splits;
     if (force_tile == 512) {
         static bool a2 = false;
         if (!a2) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             a2 = true;
         }
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
-        hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), 131072, st, p);
+        hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), 163840, st, p);
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, p.ws,
@@ -564,6 +582,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
 }
 
 int g_force_tile = 0;
+int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 
 int launch_gemm(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
                 int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
@@ -624,6 +643,10 @@ extern "C" int molly_gemm_set_workspace(void* ptr, long bytes) {
     g_ws_bytes = ptr ? (size_t)bytes : 0;
     return 0;
 }
+
+// which kernel configuration the most recent molly_gemm_* call on this thread's library instance used:
+// 128 = 128x128 tile, 256 = 256x128 ring, 512 = 256x256 ping-pong kernel; + 1000 * split-K factor
+extern "C" int molly_gemm_last_config(void) { return g_last_cfg; }
 
 // tuning/test hook: 0 = heuristic, 128 or 256 = force that BM tile configuration
 extern "C" int molly_gemm_force_tile(int bm) {

@@ -80,7 +80,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K))
+        prof.append((e0, e1, 2.0 * M * N * K, lib().query("molly_gemm_last_config"), (a_kmajor, b_kmajor)))
     return out
 
 
