@@ -507,6 +507,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
 
@@ -582,7 +583,6 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
 }
 
 int g_force_tile = 0;
-int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 
 int launch_gemm(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
                 int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
