@@ -201,7 +201,7 @@ def main():
         tokens = world * B * T * args.steps
         # dominant kernel = gemm256_kernel (the 256x256 ping-pong MFMA GEMM); its three operand-layout instantiations
         # are separate rows in rocprofv3 --stats.  Launches that went to the 128x128 kernel (small grids) are listed apart.
-        timed = [(a.elapsed_time(b), f, cfg, lay) for a, b, f, cfg, lay in prof]
+        timed = [(a.elapsed_time(b), f, kcfg, lay) for a, b, f, kcfg, lay in prof]
         gemm_ms = sum(t for t, *_ in timed)
         gemm_fl = sum(f for _, f, *_ in timed)
         n_launch = len(timed)
@@ -209,9 +209,9 @@ def main():
         by_kernel = {}
         names = {(False, False): "NT gemm256_kernel<false,false>", (False, True): "NN gemm256_kernel<false,true>",
                  (True, True): "TN gemm256_kernel<true,true>"}
-        for t, f, cfg, lay in timed:
-            key = names[lay] if cfg % 1000 == 512 else "gemm_kernel<...,128,2,64>"
-            if cfg // 1000 > 1:
+        for t, f, kcfg, lay in timed:
+            key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64>"
+            if kcfg // 1000 > 1:
                 key += " + splitk_reduce"
             d = by_kernel.setdefault(key, [0, 0.0, 0.0])
             d[0] += 1; d[1] += t; d[2] += f
