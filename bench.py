@@ -228,7 +228,10 @@ def main():
             "config": {"workload": f"Molly-{args.model.upper()} (Qwen3-{args.model.upper()} + NT-500M + ESM2-650M) train step, "
                                    f"seq_len {T} text + {K}-residue protein span per sample, {B} samples/GPU, GA=1, "
                                    f"LLM+projectors trainable, encoders frozen, ZeRO-2 dp{world}",
-                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
+                       "scored_token_fraction": 0.25,
+                       "note": "prompt = 75% of each sample with labels -100 (SURVEY 8d); lm_head+CE run on the scored rows only "
+                               "(identical loss/gradients); model_tflops_per_gpu uses the full algorithmic FLOP count"},
             "step_ms_p50": round(statistics.median(step_ms), 2),
             "model_tflops_per_gpu": round(flops_step / (dt / args.steps) / 1e12, 1),
             "mfma_roofline_frac_step": round(flops_step / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -392,8 +392,10 @@ class OmicsOne(nn.Module):
         lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
         hs, overwritten, saved = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, True)
         shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
+        scored = torch.nonzero(shifted != -100).reshape(-1).to(torch.int32)       # host-side: no device sync
         shifted = shifted.to(rt.dev, non_blocking=True)
-        rt.llm.forward(hs, B, T, lo, hi, labels_shifted=shifted, training=True)
+        rt.llm.forward(hs, B, T, lo, hi, labels_shifted=shifted, training=True,
+                       scored_rows=scored.to(rt.dev, non_blocking=True))
         if opt is not None:
             opt.wait_all_params()
         d_hs = rt.llm.loss_and_backward(accumulate=accumulate, final_micro=final_micro)

@@ -108,6 +108,7 @@ class Qwen3Engine:
             self.d_act = e(M, ff); self.d_gu = e(M, 2 * ff)
             self.d_attn = e(M, self.nh * self.hd); self.d_qkv = e(M, self.nqkv); self.d_qk = e(M, self.nqk)
             self.delta = e(B, self.nh, T, dt=torch.float32)
+            self.hn_s = e(M, h); self.dh_s = e(M, h)                       # compacted scored rows (head GEMMs)
             # split-K scratch for the wgrad GEMMs: 8 slabs of the largest per-layer weight
             ops.ensure_gemm_workspace(8 * 4 * max(2 * ff * h, self.nqkv * h), dev)
             nb1 = ops.lib().query("molly_rmsnorm_bwd_blocks", M)
@@ -116,9 +117,13 @@ class Qwen3Engine:
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward(self, inputs_embeds: torch.Tensor, B: int, T: int, kv_lo=None, kv_hi=None,
-                labels_shifted: Optional[torch.Tensor] = None, training: bool = True, return_logits: bool = False):
+                labels_shifted: Optional[torch.Tensor] = None, training: bool = True, return_logits: bool = False,
+                scored_rows: Optional[torch.Tensor] = None):
         """inputs_embeds [B*T, h] bf16.  labels_shifted int64 [B*T]: row r is scored against labels_shifted[r]
         (HF shift: pad one ignore column then drop the first, HF:loss/loss_utils.py:60-63).
+        scored_rows (training only): int32 device tensor of the rows whose label is not ignore_index, in ascending order —
+        the lm_head GEMMs and the CE then run on those rows only (rows with ignore_index contribute exactly zero loss and
+        zero gradient, so the result is identical; SFT batches mask the whole prompt).
         Returns (loss device-scalar view or None, logits [B*T, V] or None)."""
         cfg, M = self.cfg, B * T
         self.reserve(M, B, T, training)
@@ -157,6 +162,7 @@ class Qwen3Engine:
                 ops.gemm_nt(self.hn[c0:c1], self.head, out=logits_all[c0:c1])
         if labels_shifted is not None:
             self.labels = labels_shifted
+            self.scored_rows = scored_rows
             ops.count_valid(labels_shifted, self.scal[0:1], self.scal[1:2])
             if not (training and self.G is not None):
                 # loss only (eval): logits chunk by chunk, no gradient written
@@ -190,18 +196,36 @@ class Qwen3Engine:
         M = B * T
         kv_lo, kv_hi = self.kv
         dh = self.d_a
+        rows = self.scored_rows
+        if rows is not None:
+            # compact to the scored rows: gather hn / labels, run the head on n_s rows, scatter d(hn) back (zeros elsewhere)
+            n_s = rows.numel()
+            hn_s = self.hn_s[:n_s]
+            ops.copy_rows(self.hn, hn_s, n_s, src_idx32=rows)
+            lab_s = self.labels.index_select(0, rows.long())       # index plumbing (int64 gather of the labels)
+            dh.zero_()
+            src_hn, src_lab, n_rows, dh_s = hn_s, lab_s, n_s, self.dh_s[:n_s]
+        else:
+            src_hn, src_lab, n_rows, dh_s = self.hn, self.labels, M, dh
         first = True
-        for c0 in range(0, M, self.C):
-            c1 = min(M, c0 + self.C)
+        for c0 in range(0, n_rows, self.C):
+            c1 = min(n_rows, c0 + self.C)
             n = c1 - c0
             lg = self.logits[:n]
-            ops.gemm_nt(self.hn[c0:c1], self.head, out=lg)
-            ops.ce_fwd_bwd(lg, self.labels[c0:c1], self.row_loss[c0:c1], self.scal[0:1], write_grad=True)
-            self._dgrad(lg, self.head, dh[c0:c1])                                     # d(hn) = dlogits · E
+            ops.gemm_nt(src_hn[c0:c1], self.head, out=lg)
+            ops.ce_fwd_bwd(lg, src_lab[c0:c1], self.row_loss[c0:c1], self.scal[0:1], write_grad=True)
+            self._dgrad(lg, self.head, dh_s[c0:c1])                                   # d(hn) = dlogits · E
             # dE (+)= dlogits^T · hn   (tied embeddings: the gather-gradient is added later by the caller)
-            self._wgrad(lg, self.hn[c0:c1], self.d_head, accumulate or not first)
+            self._wgrad(lg, src_hn[c0:c1], self.d_head, accumulate or not first)
             first = False
-        ops.sum_f32(self.row_loss[:M], self.scal[2:3], scale=self.scal[0:1])
+        if rows is not None:
+            ops.copy_rows(dh_s, dh, n_rows, dst_idx32=rows)
+            if n_rows == 0:
+                self.row_loss[:1].zero_()
+                if not accumulate:
+                    self.d_head.zero_()
+        M_loss = n_rows
+        ops.sum_f32(self.row_loss[:max(M_loss, 1)], self.scal[2:3], scale=self.scal[0:1])
         # final norm backward
         dx = self.d_b
         ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, self.d_norm_w, cfg.rms_norm_eps, dx=dx, dw_accumulate=accumulate,
