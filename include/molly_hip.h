@@ -36,7 +36,9 @@ enum {
     MOLLY_GEMM_GELU = 2,        /* exact erf GELU after bias                      */
     MOLLY_GEMM_RESIDUAL = 4,    /* + res[m,n] (bf16, ldres)                       */
     MOLLY_GEMM_ACCUMULATE = 8,  /* C += result (same dtype as C)                  */
-    MOLLY_GEMM_OUT_F32 = 16     /* C is fp32 instead of bf16                      */
+    MOLLY_GEMM_OUT_F32 = 16,    /* C is fp32 instead of bf16                      */
+    MOLLY_GEMM_TRANS_OUT = 32   /* store C^T: the output buffer is [N][M] (ldc >= M); molly_gemm_bf16 with a_kmajor=0,
+                                   b_kmajor=1 only — the wgrad form  dW[N',K'] = (x^T)[K',tok] dy[tok,N']  stored as dW */
 };
 int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
                        int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags);
@@ -53,6 +55,8 @@ int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const v
 int molly_gemm_set_workspace(void* ptr, long bytes);
 /* configuration the most recent GEMM call used: 128 | 256 | 512 (= the 256x256 ping-pong kernel) + 1000 * split-K factor */
 int molly_gemm_last_config(void);
+/* tuning hook: M-tiles per group in the 256x256 kernel's tile walk (L2 locality; default 4) */
+int molly_gemm_set_group_m(int g);
 /* tuning/test hook: 0 = heuristic tile choice, 128 / 256 = force that BM tile configuration of the GEMM kernel. */
 int molly_gemm_force_tile(int bm);
 

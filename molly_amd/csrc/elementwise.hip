@@ -25,6 +25,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     }
 }
 
+// fast path (R, C multiples of 64, 16-byte aligned rows): 16-byte coalesced loads, transposition by
+// ds_read_b64_tr_b16 (guide T10), 16-byte stores that fill whole 64-byte segments of the output rows.  HBM-bound.
+__global__ __launch_bounds__(256) void transpose64_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int ld_in,
+                                                          int ld_out) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];      // row pitch 144 B
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    {
+        const int row = t >> 2, col = (t & 3) * 16;
+        const u32x4* src = reinterpret_cast<const u32x4*>(in + (size_t)(r0 + row) * ld_in + c0 + col);
+        const u32x4 a = src[0], b = src[1];
+        // pitch 144 B keeps 16-byte alignment only for even rows; write as 8-byte pieces
+        u32x2* dst = reinterpret_cast<u32x2*>(tile + row * 72 + col);
+        dst[0] = u32x2{a[0], a[1]}; dst[1] = u32x2{a[2], a[3]}; dst[2] = u32x2{b[0], b[1]}; dst[3] = u32x2{b[2], b[3]};
+    }
+    __syncthreads();
+    const int lane = t & 63, w = t >> 6;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int oc = w * 16;                         // this wave's 16 input columns = 16 output rows
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int rr = pass * 32 + g * 8;          // 8 input rows -> 8 consecutive output columns
+        const bf16_t* pa = tile + (rr + q) * 72 + oc + 4 * pp;
+        const bf16_t* pb = tile + (rr + 4 + q) * 72 + oc + 4 * pp;
+        const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
+        const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
+        const bf16x8 v = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        *reinterpret_cast<bf16x8*>(out + (size_t)(c0 + oc + i) * ld_out + r0 + rr) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // RMSNorm (HF:models/qwen3/modeling_qwen3.py:59-64): y = w * bf16(x * rsqrt(mean(x^2)+eps))
 // one wave per row, 4 rows per block; row kept in registers (H <= 8192)
@@ -849,6 +880,13 @@ inline int grid_for(long items, int per_block = 256, int cap = 2048) {
 
 extern "C" int molly_transpose_bf16(void* stream, const void* in, void* out, int R, int C, int ld_in, int ld_out) {
     MOLLY_CHECK(R > 0 && C > 0 && ld_in >= C && ld_out >= R, "transpose: bad shape R=%d C=%d", R, C);
+    if (R % 64 == 0 && C % 64 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in % 16) == 0 &&
+        ((uintptr_t)out % 16) == 0) {
+        hipLaunchKernelGGL(transpose64_kernel, dim3(C / 64, R / 64), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, ld_in,
+                           ld_out);
+        MOLLY_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64)), dim3(256), 0, ST, (const bf16_t*)in, (bf16_t*)out, R,
                        C, ld_in, ld_out);
     MOLLY_LAUNCH_CHECK();

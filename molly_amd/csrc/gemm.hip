@@ -32,6 +32,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     const bf16_t* zeros;      // >= 16 bytes of zeros: source of k-rows beyond K for k-major operands
     int splits;               // split-K factor of the 256x256 kernel (1 = none)
+    int group_m;              // M-tiles per group in the tile walk of the 256x256 kernel
     float* ws;                // fp32 partial slabs [splits][M][N] when splits > 1
 };
 
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 // Arithmetic intensity 128 flop/B of L2->LDS traffic (2x the 128² tile): the per-CU vector-memory path (64 B/clk) and
 // the matrix pipe are no longer at a 1:1 ridge.
 // ================================================================================================
-template <bool AT, bool BT>
+template <bool AT, bool BT, bool TO = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int ntile = p.tiles_m * p.tiles_n;
     const int split = work / ntile;
     const int swz = work - split * ntile;
-    constexpr int GROUP_M = 4;
+    const int GROUP_M = p.group_m;
     const int per_group = GROUP_M * p.tiles_n;
     const int grp = swz / per_group;
     const int first_m = grp * GROUP_M;
@@ -344,8 +345,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-            acc[(MH) * 4 + i][(NH) * 2 + j] =                                                               \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[kk][j], AF[kk][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+            acc[(MH) * 4 + i][(NH) * 2 + j] = TO                                                            \
+                ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[kk][i], BF[kk][j], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0) \
+                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[kk][j], AF[kk][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     } while (0)
 #define SEG_BARRIER()                          \
@@ -416,6 +418,42 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #undef MMA_QUAD
 #undef SEG_BARRIER
 
+    if constexpr (TO) {
+        // transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr];
+        // C^T is stored as [N][M] (ld = ldc), i.e. 4 consecutive m of one n -> 8-byte bf16 / 16-byte fp32 stores.
+        const bool accum = p.flags & MOLLY_GEMM_ACCUMULATE, out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
+        const int fr_ = lane & 15, fq_ = lane >> 4;
+        float* slab = p.splits > 1 ? p.ws + (size_t)split * p.M * p.N : nullptr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + fq_ * 4;
+            if (m >= p.M) continue;                                   // M % 4 == 0 checked by the host
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wc * 64 + j * 16 + fr_;
+                if (n >= p.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (slab) {
+                    *reinterpret_cast<f32x4*>(slab + (size_t)n * p.M + m) = f32x4{v[0], v[1], v[2], v[3]};
+                } else if (out_f32) {
+                    float* c = reinterpret_cast<float*>(p.C) + (size_t)n * p.ldc + m;
+                    if (accum) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(c);
+                        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                    }
+                    *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)n * p.ldc + m;
+                    if (accum) {
+                        const u32x2 o = *reinterpret_cast<const u32x2*>(c);
+                        v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+                    }
+                    *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                }
+            }
+        }
+        return;
+    }
     if (p.splits > 1) {
         // split-K: plain fp32 partial slab of this slice; molly's splitk_reduce kernel sums the slabs (launch-boundary
         // reduce: cheaper than an in-launch combine at these slab sizes, guide §5 "Projection GEMM" item 2)
@@ -481,6 +519,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 // out[m,n] (+)= sum_s slab[s][m][n]   (split-K combine; 4 elements per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long MN, int M, int N,
                                                             void* C, int ldc, int out_f32, int accumulate) {
+    // slab = [M rows][N cols] of the OUTPUT matrix as stored (for transposed output the caller passes rows = N_gemm)
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long)gridDim.x * 1024) {
         f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
         for (int s = 1; s < splits; ++s) {
@@ -507,13 +546,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+int g_group_m = 4;
 int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
 
 __device__ bf16_t g_zero_page[64];      // zero-initialised device memory (k-rows beyond K)
 
-template <bool AT, bool BT>
+template <bool AT, bool BT, bool TO = false>
 int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
     // force_tile: 0 heuristic | 128 = <128,2 stages,BK64> | 256 = <256,3 stages,BK64> | 32 = <128,2 stages,BK32>
     static bool attr_set = false;
@@ -528,6 +568,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
     // is long (wgrad: K = tokens), split K so that tiles x splits does (fp32 slabs + a reduce launch); else 128x128.
     p.splits = 1;
     p.ws = nullptr;
+    p.group_m = g_group_m;
     if (force_tile == 0) {
         const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256);
         auto eff = [](long items) { return (double)items / (double)(((items + 255) / 256) * 256); };
@@ -547,7 +588,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
                 p.splits = best;
                 p.ws = g_ws;
             } else {
-                force_tile = 128;
+                force_tile = TO ? 512 : 128;                   // transposed output exists in the 256x256 kernel only
             }
         }
     }
@@ -555,17 +596,20 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
     if (force_tile == 512) {
         static bool a2 = false;
         if (!a2) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             a2 = true;
         }
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
-        hipLaunchKernelGGL((gemm256_kernel<AT, BT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), 163840, st, p);
+        hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), 163840, st, p);
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, p.ws,
-                               p.splits, MN, p.M, p.N, p.C, p.ldc, (p.flags & MOLLY_GEMM_OUT_F32) ? 1 : 0,
-                               (p.flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0);
+                               p.splits, MN, TO ? p.N : p.M, TO ? p.M : p.N, p.C, p.ldc,
+                               (p.flags & MOLLY_GEMM_OUT_F32) ? 1 : 0, (p.flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0);
         }
+    } else if constexpr (TO) {
+        molly_set_error("gemm: transposed output is only built into the 256x256 kernel");
+        return 1;
     } else if (force_tile == 256) {
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, BN);
         hipLaunchKernelGGL((gemm_kernel<AT, BT, 256, 3, 64>), dim3(p.tiles_m * p.tiles_n), dim3(512),
@@ -588,7 +632,7 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
                 int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
     MOLLY_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     MOLLY_CHECK((at && bt) || K % 64 == 0, "gemm: K=%d must be a multiple of %d when an operand is k-contiguous", K, 64);
-    MOLLY_CHECK(N % 4 == 0, "gemm: N=%d must be a multiple of 4", N);
+    MOLLY_CHECK(N % 4 == 0 || (flags & MOLLY_GEMM_TRANS_OUT), "gemm: N=%d must be a multiple of 4", N);
     MOLLY_CHECK(!at || M % 8 == 0, "gemm: k-major A needs M %% 8 == 0 (M=%d)", M);
     MOLLY_CHECK(!bt || N % 8 == 0, "gemm: k-major B needs N %% 8 == 0 (N=%d)", N);
     MOLLY_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm: lda/ldb must be multiples of 8, ldc of 4");
@@ -611,7 +655,12 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
     }
     p.zeros = zeros;
     hipStream_t st = (hipStream_t)stream;
-    if (!at && !bt) launch_cfg<false, false>(st, p, g_force_tile);
+    if (flags & MOLLY_GEMM_TRANS_OUT) {
+        MOLLY_CHECK(!at && bt, "gemm: MOLLY_GEMM_TRANS_OUT is built for the (k-contiguous A, k-major B) form only");
+        MOLLY_CHECK(!(flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_GELU | MOLLY_GEMM_RESIDUAL)) && M % 4 == 0,
+                    "gemm: MOLLY_GEMM_TRANS_OUT takes no bias/GELU/residual and needs M %% 4 == 0");
+        if (launch_cfg<false, true, true>(st, p, g_force_tile == 0 ? 0 : 512)) return 1;
+    } else if (!at && !bt) launch_cfg<false, false>(st, p, g_force_tile);
     else if (!at && bt) launch_cfg<false, true>(st, p, g_force_tile);
     else if (at && bt) launch_cfg<true, true>(st, p, g_force_tile);
     else {
@@ -647,6 +696,12 @@ extern "C" int molly_gemm_set_workspace(void* ptr, long bytes) {
 // which kernel configuration the most recent molly_gemm_* call on this thread's library instance used:
 // 128 = 128x128 tile, 256 = 256x128 ring, 512 = 256x256 ping-pong kernel; + 1000 * split-K factor
 extern "C" int molly_gemm_last_config(void) { return g_last_cfg; }
+
+extern "C" int molly_gemm_set_group_m(int g) {
+    MOLLY_CHECK(g >= 1 && g <= 64, "gemm_set_group_m: %d", g);
+    g_group_m = g;
+    return 0;
+}
 
 // tuning/test hook: 0 = heuristic, 128 or 256 = force that BM tile configuration
 extern "C" int molly_gemm_force_tile(int bm) {

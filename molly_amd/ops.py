@@ -9,7 +9,7 @@ import torch
 from ._lib import lib
 
 BF16 = torch.bfloat16
-GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32 = 1, 2, 4, 8, 16
+GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32, GEMM_TRANS_OUT = 1, 2, 4, 8, 16, 32
 
 
 # optional per-launch timing of the dominant kernel (bench.py roofline): list of (start_event, end_event, flops)
@@ -48,17 +48,18 @@ def gemm_nt(a, b, out=None, bias=None, res=None, gelu=False, accumulate=False, o
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
          res: Optional[torch.Tensor] = None, gelu: bool = False, accumulate: bool = False, out_dtype=BF16,
-         a_kmajor: bool = False, b_kmajor: bool = False) -> torch.Tensor:
-    """out[M,N] = op(a) @ op(b): a is [M,K] (or [K,M] when a_kmajor), b is [N,K] (or [K,N] when b_kmajor)."""
+         a_kmajor: bool = False, b_kmajor: bool = False, trans_out: bool = False) -> torch.Tensor:
+    """out[M,N] = op(a) @ op(b): a is [M,K] (or [K,M] when a_kmajor), b is [N,K] (or [K,N] when b_kmajor).
+    trans_out: the result is stored transposed, `out` is [N, M]."""
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
     K, M = (a.shape if a_kmajor else a.shape[::-1])
     K2, N = (b.shape if b_kmajor else b.shape[::-1])
     assert K == K2, (a.shape, b.shape, a_kmajor, b_kmajor)
     if out is None:
         assert not accumulate
-        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        out = torch.empty((N, M) if trans_out else (M, N), dtype=out_dtype, device=a.device)
     _chk(out, None, "out")
-    flags = 0
+    flags = GEMM_TRANS_OUT if trans_out else 0
     if bias is not None:
         _chk(bias, BF16, "bias"); flags |= GEMM_BIAS
     if gelu:

@@ -49,6 +49,7 @@ class Qwen3Engine:
         self.ce_chunk_rows = ce_chunk_rows
         self.rope_table_dtype = rope_table_dtype
         self.cap = 0
+        self.tT = None
         self.grads_final_hook = None      # callable(lo, hi): flat-offset range of gradients that became final (ZeRO overlap)
         self.wait_params_hook = None      # callable(lo, hi): block the stream until those parameters are all-gathered
         self._views()
@@ -109,6 +110,7 @@ class Qwen3Engine:
             self.d_attn = e(M, self.nh * self.hd); self.d_qkv = e(M, self.nqkv); self.d_qk = e(M, self.nqk)
             self.delta = e(B, self.nh, T, dt=torch.float32)
             self.hn_s = e(M, h); self.dh_s = e(M, h)                       # compacted scored rows (head GEMMs)
+            self.tT = e(max(h, self.nh * self.hd) * M)                     # transposed narrow operand of the wgrad GEMMs
             # split-K scratch for the wgrad GEMMs: 8 slabs of the largest per-layer weight
             ops.ensure_gemm_workspace(8 * 4 * max(2 * ff * h, self.nqkv * h), dev)
             nb1 = ops.lib().query("molly_rmsnorm_bwd_blocks", M)
@@ -176,9 +178,26 @@ class Qwen3Engine:
         return loss, logits_all
 
     # ---- helpers ---------------------------------------------------------------------------------------------
-    @staticmethod
-    def _wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
-        """dw[N,K] (+)= dy[M,N]^T x[M,K]: both operands k-major (contraction over the token rows)."""
+    def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
+        """dw[N,K] (+)= dy[M,N]^T x[M,K], contraction over the M token rows.
+        Fast form (tokens % 64 == 0): transpose the NARROWER operand once (an HBM-bound pass over the smaller matrix) and
+        run the GEMM with a k-contiguous A and a k-major B — the layout pair the 256x256 kernel is fastest on (half the
+        transposed LDS reads of the both-k-major form):
+            x narrower : dw^T[K,N] = (x^T)[K,M] dy[M,N], stored transposed straight into dw
+            dy narrower: dw[N,K]   = (dy^T)[N,M] x[M,K]
+        Any other token count: both operands k-major (no transposes, any contraction length)."""
+        M, N = dy.shape
+        K = x.shape[1]
+        if M % 64 == 0 and min(N, K) % 64 == 0 and self.tT is not None and min(N, K) * M <= self.tT.numel():
+            if K <= N:
+                xt = self.tT[:K * M].view(K, M)
+                ops.transpose(x, xt)
+                ops.gemm(xt, dy, out=dw, accumulate=accumulate, b_kmajor=True, trans_out=True)
+            else:
+                dyt = self.tT[:N * M].view(N, M)
+                ops.transpose(dy, dyt)
+                ops.gemm(dyt, x, out=dw, accumulate=accumulate, b_kmajor=True)
+            return
         ops.gemm(dy, x, out=dw, accumulate=accumulate, a_kmajor=True, b_kmajor=True)
 
     @staticmethod

@@ -469,3 +469,26 @@ def test_gemm_splitk_wgrad_path():
     first = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32).clone()
     for _ in range(5):
         assert torch.equal(ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32), first)
+
+
+def test_transpose_fast_path_and_trans_out_gemm():
+    x = _rand(512, 1024, seed=80).to(BF)
+    assert torch.equal(ops.transpose(x), x.T.contiguous())             # 64-multiple shapes -> tr-read kernel
+    # wgrad form with the narrow operand transposed and the result stored transposed
+    Mtok, N, K = 2048, 768, 512
+    dy, xx = _rand(Mtok, N, seed=81).to(BF), _rand(Mtok, K, seed=82).to(BF)
+    ref = dy.float().T @ xx.float()                                      # dW [N, K]
+    xt = ops.transpose(xx)                                               # [K, Mtok]
+    dw = ops.gemm(xt, dy, b_kmajor=True, trans_out=True, out_dtype=torch.float32)
+    assert dw.shape == (N, K)
+    _close(dw, ref, atol=1e-3 * math.sqrt(Mtok), rtol=1e-4, what="trans_out wgrad")
+    acc = _rand(N, K, seed=83).to(BF)
+    base = acc.clone()
+    ops.gemm(xt, dy, out=acc, accumulate=True, b_kmajor=True, trans_out=True)
+    _close(acc, ref + base.float(), atol=0.3, rtol=8e-3, what="trans_out accumulate bf16")
+    # split-K + transposed slabs (long contraction, small output)
+    ops.ensure_gemm_workspace(256 << 20)
+    Mtok = 8192
+    dy, xx = _rand(Mtok, 1024, seed=84).to(BF), _rand(Mtok, 512, seed=85).to(BF)
+    dw = ops.gemm(ops.transpose(xx), dy, b_kmajor=True, trans_out=True, out_dtype=torch.float32)
+    _close(dw, dy.float().T @ xx.float(), atol=1e-3 * math.sqrt(Mtok), rtol=1e-4, what="trans_out split-K")
