@@ -425,8 +425,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 }
 
 // dK/dV: block = 128 keys (4 waves x 32 keys) of one (batch, kv head); loops over the group's query heads and query tiles.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+// MODE 0: dK and dV in one pass (256 accumulator registers -> one wave per SIMD); MODE 1: dV only (S -> P -> dV);
+// MODE 2: dK only (S, dP -> dS -> dK).  The two single-output passes recompute S (+25 % MFMAs in total) but fit two
+// waves per SIMD, which is what the matrix-pipe / VALU overlap needs — measured faster than MODE 0 at hd 128.
+template <int HD, int MODE>
+__global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TILE = BKV * HD;                               // 64 query rows per tile
     constexpr int NS = HD / 16, ND = HD / 32;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
-            vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
+            if (DO_DK) vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
         }
     }
     f32x16 dk[ND], dv[ND];
@@ -506,7 +510,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, 32 * sub + r, s, h), kf[s], sA, 0, 0, 0);
-                    dpA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sD, 32 * sub + r, s, h), vf[s], dpA, 0, 0, 0);
+                    if (DO_DK)
+                        dpA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sD, 32 * sub + r, s, h), vf[s], dpA, 0, 0, 0);
                 }
                 f32x16 pA;
 #pragma unroll
@@ -518,14 +523,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
                     pA[e] = pr;
                     sA[e] = pr * (dpA[e] - sL[64 + ql]);                        // dS (unscaled)
                 }
-                const bf16x8 p0 = acc_to_frag(pA, 0), p1 = acc_to_frag(pA, 8);
-                const bf16x8 d0 = acc_to_frag(sA, 0), d1 = acc_to_frag(sA, 8);
+                if (DO_DV) {
+                    const bf16x8 p0 = acc_to_frag(pA, 0), p1 = acc_to_frag(pA, 8);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 32 * sub, 0, d, lane), p0, dv[d], 0, 0, 0);
-                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 32 * sub, 1, d, lane), p1, dv[d], 0, 0, 0);
-                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 32 * sub, 0, d, lane), d0, dk[d], 0, 0, 0);
-                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 32 * sub, 1, d, lane), d1, dk[d], 0, 0, 0);
+                    for (int d = 0; d < ND; ++d) {
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 32 * sub, 0, d, lane), p0, dv[d], 0, 0, 0);
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 32 * sub, 1, d, lane), p1, dv[d], 0, 0, 0);
+                    }
+                }
+                if (DO_DK) {
+                    const bf16x8 d0 = acc_to_frag(sA, 0), d1 = acc_to_frag(sA, 8);
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 32 * sub, 0, d, lane), d0, dk[d], 0, 0, 0);
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 32 * sub, 1, d, lane), d1, dk[d], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -540,11 +552,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int dd = 32 * d + 8 * g4 + 4 * h;
-                *reinterpret_cast<u32x2*>(kp + dd) =
-                    u32x2{pack_bf2(dk[d][4 * g4] * p.scale, dk[d][4 * g4 + 1] * p.scale),
-                          pack_bf2(dk[d][4 * g4 + 2] * p.scale, dk[d][4 * g4 + 3] * p.scale)};
-                *reinterpret_cast<u32x2*>(vp + dd) = u32x2{pack_bf2(dv[d][4 * g4], dv[d][4 * g4 + 1]),
-                                                           pack_bf2(dv[d][4 * g4 + 2], dv[d][4 * g4 + 3])};
+                if (DO_DK)
+                    *reinterpret_cast<u32x2*>(kp + dd) =
+                        u32x2{pack_bf2(dk[d][4 * g4] * p.scale, dk[d][4 * g4 + 1] * p.scale),
+                              pack_bf2(dk[d][4 * g4 + 2] * p.scale, dk[d][4 * g4 + 3] * p.scale)};
+                if (DO_DV)
+                    *reinterpret_cast<u32x2*>(vp + dd) = u32x2{pack_bf2(dv[d][4 * g4], dv[d][4 * g4 + 1]),
+                                                               pack_bf2(dv[d][4 * g4 + 2], dv[d][4 * g4 + 3])};
             }
     }
 }
@@ -602,17 +616,19 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
         attr_set = true;
     }
     dim3 gq(n_heads * B, cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(256), lds_dkv, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk, dim3(256), lds_dkv, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2>), gk, dim3(256), lds_dkv, st, p);
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), lds_dq, st, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), lds_dkv, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 0>), gk, dim3(256), lds_dkv, st, p);
     }
     MOLLY_LAUNCH_CHECK();
     return 0;
