@@ -57,6 +57,9 @@ int molly_gemm_set_workspace(void* ptr, long bytes);
 int molly_gemm_last_config(void);
 /* tuning hook: M-tiles per group in the 256x256 kernel's tile walk (L2 locality; default 4) */
 int molly_gemm_set_group_m(int g);
+/* tuning hook: resident blocks of the persistent 256x256 kernel (default 256 = one per CU; multiple of 8);
+ * 0 = launch one block per tile. */
+int molly_gemm_set_persistent_blocks(int n);
 /* tuning/test hook: 0 = heuristic tile choice, 128 / 256 = force that BM tile configuration of the GEMM kernel. */
 int molly_gemm_force_tile(int bm);
 

@@ -282,32 +282,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // K-slice is the SLOWEST index: the work items that run side by side on one XCD then belong to one slice and keep
-    // sharing operand panels through its L2 (slices of one tile share nothing: they read different K ranges)
+    // ---- persistent tile loop: block b runs virtual ids b, b+G, b+2G, ... (G = gridDim.x, a multiple of 8 whenever there
+    // is more than one round, so a block's XCD label v&7 never changes).  The first two K-tiles of the NEXT tile are issued
+    // before the epilogue stores of the current one, so neither the prologue load latency nor the store tail idles the
+    // matrix pipe between tiles.
+    const int nwork = p.tiles_m * p.tiles_n * p.splits;
     const int ntile = p.tiles_m * p.tiles_n;
-    const int split = work / ntile;
-    const int swz = work - split * ntile;
-    const int GROUP_M = p.group_m;
-    const int per_group = GROUP_M * p.tiles_n;
-    const int grp = swz / per_group;
-    const int first_m = grp * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (swz % per_group) % gsz;
-    const int tn = (swz % per_group) / gsz;
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk_all = (p.K + BK - 1) / BK;
+    int m0, n0, split, kt0, nk;
+    auto decode = [&](int v) {
+        const int q = nwork >> 3, r = nwork & 7, xcd = v & 7;
+        const int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        // K-slice is the SLOWEST index: the work items that run side by side on one XCD then belong to one slice and
+        // keep sharing operand panels through its L2 (slices of one tile share nothing: they read different K ranges)
+        split = work / ntile;
+        const int swz = work - split * ntile;
+        const int GROUP_M = p.group_m;
+        const int per_group = GROUP_M * p.tiles_n;
+        const int grp = swz / per_group;
+        const int first_m = grp * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (swz % per_group) % gsz) * 256;
+        n0 = ((swz % per_group) / gsz) * 256;
+        kt0 = (int)((long)nk_all * split / p.splits);
+        nk = (int)((long)nk_all * (split + 1) / p.splits) - kt0;      // K-tiles of this slice
+    };
+    int vcur = blockIdx.x;
+    decode(vcur);
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk_all = (p.K + BK - 1) / BK;
-    const int kt0 = (int)((long)nk_all * split / p.splits), kt1 = (int)((long)nk_all * (split + 1) / p.splits);
-    const int nk = kt1 - kt0;                 // K-tiles of this slice
     // LDS = 10 half-tile slots (all 160 KiB): A triple-buffered [3][A0|A1], then B double-buffered [2][B0|B1]
     // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; ktl is slice-local
     auto issue = [&](int ktl, int which) {
@@ -357,13 +360,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
-    // ---- prologue: K-tiles 0 and 1 issued; wait for K-tile 0 only
+    // ---- prologue of the first tile: K-tiles 0 and 1 issued
     issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
-    if (nk > 1) {
-        issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (nk > 1) { issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3); }
+    bool exact_stores = false;                // previous epilogue issued exactly 32 plain stores per lane (and no loads)
+
+    for (;;) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // wait for K-tile 0 only.  Outstanding, oldest first: [K-tile 0: 8][K-tile 1: 8 if nk > 1][previous epilogue stores].
+    // vmcnt counts loads and stores together in issue order, so with exactly 32 stores behind the loads the counted wait
+    // lets all of them (and K-tile 1) stay in flight; any other epilogue falls back to a conservative count.
+    if (exact_stores) {
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     SEG_BARRIER();
     if (wr == 1) SEG_BARRIER();               // stagger: group 1 runs one segment behind group 0
@@ -414,23 +429,33 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         SEG_BARRIER();
         abuf = abuf == 2 ? 0 : abuf + 1;
     }
-    if (wr == 0) SEG_BARRIER();               // balance the stagger barrier
-#undef MMA_QUAD
-#undef SEG_BARRIER
+    if (wr == 0) SEG_BARRIER();               // balance the stagger barrier (every LDS read of this tile has returned)
+
+    // this tile's coordinates for the epilogue; then decode + prefetch the next tile BEFORE the stores
+    const int em0 = m0, en0 = n0, esplit = split;
+    const int vnext = vcur + gridDim.x;
+    const bool more = vnext < nwork;
+    if (more) {
+        decode(vnext);
+        issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
+        if (nk > 1) { issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3); }
+    }
+    exact_stores = em0 + 256 <= p.M && en0 + 256 <= p.N &&
+                   !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE));
 
     if constexpr (TO) {
         // transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr];
         // C^T is stored as [N][M] (ld = ldc), i.e. 4 consecutive m of one n -> 8-byte bf16 / 16-byte fp32 stores.
         const bool accum = p.flags & MOLLY_GEMM_ACCUMULATE, out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
         const int fr_ = lane & 15, fq_ = lane >> 4;
-        float* slab = p.splits > 1 ? p.ws + (size_t)split * p.M * p.N : nullptr;
+        float* slab = p.splits > 1 ? p.ws + (size_t)esplit * p.M * p.N : nullptr;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + fq_ * 4;
+            const int m = em0 + wr * 128 + i * 16 + fq_ * 4;
             if (m >= p.M) continue;                                   // M % 4 == 0 checked by the host
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wc * 64 + j * 16 + fr_;
+                const int n = en0 + wc * 64 + j * 16 + fr_;
                 if (n >= p.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (slab) {
@@ -452,25 +477,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
             }
         }
-        return;
-    }
-    if (p.splits > 1) {
+    } else if (p.splits > 1) {
         // split-K: plain fp32 partial slab of this slice; molly's splitk_reduce kernel sums the slabs (launch-boundary
         // reduce: cheaper than an in-launch combine at these slab sizes, guide §5 "Projection GEMM" item 2)
-        float* slab = p.ws + (size_t)split * p.M * p.N;
+        float* slab = p.ws + (size_t)esplit * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            const int m = em0 + wr * 128 + i * 16 + (lane & 15);
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                const int n = en0 + wc * 64 + j * 16 + (lane >> 4) * 4;
                 if (n >= p.N) continue;
                 *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
             }
         }
-        return;
-    }
+    } else {
 
     // ---- epilogue: lane owns C[m = .. + fr][n = .. + fq*4 + 0..3]
     const bool has_bias = p.flags & MOLLY_GEMM_BIAS, has_res = p.flags & MOLLY_GEMM_RESIDUAL;
@@ -478,11 +500,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const bool out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + fr;
+        const int m = em0 + wr * 128 + i * 16 + fr;
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + fq * 4;
+            const int n = en0 + wc * 64 + j * 16 + fq * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (has_bias) {
@@ -514,6 +536,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             }
         }
     }
+    }   // epilogue variants
+
+    if (!more) break;
+    vcur = vnext;
+    }   // persistent tile loop
+#undef MMA_QUAD
+#undef SEG_BARRIER
 }
 
 // out[m,n] (+)= sum_s slab[s][m][n]   (split-K combine; 4 elements per thread)
@@ -547,6 +576,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int g_group_m = 4;
+int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile
 int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
@@ -600,7 +630,10 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             a2 = true;
         }
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
-        hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(512), 163840, st, p);
+        // persistent: at most g_persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
+        const int nwork = p.tiles_m * p.tiles_n * p.splits;
+        const int grid = g_persist_blocks > 0 ? min(nwork, g_persist_blocks) : nwork;
+        hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO>), dim3(grid), dim3(512), 163840, st, p);
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, p.ws,
@@ -700,6 +733,12 @@ extern "C" int molly_gemm_last_config(void) { return g_last_cfg; }
 extern "C" int molly_gemm_set_group_m(int g) {
     MOLLY_CHECK(g >= 1 && g <= 64, "gemm_set_group_m: %d", g);
     g_group_m = g;
+    return 0;
+}
+
+extern "C" int molly_gemm_set_persistent_blocks(int n) {
+    MOLLY_CHECK(n >= 0 && n % 8 == 0, "gemm_set_persistent_blocks: %d must be a non-negative multiple of 8", n);
+    g_persist_blocks = n;
     return 0;
 }
 

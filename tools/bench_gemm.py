@@ -28,10 +28,14 @@ def main():
     ap.add_argument("--tiles", type=int, nargs="+", default=[128, 256])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--persist", type=int, nargs="+", default=None,
+                    help="compare resident-block counts of the persistent 256x256 kernel (0 = one block per tile)")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
+    if args.persist is not None:
+        args.tiles = [512000 + pv for pv in args.persist]      # column key = 512 kernel with that resident-block count
     print(f"{'shape':16s} {'form':4s} {'M':>7s} {'N':>7s} {'K':>7s} " + " ".join(f"{'BM' + str(t) + ' TF/s':>12s}" for t in args.tiles))
     for name, form, m, n, k in SHAPES:
         if args.only and args.only not in name:
@@ -49,7 +53,11 @@ def main():
         best = {t: 1e9 for t in args.tiles}
         for r in range(args.rounds):
             for t in args.tiles:
-                lib().call("molly_gemm_force_tile", t)
+                if t >= 512000:
+                    lib().call("molly_gemm_force_tile", 512)
+                    lib().call("molly_gemm_set_persistent_blocks", t - 512000)
+                else:
+                    lib().call("molly_gemm_force_tile", t)
                 ops.gemm(a, b, out=out, **kw)              # warm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -59,6 +67,7 @@ def main():
                 torch.cuda.synchronize()
                 best[t] = min(best[t], e0.elapsed_time(e1) / 3)
         lib().call("molly_gemm_force_tile", 0)
+        lib().call("molly_gemm_set_persistent_blocks", 256)
         fl = 2.0 * m * n * k
         print(f"{name:16s} {form:4s} {m:7d} {n:7d} {k:7d} " + " ".join(f"{fl / (best[t] * 1e-3) / 1e12:12.1f}" for t in args.tiles))
         del a, b, out
