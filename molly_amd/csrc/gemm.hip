@@ -47,13 +47,18 @@ __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, i
     const int r_in = lane / CPR;
     // swizzle on the SOURCE chunk: BK=64: ch ^ (row&7) ; BK=32: ch ^ ((row>>2)&3)   (row = inst*RPI + r_in)
     const int c_src = BK == 64 ? ((lane & 7) ^ r_in) : ((lane & 3) ^ ((r_in >> 2) & 3));
+    // address = wave-uniform 64-bit base (tile row 0, K offset: SGPRs) + one 32-bit per-lane byte offset: the K advance
+    // of the main loop then lives in scalar registers and each LDS-DMA costs ONE address VGPR
+    const int r0 = row0 < rows_total ? row0 : rows_total - 1;   // a half-tile may start past the last row
+    const char* base = reinterpret_cast<const char*>(g + (size_t)r0 * ld + k0);
+    const int last = rows_total - 1 - r0;         // clamp: OOB rows re-read a valid row, masked at store
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int inst = wave * PER + i;
-        int row = row0 + inst * RPI + r_in;
-        row = row < rows_total ? row : rows_total - 1;     // clamp: OOB rows re-read a valid row, masked at store
-        const bf16_t* src = g + (size_t)row * ld + k0 + c_src * 8;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+        int rel = inst * RPI + r_in;
+        rel = rel < last ? rel : last;
+        const unsigned off = ((unsigned)rel * (unsigned)ld + (unsigned)(c_src * 8)) * 2u;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
     }
 }
 
@@ -74,6 +79,11 @@ __device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, i
     constexpr int NCB = COLS / 16;
     constexpr int NINST = BK * COLS * 2 / 1024;   // 1 KiB per wave-instruction = 8 blocks
     constexpr int PER = NINST / NW;
+    const int c0 = col0 <= cols_total - 8 ? col0 : cols_total - 8;     // a half-tile may start past the last column
+    const int last = cols_total - 8 - c0;         // clamp: OOB columns duplicate valid data, masked at store
+    const bool full = k0 + BK <= k_total;         // wave-uniform: every K-tile but a ragged last one
+    // full K-tile: wave-uniform 64-bit base + one 32-bit per-lane byte offset (see stage_kc)
+    const char* base = reinterpret_cast<const char*>(g + (size_t)k0 * ld + c0);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int inst = wave * PER + i;
@@ -81,11 +91,15 @@ __device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, i
         const int blk = P >> 3, cin = P & 7;
         const int kblk = blk / NCB, cbs = blk % NCB;
         const int kr = kblk * 4 + (cin >> 1);
-        int col = col0 + ((cbs ^ ((kblk >> 1) & 1)) << 4) + ((cin & 1) << 3);
-        col = col <= cols_total - 8 ? col : cols_total - 8;  // clamp: OOB columns duplicate valid data, masked at store
-        const int k = k0 + kr;
-        const bf16_t* src = (k < k_total) ? g + (size_t)k * ld + col : zeros;   // rows past K contribute exact zeros
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+        int rel = col0 - c0 + ((cbs ^ ((kblk >> 1) & 1)) << 4) + ((cin & 1) << 3);
+        rel = rel < last ? rel : last;
+        const unsigned off = ((unsigned)kr * (unsigned)ld + (unsigned)rel) * 2u;
+        if (full) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+        } else {
+            const char* src = (k0 + kr < k_total) ? base + off : reinterpret_cast<const char*>(zeros);   // rows past K: exact zeros
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+        }
     }
 }
 
@@ -630,6 +644,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             a2 = true;
         }
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
+
         // persistent: at most g_persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
         const int grid = g_persist_blocks > 0 ? min(nwork, g_persist_blocks) : nwork;

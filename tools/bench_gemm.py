@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--tiles", type=int, nargs="+", default=[128, 256])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--torch", action="store_true", help="add a torch.matmul (hipBLASLt/rocBLAS) column for orientation")
     ap.add_argument("--persist", type=int, nargs="+", default=None,
                     help="compare resident-block counts of the persistent 256x256 kernel (0 = one block per tile)")
     args = ap.parse_args()
@@ -69,7 +70,22 @@ def main():
         lib().call("molly_gemm_force_tile", 0)
         lib().call("molly_gemm_set_persistent_blocks", 256)
         fl = 2.0 * m * n * k
-        print(f"{name:16s} {form:4s} {m:7d} {n:7d} {k:7d} " + " ".join(f"{fl / (best[t] * 1e-3) / 1e12:12.1f}" for t in args.tiles))
+        tcol = ""
+        if args.torch:
+            ta = a.t() if form == "tn" else a
+            tb = b.t() if form == "nt" else b
+            tbest = 1e9
+            for r in range(args.rounds):
+                torch.matmul(ta, tb, out=out)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    torch.matmul(ta, tb, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                tbest = min(tbest, e0.elapsed_time(e1) / 3)
+            tcol = f"   torch {fl / (tbest * 1e-3) / 1e12:8.1f}"
+        print(f"{name:16s} {form:4s} {m:7d} {n:7d} {k:7d} " + " ".join(f"{fl / (best[t] * 1e-3) / 1e12:12.1f}" for t in args.tiles) + tcol)
         del a, b, out
 
 
