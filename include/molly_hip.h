@@ -166,6 +166,17 @@ int molly_attn_decode(void* stream, const void* q, const void* kcache, const voi
                       const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim, int ldq, float scale);
 
 /* ------------------------------------------------------------------------------------------------
+ * LoRA branch  y = W x + (alpha/r) * B (A dropout(x))  — PEFT lora.Linear.forward as the reference configures it
+ * (src/utils/tools.py:379-389: r = --lora_r, lora_alpha 64, lora_dropout 0.05).  The rank-r contractions are
+ * molly_gemm_bf16 calls; these are the HBM-bound parts.
+ * dropout: out[i] = keep_i ? x[i] / (1-p) : 0 with keep_i a pure function of (seed, i) (Philox4x32-10), so the backward
+ * regenerates the mask from the seed instead of storing it.  n % 8 == 0.  In place (out == x) is allowed.
+ * accumulate != 0: out[i] += dropped value (the branch's contribution to d(x): the same mask applied to the gradient). */
+int molly_dropout_bf16(void* stream, const void* x, void* out, long n, float p, uint64_t seed, int accumulate);
+/* x[i] *= s (bf16, rounds once): the alpha/r scaling of the rank-r intermediate and of its gradient. */
+int molly_scale_bf16(void* stream, void* x, long n, float s);
+
+/* ------------------------------------------------------------------------------------------------
  * layout / instruction probes (used by tests/test_gpu_probes.py to pin the gfx950 operand maps the
  * kernels rely on; not part of the product path) */
 int molly_probe_mfma16(void* stream, const void* A16x32, const void* B16x32, float* D16x16);

@@ -22,7 +22,8 @@ import torch.nn as nn
 from . import ops
 from .config import EncConfig, LlmConfig, OmicsModalConfig
 from .esm import EsmEngine
-from .params import FlatBuffer, enc_param_specs, is_no_decay, trainable_specs
+from .params import (FlatBuffer, enc_param_specs, is_no_decay, llm_norm_specs, llm_param_specs, projector_specs,
+                     trainable_specs)
 from .qwen3 import Qwen3Engine
 
 BF16 = torch.bfloat16
@@ -247,24 +248,53 @@ class OmicsOne(nn.Module):
 
     # ---- runtime --------------------------------------------------------------------------------------------
     def prepare(self, device="cuda", train_llm=True, train_mlp=True, ce_chunk_rows=16384, rope_table_dtype=BF16,
-                random_init_seed: Optional[int] = None):
-        """Re-home all tensors into flat bf16 HBM buffers and build the HIP engines.  Trainable group = LLM + projectors
-        (reference default `--train-llm --train-mlp`, encoders frozen: src/utils/tools.py:313-338)."""
+                random_init_seed: Optional[int] = None, lora=None):
+        """Re-home all tensors into flat bf16 HBM buffers and build the HIP engines.
+
+        Trainable group (what `rt.P` / `rt.G` / `n_decay` describe and the ZeRO-2 optimizer steps) — reference
+        src/utils/tools.py:313-338 (`set_up_trainable_param`) and :345-396 (`pre_train_lora`):
+          train_llm                      -> the whole LLM + the projectors (reference default `--train-llm --train-mlp`)
+          lora=LoraConfig (`--use-lora`) -> rank-r adapters on every LLM Linear except lm_head + the projectors; base frozen
+          train_mlp only                 -> the two projectors; the LLM is frozen (backward only propagates through it)
+          neither                        -> nothing (inference)
+        The encoders are always frozen buffers (`--train-bio` is SURVEY.md §8f-4)."""
         assert self.model is not None and self.dna_rna_model is not None and self.protein_model is not None, \
             "attach .model / .dna_rna_model / .protein_model first (reference: src/train.py:127,143,152)"
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("molly_amd.OmicsOne runs on the GPU only; the CPU oracle lives in /oracle (tests only)")
+        if train_llm and lora is not None:
+            raise ValueError("lora and train_llm are exclusive: the reference freezes the base under --use-lora")
+        if train_llm and not train_mlp:
+            raise NotImplementedError("--train-llm without --train-mlp (frozen projectors inside the LLM's flat group)")
         sd = self.state_dict()
-        decay, no_decay = trainable_specs(self.text_config, self.dna_rna_config, self.protein_config)
-        P = FlatBuffer(decay + no_decay, dev, pad_to=8 * 64)
-        self.n_decay = P.offsets[no_decay[0][0]]
+        pw, pb = projector_specs(self.text_config, self.dna_rna_config, self.protein_config)
+        full = bool(train_llm)
+        adapters = (lora is not None) or (train_mlp and not train_llm)
+        Q = None
+        if full or not adapters:
+            decay, no_decay = trainable_specs(self.text_config, self.dna_rna_config, self.protein_config)
+            base = FlatBuffer(decay + no_decay, dev, pad_to=8 * 64)
+            n_decay = base.offsets[no_decay[0][0]]
+        else:
+            # frozen LLM in one buffer, the small trainable group (adapters + projectors) in another
+            base = FlatBuffer(llm_param_specs(self.text_config) + llm_norm_specs(self.text_config), dev)
+            q_decay = pw
+            if lora is not None:
+                from .lora import lora_specs
+                q_decay = lora_specs(self.text_config, lora) + pw
+            Q = FlatBuffer(q_decay + pb, dev, pad_to=8 * 64)
+            n_decay = Q.offsets[pb[0][0]]
+        self.n_decay = n_decay
         enc = {}
         for pre, cfg in (("dna_rna_model.", self.dna_rna_config), ("protein_model.", self.protein_config)):
             enc[pre] = FlatBuffer(enc_param_specs(cfg, pre), dev)
         gen = None
-        for buf in [P] + list(enc.values()):
+        bufs = [base] + ([Q] if Q is not None else []) + list(enc.values())
+        for buf in bufs:
             for n, v in buf.views.items():
+                if ".lora_" in n:
+                    continue                                  # adapters are initialised below
                 src = sd[n]
                 if src.is_meta:
                     # un-materialised shell (== the reference's --no-load-pretrained, src/train.py:107-116):
@@ -282,9 +312,10 @@ class OmicsOne(nn.Module):
                 else:
                     v.copy_(src.to(dev))
         # re-point module parameters at the flat views (so state_dict()/save keep working and see updates)
+        trainable_bufs = [base] if full else ([Q] if Q is not None else [])
         with torch.no_grad():
             named = dict(self.named_parameters(remove_duplicate=False))
-            for buf in [P] + list(enc.values()):
+            for buf in bufs:
                 for n, v in buf.views.items():
                     if n not in named:
                         continue
@@ -292,18 +323,33 @@ class OmicsOne(nn.Module):
                     *path, leaf = n.split(".")
                     for k in path:
                         mod = mod[int(k)] if k.isdigit() else getattr(mod, k)
-                    setattr(mod, leaf, nn.Parameter(v, requires_grad=named[n].requires_grad and buf is P))
+                    setattr(mod, leaf, nn.Parameter(v, requires_grad=named[n].requires_grad and
+                                                    any(buf is tb for tb in trainable_bufs)))
             if self.text_config.tie_word_embeddings:
                 self.model.lm_head.weight = self.model.model.embed_tokens.weight
-        G = P.like() if (train_llm or train_mlp) else None
         rt = type("Runtime", (), {})()
-        rt.dev, rt.P, rt.G, rt.enc = dev, P, G, enc
-        rt.llm = Qwen3Engine(self.text_config, P, G, dev, ce_chunk_rows=ce_chunk_rows, rope_table_dtype=rope_table_dtype)
+        rt.dev, rt.base, rt.enc = dev, base, enc
+        rt.full, rt.train_llm, rt.train_mlp = full, bool(train_llm), bool(train_mlp or lora is not None)
+        if full:
+            rt.P, rt.G = base, base.like()
+        elif Q is not None:
+            rt.P, rt.G = Q, Q.like()
+        else:
+            rt.P, rt.G = base, None
+        rt.W = dict(base.views)                               # name -> weight view, whichever buffer owns it
+        if Q is not None:
+            rt.W.update(Q.views)
+        lora_rt = None
+        if lora is not None:
+            from .lora import LoraRuntime
+            lora_rt = LoraRuntime(self.text_config, lora, Q, rt.G)
+            if gen is None:
+                gen = torch.Generator(device=dev).manual_seed(1234 if random_init_seed is None else random_init_seed)
+            lora_rt.init_gaussian(gen)
+        rt.llm = Qwen3Engine(self.text_config, base, rt.G if full else None, dev, ce_chunk_rows=ce_chunk_rows,
+                             rope_table_dtype=rope_table_dtype, lora=lora_rt, backward=rt.G is not None)
         rt.dna = EsmEngine(self.dna_rna_config, enc["dna_rna_model."], dev, "dna_rna_model.", rope_table_dtype)
         rt.prot = EsmEngine(self.protein_config, enc["protein_model."], dev, "protein_model.", rope_table_dtype)
-        rt.train_llm, rt.train_mlp = train_llm, train_mlp
-        if G is not None:
-            rt.llm.refresh_transposed_weights()
         self._rt = rt
         return self
 
@@ -342,7 +388,7 @@ class OmicsOne(nn.Module):
                     enc_out = eng.forward(ids.to(rt.dev, non_blocking=True))
                 except Exception as e:  # reference re-wraps encoder failures (omics_one.py:89-90)
                     raise RuntimeError(f"Error processing omic sequences: {e}")
-                emb = ops.gemm_nt(enc_out, rt.P.views[proj + ".weight"], bias=rt.P.views[proj + ".bias"])
+                emb = ops.gemm_nt(enc_out, rt.W[proj + ".weight"], bias=rt.W[proj + ".bias"])
                 dst_dev = dst.to(rt.dev, non_blocking=True)
                 ops.copy_rows(emb, hs, emb.shape[0], dst_idx32=dst_dev)
                 valid = dst.numpy() >= 0
@@ -371,9 +417,11 @@ class OmicsOne(nn.Module):
         """Wire a Zero2Optimizer's overlap hooks into the engines (no-ops when the optimizer does not overlap)."""
         rt = self._runtime()
         rt.opt = opt
-        opt.hooked = True
-        rt.llm.grads_final_hook = opt.on_grads_final
-        rt.llm.wait_params_hook = opt.wait_params
+        if rt.full:
+            # per-layer overlap: flat offsets of the optimizer's group ARE the LLM's parameter offsets
+            opt.hooked = True
+            rt.llm.grads_final_hook = opt.on_grads_final
+            rt.llm.wait_params_hook = opt.wait_params
 
     def forward_backward(self, input_ids, attention_mask, omic_ids, omic_info_list, labels, accumulate=False,
                          final_micro=True):
@@ -384,7 +432,11 @@ class OmicsOne(nn.Module):
         B, T = input_ids.shape
         M = B * T
         opt = getattr(rt, "opt", None)
-        if opt is not None:
+        if rt.G is None:
+            raise RuntimeError("forward_backward: nothing is trainable (prepare(train_llm/train_mlp/lora))")
+        if opt is not None and not rt.full:
+            opt.wait_all_params()                 # small adapter/projector group: no per-layer overlap
+        elif opt is not None:
             # parameters read before the decoder layers: gains/biases (tail region), projectors, embedding (= tied head)
             opt.wait_params(self.n_decay, rt.P.numel)
             opt.wait_params(0, rt.llm.layer_lo[0])
@@ -438,7 +490,7 @@ class OmicsOne(nn.Module):
                 enc_out = eng.forward(ids.to(rt.dev))
             except Exception as e:
                 raise RuntimeError(f"Error processing omic sequences: {e}")
-            emb = ops.gemm_nt(enc_out, rt.P.views[proj + ".weight"], bias=rt.P.views[proj + ".bias"])
+            emb = ops.gemm_nt(enc_out, rt.W[proj + ".weight"], bias=rt.W[proj + ".bias"])
             ops.copy_rows(emb, flat, emb.shape[0], dst_idx32=dst.to(rt.dev))
         return hidden_states
 

@@ -250,3 +250,22 @@ def attn_decode(q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, scal
     lib().call("molly_attn_decode", _stream(), q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, q.stride(0),
                float(scale))
     return out
+
+
+def dropout(x, p: float, seed: int, out=None, accumulate=False):
+    """out (+)= x * keep / (1-p), keep a pure function of (seed, element index)."""
+    _chk(x, BF16, "x")
+    assert x.is_contiguous()
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.numel() == x.numel()
+    lib().call("molly_dropout_bf16", _stream(), x, out, x.numel(), float(p), int(seed) & ((1 << 64) - 1), int(accumulate))
+    return out
+
+
+def scale_(x, s: float):
+    _chk(x, BF16, "x")
+    assert x.is_contiguous()
+    lib().call("molly_scale_bf16", _stream(), x, x.numel(), float(s))
+    return x

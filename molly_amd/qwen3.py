@@ -19,6 +19,7 @@ import torch
 
 from . import ops
 from .config import LlmConfig
+from .lora import TARGETS as LORA_TARGETS
 from .params import FlatBuffer
 
 BF16 = torch.bfloat16
@@ -39,8 +40,14 @@ def rope_tables(n_pos: int, head_dim: int, theta: float, device, table_dtype=BF1
 
 class Qwen3Engine:
     def __init__(self, cfg: LlmConfig, params: FlatBuffer, grads: Optional[FlatBuffer], device, prefix: str = "model.",
-                 ce_chunk_rows: int = 16384, rope_table_dtype=BF16):
+                 ce_chunk_rows: int = 16384, rope_table_dtype=BF16, lora=None, backward: Optional[bool] = None):
+        """grads: flat gradient buffer of the base weights (None = base frozen: the backward then only propagates to the
+        inputs and to the adapters).  lora: a `LoraRuntime` (molly_amd.lora) or None.  backward: build the backward at all
+        (default: when anything upstream or inside is trainable, i.e. grads or lora given)."""
         self.cfg, self.P, self.G, self.dev, self.pre = cfg, params, grads, device, prefix
+        self.lora = lora
+        self.train_base = grads is not None
+        self.has_backward = (grads is not None or lora is not None) if backward is None else backward
         self.h, self.hd = cfg.hidden_size, cfg.head_dim
         self.nh, self.nkv, self.ff, self.V, self.L = (cfg.num_attention_heads, cfg.num_key_value_heads,
                                                       cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers)
@@ -97,6 +104,12 @@ class Qwen3Engine:
         for _ in range(nl):
             self.A.append(dict(x=e(M, h), xn=e(M, h), qkv=e(M, self.nqkv), qk=e(M, self.nqk), attn=e(M, self.nh * self.hd),
                                lse=e(B, self.nh, T, dt=torch.float32), x2=e(M, h), xn2=e(M, h), gu=e(M, 2 * ff), act=e(M, ff)))
+            if self.lora is not None:
+                # s * (dropout(x) A^T) of every target, kept for the adapter gradients
+                self.A[-1]["lt"] = {m: e(M, self.lora.rp) for m in LORA_TARGETS}
+        if self.lora is not None:
+            self.lora_xd = e(M * max(h, ff, self.nh * self.hd))       # dropout(x) of the target being processed
+            self.lora_dt = e(M, self.lora.rp)
         self.x_out = e(M, h)
         self.hn = e(M, h)
         self.C = min(self.ce_chunk_rows, M)
@@ -111,6 +124,8 @@ class Qwen3Engine:
             self.delta = e(B, self.nh, T, dt=torch.float32)
             self.hn_s = e(M, h); self.dh_s = e(M, h)                       # compacted scored rows (head GEMMs)
             self.tT = e(max(h, self.nh * self.hd) * M)                     # transposed narrow operand of the wgrad GEMMs
+            if not self.train_base:
+                self.junk = torch.zeros(max(h, 2 * self.hd), dtype=BF16, device=dev)   # gain gradients nobody reads
             # split-K scratch for the wgrad GEMMs: 8 slabs of the largest per-layer weight
             ops.ensure_gemm_workspace(8 * 4 * max(2 * ff * h, self.nqkv * h), dev)
             nb1 = ops.lib().query("molly_rmsnorm_bwd_blocks", M)
@@ -130,6 +145,8 @@ class Qwen3Engine:
         cfg, M = self.cfg, B * T
         self.reserve(M, B, T, training)
         self.B_, self.T_, self.kv = B, T, (kv_lo, kv_hi)
+        if self.lora is not None and training:
+            self.lora.step += 1                           # a fresh dropout stream per training forward
         x = inputs_embeds
         for i in range(self.L):
             a = self.A[i if training else 0]
@@ -143,16 +160,28 @@ class Qwen3Engine:
                 xin = x
             ops.rmsnorm_fwd(xin, w["ln1"], cfg.rms_norm_eps, out=a["xn"])
             ops.gemm_nt(a["xn"], w["qkv"], out=a["qkv"])
+            if self.lora is not None:
+                nq_, nk_ = self.nh * self.hd, self.nkv * self.hd
+                self._lora_fwd(i, a, "q_proj", a["xn"], a["qkv"][:, :nq_], training)
+                self._lora_fwd(i, a, "k_proj", a["xn"], a["qkv"][:, nq_:nq_ + nk_], training)
+                self._lora_fwd(i, a, "v_proj", a["xn"], a["qkv"][:, nq_ + nk_:], training)
             ops.norm_rope_fwd(a["qkv"], a["qk"], self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos, self.sin,
                               eps=cfg.rms_norm_eps)
             ops.attn_fwd(a["qk"][:, :self.nh * self.hd], a["qk"][:, self.nh * self.hd:], a["qkv"][:, self.nqk:], B, T,
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, kv_lo, kv_hi, out=a["attn"], lse=a["lse"])
             ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=xin)
+            if self.lora is not None:
+                self._lora_fwd(i, a, "o_proj", a["attn"], a["x2"], training)
             ops.rmsnorm_fwd(a["x2"], w["ln2"], cfg.rms_norm_eps, out=a["xn2"])
             ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
+            if self.lora is not None:
+                self._lora_fwd(i, a, "gate_proj", a["xn2"], a["gu"][:, :self.ff], training)
+                self._lora_fwd(i, a, "up_proj", a["xn2"], a["gu"][:, self.ff:], training)
             ops.swiglu_fwd(a["gu"], out=a["act"])
             nxt = self.A[i + 1]["x"] if (training and i + 1 < self.L) else self.x_out
             ops.gemm_nt(a["act"], w["down"], out=nxt, res=a["x2"])
+            if self.lora is not None:
+                self._lora_fwd(i, a, "down_proj", a["act"], nxt, training)
             x = nxt
         ops.rmsnorm_fwd(self.x_out, self.norm_w, cfg.rms_norm_eps, out=self.hn)
         loss = None
@@ -166,7 +195,7 @@ class Qwen3Engine:
             self.labels = labels_shifted
             self.scored_rows = scored_rows
             ops.count_valid(labels_shifted, self.scal[0:1], self.scal[1:2])
-            if not (training and self.G is not None):
+            if not (training and self.has_backward):
                 # loss only (eval): logits chunk by chunk, no gradient written
                 for c0 in range(0, M, self.C):
                     c1 = min(M, c0 + self.C)
@@ -176,6 +205,40 @@ class Qwen3Engine:
                 ops.sum_f32(self.row_loss[:M], self.scal[2:3], scale=self.scal[0:1])
                 loss = self.scal[2]
         return loss, logits_all
+
+    # ---- LoRA branch (PEFT lora.Linear.forward: result + lora_B(lora_A(dropout(x))) * scaling) --------------------
+    def _lora_xd(self, i: int, mod: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+        lo = self.lora
+        if not (training and lo.p > 0.0):
+            return x
+        xd = self.lora_xd[:x.numel()].view(x.shape)
+        return ops.dropout(x, lo.p, lo.mask_seed(i, mod), out=xd)
+
+    def _lora_fwd(self, i: int, a: dict, mod: str, x: torch.Tensor, y: torch.Tensor, training: bool):
+        """y += s * (dropout(x) A^T) B^T; keeps t = s * dropout(x) A^T for the backward."""
+        lo = self.lora
+        t = a["lt"][mod]
+        ops.gemm_nt(self._lora_xd(i, mod, x, training), lo.A[i][mod], out=t)
+        if lo.scale != 1.0:
+            ops.scale_(t, lo.scale)
+        ops.gemm_nt(t, lo.B[i][mod], out=y, accumulate=True)
+
+    def _lora_bwd(self, i: int, a: dict, mod: str, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool):
+        """dB (+)= dy^T t ; dt = s * dy B ; dA (+)= dt^T dropout(x) ; dx += mask * (dt A)."""
+        lo = self.lora
+        self._wgrad(dy, a["lt"][mod], lo.dB[i][mod], accumulate)
+        dt = self.lora_dt
+        self._dgrad(dy, lo.B[i][mod], dt)
+        if lo.scale != 1.0:
+            ops.scale_(dt, lo.scale)
+        xd = self._lora_xd(i, mod, x, True)
+        self._wgrad(dt, xd, lo.dA[i][mod], accumulate)
+        if lo.p > 0.0:
+            tmp = self.lora_xd[:x.numel()].view(x.shape)           # dropout(x) is dead after the dA GEMM
+            ops.gemm(dt, lo.A[i][mod], out=tmp, b_kmajor=True)
+            ops.dropout(tmp, lo.p, lo.mask_seed(i, mod), out=dx, accumulate=True)
+        else:
+            ops.gemm(dt, lo.A[i][mod], out=dx, accumulate=True, b_kmajor=True)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
@@ -227,6 +290,7 @@ class Qwen3Engine:
         else:
             src_hn, src_lab, n_rows, dh_s = self.hn, self.labels, M, dh
         first = True
+        tb = self.train_base
         for c0 in range(0, n_rows, self.C):
             c1 = min(n_rows, c0 + self.C)
             n = c1 - c0
@@ -234,49 +298,72 @@ class Qwen3Engine:
             ops.gemm_nt(src_hn[c0:c1], self.head, out=lg)
             ops.ce_fwd_bwd(lg, src_lab[c0:c1], self.row_loss[c0:c1], self.scal[0:1], write_grad=True)
             self._dgrad(lg, self.head, dh_s[c0:c1])                                   # d(hn) = dlogits · E
-            # dE (+)= dlogits^T · hn   (tied embeddings: the gather-gradient is added later by the caller)
-            self._wgrad(lg, src_hn[c0:c1], self.d_head, accumulate or not first)
+            if tb:
+                # dE (+)= dlogits^T · hn   (tied embeddings: the gather-gradient is added later by the caller)
+                self._wgrad(lg, src_hn[c0:c1], self.d_head, accumulate or not first)
             first = False
         if rows is not None:
             ops.copy_rows(dh_s, dh, n_rows, dst_idx32=rows)
             if n_rows == 0:
                 self.row_loss[:1].zero_()
-                if not accumulate:
+                if tb and not accumulate:
                     self.d_head.zero_()
         M_loss = n_rows
         ops.sum_f32(self.row_loss[:max(M_loss, 1)], self.scal[2:3], scale=self.scal[0:1])
+        # frozen base: gain gradients go to a scratch nobody reads (the kernels always produce them)
+        junk = None if tb else self.junk
+        gw = (lambda g, k: g[k]) if tb else (lambda g, k: junk[:self.hd] if k == "qn" else
+                                             (junk[self.hd:2 * self.hd] if k == "kn" else junk[:self.h]))
+        lora = self.lora
         # final norm backward
         dx = self.d_b
-        ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, self.d_norm_w, cfg.rms_norm_eps, dx=dx, dw_accumulate=accumulate,
-                        workspace=self.ws)
+        ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, self.d_norm_w if tb else junk[:self.h], cfg.rms_norm_eps, dx=dx,
+                        dw_accumulate=accumulate and tb, workspace=self.ws)
         spare = [self.d_a, self.d_c]
+        acc_n = accumulate and tb
+        nq, nk_ = self.nh * self.hd, self.nkv * self.hd
         for i in reversed(range(self.L)):
-            a, w, g = self.A[i], self.W[i], self.dW[i]
+            a, w = self.A[i], self.W[i]
+            g = self.dW[i] if tb else None
             # ---- MLP: x3 = x2 + down(silu(g)*u)
             self._dgrad(dx, w["down"], self.d_act)
-            self._wgrad(dx, a["act"], g["down"], accumulate)
+            if lora is not None:
+                self._lora_bwd(i, a, "down_proj", a["act"], dx, self.d_act, accumulate)
+            if tb:
+                self._wgrad(dx, a["act"], g["down"], accumulate)
             ops.swiglu_bwd(a["gu"], self.d_act, self.d_gu)
             dxn2 = spare[0]
             self._dgrad(self.d_gu, w["gu"], dxn2)
-            self._wgrad(self.d_gu, a["xn2"], g["gu"], accumulate)
+            if lora is not None:
+                self._lora_bwd(i, a, "gate_proj", a["xn2"], self.d_gu[:, :self.ff], dxn2, accumulate)
+                self._lora_bwd(i, a, "up_proj", a["xn2"], self.d_gu[:, self.ff:], dxn2, accumulate)
+            if tb:
+                self._wgrad(self.d_gu, a["xn2"], g["gu"], accumulate)
             dx2 = spare[1]
-            ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, g["ln2"], cfg.rms_norm_eps, dres=dx, dx=dx2,
-                            dw_accumulate=accumulate, workspace=self.ws)
+            ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, gw(g, "ln2"), cfg.rms_norm_eps, dres=dx, dx=dx2,
+                            dw_accumulate=acc_n, workspace=self.ws)
             # ---- attention: x2 = x + o_proj(attn)
             self._dgrad(dx2, w["o"], self.d_attn)
-            self._wgrad(dx2, a["attn"], g["o"], accumulate)
-            nq = self.nh * self.hd
+            if lora is not None:
+                self._lora_bwd(i, a, "o_proj", a["attn"], dx2, self.d_attn, accumulate)
+            if tb:
+                self._wgrad(dx2, a["attn"], g["o"], accumulate)
             ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
                          self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta)
             ops.norm_rope_bwd(a["qkv"], self.d_qk, self.d_qkv, self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos,
-                              self.sin, g["qn"], g["kn"], eps=cfg.rms_norm_eps, dw_accumulate=accumulate,
+                              self.sin, gw(g, "qn"), gw(g, "kn"), eps=cfg.rms_norm_eps, dw_accumulate=acc_n,
                               workspace=self.ws)
             dxn = spare[0]
             self._dgrad(self.d_qkv, w["qkv"], dxn)
-            self._wgrad(self.d_qkv, a["xn"], g["qkv"], accumulate)
-            ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, g["ln1"], cfg.rms_norm_eps, dres=dx2, dx=dx,
-                            dw_accumulate=accumulate, workspace=self.ws)
-            if final_micro and self.grads_final_hook is not None:
+            if lora is not None:
+                self._lora_bwd(i, a, "q_proj", a["xn"], self.d_qkv[:, :nq], dxn, accumulate)
+                self._lora_bwd(i, a, "k_proj", a["xn"], self.d_qkv[:, nq:nq + nk_], dxn, accumulate)
+                self._lora_bwd(i, a, "v_proj", a["xn"], self.d_qkv[:, nq + nk_:], dxn, accumulate)
+            if tb:
+                self._wgrad(self.d_qkv, a["xn"], g["qkv"], accumulate)
+            ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, gw(g, "ln1"), cfg.rms_norm_eps, dres=dx2, dx=dx,
+                            dw_accumulate=acc_n, workspace=self.ws)
+            if tb and final_micro and self.grads_final_hook is not None:
                 self.grads_final_hook(self.layer_lo[i], self.layers_hi)       # matrices of layers i..L-1 are final
         return dx

@@ -46,7 +46,8 @@ def main(argv=None):
                  ("--eval-max-len", 1024), ("--eval-max-src-len", 1024), ("--per_device_train_batch_size", 1),
                  ("--per_device_eval_batch_size", 1), ("--read-nums", 0), ("--eval-read-nums", 0), ("--save_steps", 0),
                  ("--eval_steps", 0), ("--logging_steps", 20), ("--gradient-accumulation-steps", 1), ("--save-total-limit", 0),
-                 ("--early-stopping-patience", 0), ("--seed", 42), ("--train-iters", -1), ("--local_rank", 0)]:
+                 ("--early-stopping-patience", 0), ("--seed", 42), ("--train-iters", -1), ("--local_rank", 0),
+                 ("--lora_r", 64)]:
         ap.add_argument(f, type=int, default=d)
     for f, d in [("--num_train_epochs", 1.0), ("--learning_rate", 3e-5), ("--warmup_ratio", 0.1), ("--weight-decay", 1e-2),
                  ("--eps", 1e-8)]:
@@ -57,8 +58,12 @@ def main(argv=None):
     a = ap.parse_args(argv)
     if a.train_bio:
         raise NotImplementedError("--train-bio (encoder backward) is not built yet: SURVEY.md §8f-4")
+    lora = None
     if a.use_lora:
-        raise NotImplementedError("--use-lora is not built yet: SURVEY.md §8f-1")
+        # reference src/train.py:654-657 -> pre_train_lora (src/utils/tools.py:345-396): base + encoders frozen, adapters on
+        # every LLM Linear but lm_head, projectors trainable whatever --train-mlp says
+        from .lora import LoraConfig
+        lora = LoraConfig(r=a.lora_r, lora_alpha=64.0, lora_dropout=0.05, seed=a.seed)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,7 +91,8 @@ def main(argv=None):
             if not os.path.exists(f):
                 raise FileNotFoundError(f"{f}: no weights; pass --no-load-pretrained for random init")
             sub.load_state_dict(torch.load(f, map_location="cpu"), strict=False, assign=True)
-    m.prepare(torch.device("cuda", local), train_llm=a.train_llm, train_mlp=a.train_mlp, random_init_seed=1234)
+    m.prepare(torch.device("cuda", local), train_llm=a.train_llm and lora is None, train_mlp=a.train_mlp or lora is not None,
+              random_init_seed=1234, lora=lora)
     # tokenizers: the real ones need vocab files (none offline) -> the deterministic stand-ins of molly_amd.data
     dcfg = DatasetConfig(max_len=a.max_len, max_src_len=a.max_src_len, mode=a.mode, cal_metric_pos=None,
                          dna_rna_k_tokens=a.dna_rna_k_tokens, protein_k_tokens=a.protein_k_tokens)

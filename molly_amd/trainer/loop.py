@@ -51,8 +51,13 @@ class TrainArgs:
 
 
 def save_model(model, output_dir: str):
-    """reference: OmicsTrainer.save_model -> `pytorch_model.bin` with the reference's keys."""
+    """reference: OmicsTrainer.save_model (src/trainer/omics_trainer.py:85-105): under LoRA the PEFT adapter + the two
+    projector .bin files; otherwise `pytorch_model.bin` with the reference's keys."""
     os.makedirs(output_dir, exist_ok=True)
+    if model._runtime().llm.lora is not None:
+        from ..lora import save_adapter
+        save_adapter(model, output_dir)
+        return
     sd = {k: v.detach().to("cpu").clone() for k, v in model.state_dict().items()}
     torch.save(sd, os.path.join(output_dir, "pytorch_model.bin"))
     # the projectors on their own as well (what the LoRA branch of the reference writes and inference_lora.py reads)
