@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--k-protein", type=int, default=512)
     ap.add_argument("--model", default="1.7b")
+    ap.add_argument("--train-mode", choices=("full", "lora", "mlp"), default="full",
+                    help="full = headline (--train-llm --train-mlp); lora = --use-lora r=64; mlp = projectors only (side figures)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", nargs=3, type=int, metavar=("LLM_LAYERS", "ENC_LAYERS", "THREADS"))
     args = ap.parse_args()
@@ -156,7 +158,12 @@ def main():
     m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
     m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
     torch.manual_seed(1234)
-    m.prepare(dev, random_init_seed=1234)              # same seed on every rank: replicas start identical
+    if args.train_mode == "full":
+        m.prepare(dev, random_init_seed=1234)          # same seed on every rank: replicas start identical
+    else:
+        from molly_amd.lora import LoraConfig
+        m.prepare(dev, random_init_seed=1234, train_llm=False, train_mlp=True,
+                  lora=LoraConfig(r=64, lora_alpha=64, lora_dropout=0.05, seed=42) if args.train_mode == "lora" else None)
     rt = m._rt
     opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0)
     m.attach_optimizer(opt)
@@ -227,7 +234,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Molly-{args.model.upper()} (Qwen3-{args.model.upper()} + NT-500M + ESM2-650M) train step, "
                                    f"seq_len {T} text + {K}-residue protein span per sample, {B} samples/GPU, GA=1, "
-                                   f"LLM+projectors trainable, encoders frozen, ZeRO-2 dp{world}",
+                                   + {"full": "LLM+projectors trainable", "lora": "LoRA r=64 adapters+projectors trainable, base frozen",
+                                      "mlp": "projectors trainable, LLM frozen"}[args.train_mode] +
+                                   f", encoders frozen, ZeRO-2 dp{world}",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "scored_token_fraction": 0.25,
                        "note": "prompt = 75% of each sample with labels -100 (SURVEY 8d); lm_head+CE run on the scored rows only "

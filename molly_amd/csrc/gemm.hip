@@ -621,13 +621,22 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
         } else {
             const int nk = cdiv(p.K, 64);
             const bool plain_epilogue = !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_GELU | MOLLY_GEMM_RESIDUAL));
+            // "skinny": one side of the output is narrower than a tile (rank-r adapter GEMMs: N = r or M = r) and the
+            // 128x128 grid would leave CUs empty.  Such a problem is bound by streaming the big operand once, so what
+            // matters is blocks (and bytes in flight) on every CU: split K finer (>= 8 K-tiles per slice) and further.
+            const long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, BN);
+            const bool skinny = (p.M < 256 || p.N < 256) && p.M >= 64 && p.N >= 64 && t128 < 256;
+            const int min_kt = skinny ? 8 : 16;
             int best = 0;
-            for (int sp : {2, 3, 4, 6, 8}) {
-                if (nk / sp < 16) break;                                   // keep >= 1024-deep slices
+            double best_score = 0.0;
+            for (int sp : {2, 3, 4, 6, 8, 12, 16, 24, 32}) {
+                if (nk / sp < min_kt) break;                               // keep slices >= 1024 (skinny: 512) deep
                 if ((size_t)sp * p.M * p.N * sizeof(float) > g_ws_bytes) break;
                 if (t256 * sp >= 200 && eff(t256 * sp) >= 0.85) { best = sp; break; }
+                if (skinny && eff(t256 * sp) > best_score + 1e-9) { best_score = eff(t256 * sp); best = -sp; }
             }
-            if (best && plain_epilogue && p.N % 4 == 0 && p.M >= 256 && p.N >= 256) {
+            if (best < 0) best = skinny && best_score > eff(t128) ? -best : 0;   // nothing fills the chip: the fullest
+            if (best && plain_epilogue && p.N % 4 == 0 && ((p.M >= 256 && p.N >= 256) || skinny)) {
                 force_tile = 512;
                 p.splits = best;
                 p.ws = g_ws;

@@ -278,6 +278,25 @@ class ToyTextTokenizer:
                 out.extend(part.encode("utf-8"))
         return out
 
+    def decode(self, ids, skip_special_tokens=True):
+        inv = {v: k for k, v in self.special.items()}
+        out, run = [], bytearray()
+        for i in (int(x) for x in ids):
+            if i < 256:
+                run.append(i)
+                continue
+            if run:
+                out.append(run.decode("utf-8", errors="replace"))
+                run = bytearray()
+            if not skip_special_tokens and i in inv:
+                out.append(inv[i])
+        if run:
+            out.append(run.decode("utf-8", errors="replace"))
+        return "".join(out)
+
+    def batch_decode(self, batch, skip_special_tokens=True):
+        return [self.decode(row, skip_special_tokens) for row in (batch.tolist() if hasattr(batch, "tolist") else batch)]
+
 
 class ToyOmicTokenizer:
     """ESM-style stand-in: <cls> body <eos>? truncated/padded to max_length with pad id 1.

@@ -50,10 +50,16 @@ class GenerationSession:
         a = e.A[0]
         x = hs
         nq = e.nh * e.hd
+        nk_ = e.nkv * e.hd
+        if e.lora is not None:
+            self.lt = torch.empty(B * T, e.lora.rp, dtype=BF16, device=dev)
         for i in range(L):
             w = e.W[i]
             ops.rmsnorm_fwd(x, w["ln1"], e.cfg.rms_norm_eps, out=a["xn"])
             ops.gemm_nt(a["xn"], w["qkv"], out=a["qkv"])
+            self._lora(i, "q_proj", a["xn"], a["qkv"][:, :nq])
+            self._lora(i, "k_proj", a["xn"], a["qkv"][:, nq:nq + nk_])
+            self._lora(i, "v_proj", a["xn"], a["qkv"][:, nq + nk_:])
             ops.norm_rope_fwd(a["qkv"], a["qk"], e.nh, e.nkv, e.hd, T, w["qn"], w["kn"], self.cos, self.sin,
                               positions=positions, eps=e.cfg.rms_norm_eps)
             ops.copy_rows(a["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B * T, dst_idx32=rows)
@@ -61,15 +67,30 @@ class GenerationSession:
             ops.attn_fwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, e.nqk:], B, T, e.nh, e.nkv, e.hd, e.hd ** -0.5, True,
                          lo, hi, out=a["attn"], lse=False)
             ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=x)
+            self._lora(i, "o_proj", a["attn"], a["x2"])
             ops.rmsnorm_fwd(a["x2"], w["ln2"], e.cfg.rms_norm_eps, out=a["xn2"])
             ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
+            self._lora(i, "gate_proj", a["xn2"], a["gu"][:, :e.ff])
+            self._lora(i, "up_proj", a["xn2"], a["gu"][:, e.ff:])
             ops.swiglu_fwd(a["gu"], out=a["act"])
             ops.gemm_nt(a["act"], w["down"], out=e.x_out, res=a["x2"])
+            self._lora(i, "down_proj", a["act"], e.x_out)
             x = e.x_out
         last = x.view(B, T, e.h)[:, T - 1, :].contiguous()                    # left-padded prompts end at T-1
         self.cur_len = T
         self._alloc_step(B)
         return self._head(last)
+
+    def _lora(self, i, mod, x, y):
+        """live (un-merged) adapter: y += s * (x A^T) B^T, no dropout at inference (PEFT eval mode)."""
+        lo = self.eng.lora
+        if lo is None:
+            return
+        t = self.lt[:x.shape[0]]
+        ops.gemm_nt(x, lo.A[i][mod], out=t)
+        if lo.scale != 1.0:
+            ops.scale_(t, lo.scale)
+        ops.gemm_nt(t, lo.B[i][mod], out=y, accumulate=True)
 
     def _alloc_step(self, B):
         e, dev = self.eng, self.rt.dev
@@ -102,6 +123,9 @@ class GenerationSession:
             w = e.W[i]
             ops.rmsnorm_fwd(x, w["ln1"], e.cfg.rms_norm_eps, out=s["xn"])
             ops.gemm_nt(s["xn"], w["qkv"], out=s["qkv"])
+            self._lora(i, "q_proj", s["xn"], s["qkv"][:, :nq])
+            self._lora(i, "k_proj", s["xn"], s["qkv"][:, nq:nq + nkvd])
+            self._lora(i, "v_proj", s["xn"], s["qkv"][:, nq + nkvd:])
             ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin,
                               positions=positions, eps=e.cfg.rms_norm_eps)
             ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=slot)
@@ -109,10 +133,14 @@ class GenerationSession:
             ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
                             e.hd ** -0.5)
             ops.gemm_nt(s["attn"], w["o"], out=s["x2"], res=x)
+            self._lora(i, "o_proj", s["attn"], s["x2"])
             ops.rmsnorm_fwd(s["x2"], w["ln2"], e.cfg.rms_norm_eps, out=s["xn2"])
             ops.gemm_nt(s["xn2"], w["gu"], out=s["gu"])
+            self._lora(i, "gate_proj", s["xn2"], s["gu"][:, :e.ff])
+            self._lora(i, "up_proj", s["xn2"], s["gu"][:, e.ff:])
             ops.swiglu_fwd(s["gu"], out=s["act"])
             ops.gemm_nt(s["act"], w["down"], out=s["x"], res=s["x2"])
+            self._lora(i, "down_proj", s["act"], s["x"])
             x = s["x"]
         self.cur_len += 1
         return self._head(x)

@@ -98,6 +98,37 @@ class LoraRuntime:
         return ((self.seed & 0xffffffff) << 32) | ((self.step & 0xfffff) << 12) | (layer << 4) | TARGETS.index(mod)
 
 
+def load_live_adapter(model, path: str) -> int:
+    """Copy a PEFT LoRA checkpoint into the LIVE adapter of a model prepared with `lora=LoraConfig(...)` (continue training,
+    or un-merged inference); loads the projector .bin files if present.  Returns the number of target matrices."""
+    rt = model._runtime()
+    lo = rt.llm.lora
+    if lo is None:
+        raise RuntimeError("load_live_adapter: the model was prepared without lora=...")
+    with open(os.path.join(path, "adapter_config.json")) as f:
+        cfg = json.load(f)
+    if int(cfg["r"]) != lo.r or float(cfg["lora_alpha"]) / int(cfg["r"]) != lo.scale:
+        raise ValueError(f"adapter r={cfg['r']} alpha={cfg['lora_alpha']} does not match the prepared LoraConfig")
+    tens = load_adapter_tensors(path)
+    n = 0
+    for i in range(len(lo.A)):
+        for m in TARGETS:
+            key = "base_model.model." + lora_name(i, m, "A", "")
+            if key not in tens:
+                continue
+            lo.A[i][m].zero_(); lo.B[i][m].zero_()
+            lo.A[i][m][:lo.r].copy_(tens[key].to(rt.dev, torch.bfloat16))
+            lo.B[i][m][:, :lo.r].copy_(tens[key.replace("lora_A", "lora_B")].to(rt.dev, torch.bfloat16))
+            n += 1
+    for proj in ("dna_rna_projector", "protein_projector"):
+        f = os.path.join(path, proj + ".bin")
+        if os.path.exists(f):
+            sd = torch.load(f, map_location="cpu")
+            rt.W[proj + ".weight"].copy_(sd["weight"].to(rt.dev))
+            rt.W[proj + ".bias"].copy_(sd["bias"].to(rt.dev))
+    return n
+
+
 def adapter_state_dict(model) -> Dict[str, torch.Tensor]:
     """PEFT file layout: base_model.model.<llm path>.lora_A.weight [r, in] / lora_B.weight [out, r] (pad cut off)."""
     rt = model._runtime()

@@ -238,3 +238,41 @@ def test_lora_training_saves_a_peft_adapter_that_merges_back(tiny_meta, tmp_path
     err = (live.logits.float() - merged.logits.float()).cpu()[valid].abs().max().item()
     assert err <= 3e-2 * live.logits.float().abs().max().item(), err
     assert abs(live.loss.item() - merged.loss.item()) <= 5e-3
+
+
+def test_cli_lora_train_then_batch_inference_jsonl(tmp_path):
+    """`--use-lora` through the launchers with the reference's flag names: train.py writes the PEFT adapter + projector
+    files (src/trainer/omics_trainer.py:89-103), inference.py reads them back (merged and live) and writes the reference's
+    JSONL records (src/inference_lora.py:316-323)."""
+    from molly_amd import inference, train
+    rows = [dict(task="Solubility-Solubility", input=f"Is <protein>{'MKTAYIAKQR' * (1 + i % 3)}</protein> soluble?", think="",
+                 output="Yes." if i % 2 else "No.", label=str(i % 2), kind="protein", task_num=i) for i in range(8)]
+    rows += [dict(task="tf-h", input=f"Does <dna>{'ACGTTGCA' * (2 + i % 4)}</dna> bind?", think="", output="It does.",
+                  label="1", kind="dna", task_num=i) for i in range(8)]
+    data = tmp_path / "mini.jsonl"
+    data.write_text("\n".join(json.dumps(r) for r in rows))
+    out = tmp_path / "ckpt"
+    common = ["--text-model-path", "tiny", "--dna-rna-model-path", "tiny", "--protein-model-path", "tiny", "--no-load-pretrained",
+              "--dna-rna-k-tokens", "64", "--protein-k-tokens", "64"]
+    train.main(common + ["--output_dir", str(out), "--train-dataset-path", str(data), "--max-len", "256", "--use-lora",
+                         "--lora_r", "16", "--per_device_train_batch_size", "4", "--train-iters", "3", "--learning_rate", "1e-3",
+                         "--logging_steps", "1", "--bf16"])
+    for f in ("adapter_config.json", "dna_rna_projector.bin", "protein_projector.bin"):
+        assert (out / f).exists(), f
+    assert (out / "adapter_model.safetensors").exists() or (out / "adapter_model.bin").exists()
+    assert not (out / "pytorch_model.bin").exists()
+    recs = {}
+    for tag, extra in (("merged", []), ("live", ["--lora-live"])):
+        jf = tmp_path / f"pred_{tag}.jsonl"
+        inference.main(common + ["--trained-model-path", str(out), "--use-lora", *extra, "--dataset-path", str(data),
+                                 "--max-length", "256", "--batch-size", "4", "--max-samples", "6", "--greedy",
+                                 "--max-new-tokens", "5", "--json-file", str(jf)])
+        recs[tag] = [json.loads(l) for l in jf.read_text().splitlines()]
+        assert len(recs[tag]) == 6
+        for r, src in zip(recs[tag], rows):
+            assert set(r) == {"decoded_output", "input", "gt_output", "gt_label", "task", "kind"}
+            assert r["task"] == src["task"] and r["gt_label"] == src["label"]
+            # reference quirk kept: the Test-mode sample dict carries no "kind" (src/dataset/omics_dataset.py:393-402), so the
+            # collate's sample.get("kind") (:528) — and the JSONL field — is always None
+            assert r["kind"] is None
+            assert isinstance(r["decoded_output"], str)
