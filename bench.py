@@ -225,6 +225,14 @@ def main():
         by_kernel = {k: {"launches": v[0], "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
                          "achieved_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in by_kernel.items()}
         step_ms = [a.elapsed_time(b) for a, b in step_ev]
+        # HBM-side traffic of the dominant kernel cannot be counted live (PMC needs rocprofv3): quote the committed PMC
+        # passes of this same workload (profiles/r01_pmc_hbm_traffic.csv; corrected as MI355X_MICROARCH.md §HBM prescribes)
+        traffic, traffic_src = None, None
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+        if args.train_mode == "full" and (B, T, K, args.model) == (8, 2048, 512, "1.7b") and os.path.exists(tj):
+            with open(tj) as f:
+                tr = json.load(f)
+            traffic, traffic_src = tr["gemm_hbm_bytes_per_launch"], tr["source"]
         flops_step = B * (T * algorithmic_flops_per_token(cfg.text_config, T) +
                           K * (enc_flops_per_token(cfg.protein_config, K) + 3 * 2 * cfg.protein_config.hidden_size *
                                cfg.text_config.hidden_size))
@@ -247,7 +255,8 @@ def main():
             "loss": round(loss_v, 4),
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM (gemm256_kernel / gemm_kernel, all launches of the timed region)",
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "launches": n_launch,
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (L2 fabric-side: "
+                         "Infinity Cache + HBM)", "traffic_source": traffic_src, "launches": n_launch,
                          "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                          "gemm_share_of_step": round(gemm_ms / sum(step_ms), 3), "by_kernel": by_kernel},
         }
