@@ -160,10 +160,15 @@ int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, co
                    int lddq, int lddk, int lddv, float scale, int causal);
 
 /* single-query attention over a KV cache — the decode step of HF `generate` with DynamicCache that the reference runs
- * for inference (reference src/model/omics_one.py:220-232).  q [B, ldq] (heads at column h*hd), out [B, n_heads*hd]; k/v cache [B, Tmax, n_kv_heads*hd];
- * keys kv_lo[b] <= key < kv_hi[b] (kv_lo NULL = 0).  Tmax <= 16384. */
+ * for inference (reference src/model/omics_one.py:220-232).  q [B, ldq] (heads at column h*hd), out [B, n_heads*hd]; k/v
+ * cache [B, Tmax, n_kv_heads*hd]; keys kv_lo[b] <= key < kv_hi[b] (kv_lo NULL = 0).  The query heads of one KV head are
+ * processed together (K/V read once) and the key range is split over blocks (flash-decoding); `workspace` holds the fp32
+ * partials of the splits: molly_attn_decode_workspace(B, n_heads, head_dim) floats (NULL = no split).  kv_len_hint: an
+ * upper bound of kv_hi - kv_lo used only to choose the split count (0 = Tmax).  head_dim 64 | 128, n_heads/n_kv_heads 1|2|4|8. */
+int molly_attn_decode_workspace(int B, int n_heads, int head_dim);
 int molly_attn_decode(void* stream, const void* q, const void* kcache, const void* vcache, void* out, const int* kv_lo,
-                      const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim, int ldq, float scale);
+                      const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim, int ldq, float scale,
+                      int kv_len_hint, float* workspace, long workspace_floats);
 
 /* ------------------------------------------------------------------------------------------------
  * LoRA branch  y = W x + (alpha/r) * B (A dropout(x))  — PEFT lora.Linear.forward as the reference configures it

@@ -801,62 +801,6 @@ __global__ __launch_bounds__(256) void colsum_bf16_part_kernel(const bf16_t* __r
     part[(size_t)blockIdx.y * H + j] = s;
 }
 
-// ------------------------------------------------------------------------------------------------
-// single-query attention over a KV cache (decode step of HF generate with DynamicCache; reference call site
-// src/model/omics_one.py:220-232).  HBM-bound: every cached K and V byte of the (batch, kv-head) is read once per query
-// head.  One block per (batch, query head); scores live in LDS (cache length <= 16 Ki keys).
-// q [B, nh*hd] ; kcache/vcache [B, Tmax, nkv*hd] ; keys lo[b] <= key < hi[b]
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
-                                                          const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
-                                                          const int* __restrict__ lo_, const int* __restrict__ hi_, int Tmax,
-                                                          int nh, int nkv, int hd, int ldq, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
-    float* sq = reinterpret_cast<float*>(sm_raw);          // [hd]
-    float* sacc = sq + hd;                                  // [256] partial outputs
-    float* sc = sacc + 256;                                 // [Tmax] scores
-    __shared__ float red[16];
-    const int b = blockIdx.x / nh, head = blockIdx.x % nh;
-    const int kvh = head / (nh / nkv);
-    const int lo = lo_ ? lo_[b] : 0, hi = hi_[b];
-    const int ldc = nkv * hd;
-    for (int d = threadIdx.x; d < hd; d += 256) sq[d] = bf2f(q[(size_t)b * ldq + head * hd + d]) * scale;
-    __syncthreads();
-    const bf16_t* kb = kc + (size_t)b * Tmax * ldc + kvh * hd;
-    const bf16_t* vb = vc + (size_t)b * Tmax * ldc + kvh * hd;
-    float mx = -INFINITY;
-    for (int key = lo + threadIdx.x; key < hi; key += 256) {
-        const u32x4* kr = reinterpret_cast<const u32x4*>(kb + (size_t)key * ldc);
-        float s = 0.f;
-        for (int c = 0; c < hd / 8; ++c) {
-            const u32x4 v = kr[c];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s += bflo(v[e]) * sq[c * 8 + 2 * e] + bfhi(v[e]) * sq[c * 8 + 2 * e + 1];
-        }
-        sc[key - lo] = s;
-        mx = fmaxf(mx, s);
-    }
-    mx = block_max(mx, red);
-    float sum = 0.f;
-    for (int key = lo + threadIdx.x; key < hi; key += 256) {
-        const float pexp = __expf(sc[key - lo] - mx);
-        sc[key - lo] = pexp;
-        sum += pexp;
-    }
-    sum = block_sum(sum, red);                               // (block_sum's barriers also publish sc[])
-    const int groups = 256 / hd > 0 ? 256 / hd : 1;          // key groups working in parallel on the PV sum
-    const int d = threadIdx.x % hd, grp = threadIdx.x / hd;
-    float acc = 0.f;
-    if (grp < groups)
-        for (int key = lo + grp; key < hi; key += groups) acc += sc[key - lo] * bf2f(vb[(size_t)key * ldc + d]);
-    sacc[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x < hd) {
-        float t = 0.f;
-        for (int g = 0; g < groups; ++g) t += sacc[g * hd + threadIdx.x];
-        out[(size_t)b * nh * hd + head * hd + threadIdx.x] = f2bf(sum > 0.f ? t / sum : 0.f);
-    }
-}
 
 inline int grid_for(long items, int per_block = 256, int cap = 2048) {
     long g = (items + per_block - 1) / per_block;
@@ -1087,23 +1031,6 @@ extern "C" int molly_adamw_step(void* stream, float* master, float* exp_avg, flo
     return 0;
 }
 
-extern "C" int molly_attn_decode(void* stream, const void* q, const void* kcache, const void* vcache, void* out,
-                                 const int* kv_lo, const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim,
-                                 int ldq, float scale) {
-    MOLLY_CHECK(head_dim % 8 == 0 && head_dim <= 256 && 256 % head_dim == 0, "attn_decode: head_dim=%d unsupported", head_dim);
-    MOLLY_CHECK(Tmax > 0 && Tmax <= 16384, "attn_decode: cache length %d exceeds the LDS score buffer (16384 keys)", Tmax);
-    MOLLY_CHECK(kv_hi != nullptr && n_heads % n_kv_heads == 0, "attn_decode: kv_hi required");
-    const size_t lds = (head_dim + 256 + (size_t)Tmax) * sizeof(float);
-    static size_t max_set = 0;
-    if (lds > max_set) {
-        (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        max_set = lds;
-    }
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(B * n_heads), dim3(256), lds, ST, (const bf16_t*)q, (const bf16_t*)kcache,
-                       (const bf16_t*)vcache, (bf16_t*)out, kv_lo, kv_hi, Tmax, n_heads, n_kv_heads, head_dim, ldq, scale);
-    MOLLY_LAUNCH_CHECK();
-    return 0;
-}
 
 extern "C" int molly_colsum_parts(int rows) { return rows >= 1024 ? 64 : (rows >= 64 ? 16 : 1); }
 

@@ -98,6 +98,7 @@ class GenerationSession:
         self.s = dict(x=z(B, e.h), xn=z(B, e.h), qkv=z(B, e.nqkv), qk=z(B, e.nqk), attn=z(B, e.nh * e.hd), x2=z(B, e.h),
                       xn2=z(B, e.h), gu=z(B, 2 * e.ff), act=z(B, e.ff), hn=z(B, e.h))
         self.hi = torch.empty(B, dtype=torch.int32, device=dev)
+        self.dec_ws = ops.attn_decode_workspace(B, e.nh, e.hd, dev)
 
     def _head(self, x):
         e = self.eng
@@ -131,7 +132,7 @@ class GenerationSession:
             ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=slot)
             ops.copy_rows(s["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B, dst_idx32=slot)
             ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
-                            e.hd ** -0.5)
+                            e.hd ** -0.5, kv_len_hint=t + 1, workspace=self.dec_ws)
             ops.gemm_nt(s["attn"], w["o"], out=s["x2"], res=x)
             self._lora(i, "o_proj", s["attn"], s["x2"])
             ops.rmsnorm_fwd(s["x2"], w["ln2"], e.cfg.rms_norm_eps, out=s["xn2"])

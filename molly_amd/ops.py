@@ -246,9 +246,13 @@ def colsum(x, out, accumulate=False, workspace=None):
     return out
 
 
-def attn_decode(q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, scale):
+def attn_decode_workspace(B, nh, hd, device):
+    return torch.empty(lib().query("molly_attn_decode_workspace", B, nh, hd), dtype=torch.float32, device=device)
+
+
+def attn_decode(q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, scale, kv_len_hint=0, workspace=None):
     lib().call("molly_attn_decode", _stream(), q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, q.stride(0),
-               float(scale))
+               float(scale), int(kv_len_hint), workspace, workspace.numel() if workspace is not None else 0)
     return out
 
 

@@ -492,3 +492,34 @@ def test_transpose_fast_path_and_trans_out_gemm():
     dy, xx = _rand(Mtok, 1024, seed=84).to(BF), _rand(Mtok, 512, seed=85).to(BF)
     dw = ops.gemm(ops.transpose(xx), dy, b_kmajor=True, trans_out=True, out_dtype=torch.float32)
     _close(dw, dy.float().T @ xx.float(), atol=1e-3 * math.sqrt(Mtok), rtol=1e-4, what="trans_out split-K")
+
+
+@pytest.mark.parametrize("hd,nh,nkv,B,Tmax,use_ws", [(128, 16, 8, 4, 1500, True), (128, 32, 8, 3, 3000, True), (128, 8, 8, 2, 700, True),
+                                                     (64, 8, 1, 5, 900, True), (128, 16, 8, 4, 1500, False), (64, 4, 2, 33, 300, True)])
+def test_attn_decode_flash_decoding(hd, nh, nkv, B, Tmax, use_ws):
+    """Decode-step attention (GQA group per block, split-KV + merge) against torch fp32 softmax over the valid key window
+    [lo, hi) of each sample (left-padded prompts: lo > 0; one sample with a single key; rows outside the window are poison)."""
+    from molly_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(hd + nh + Tmax)
+    q = torch.randn(B, (nh + 2 * nkv) * hd, device="cuda", generator=g).bfloat16()         # q heads first, as in the qkv row
+    kc = torch.randn(B, Tmax, nkv * hd, device="cuda", generator=g).bfloat16()
+    vc = torch.randn(B, Tmax, nkv * hd, device="cuda", generator=g).bfloat16()
+    lo = torch.randint(0, Tmax // 3, (B,), generator=torch.Generator().manual_seed(1)).int()
+    hi = (lo + torch.randint(1, Tmax - Tmax // 3, (B,), generator=torch.Generator().manual_seed(2)).int()).clamp(max=Tmax)
+    hi[0] = lo[0] + 1
+    for b in range(B):                                                                       # poison outside the window
+        kc[b, :lo[b]] = float("nan"); kc[b, hi[b]:] = float("nan")
+        vc[b, :lo[b]] = float("nan"); vc[b, hi[b]:] = float("nan")
+    out = torch.empty(B, nh * hd, dtype=torch.bfloat16, device="cuda")
+    ws = ops.attn_decode_workspace(B, nh, hd, "cuda") if use_ws else None
+    ops.attn_decode(q, kc, vc, out, lo.cuda(), hi.cuda(), B, Tmax, nh, nkv, hd, hd ** -0.5, kv_len_hint=int(hi.max()), workspace=ws)
+    torch.cuda.synchronize()
+    for b in range(B):
+        k = kc[b, lo[b]:hi[b]].float().view(-1, nkv, hd).repeat_interleave(nh // nkv, dim=1)   # [n, nh, hd]
+        v = vc[b, lo[b]:hi[b]].float().view(-1, nkv, hd).repeat_interleave(nh // nkv, dim=1)
+        qq = q[b, :nh * hd].float().view(nh, hd)
+        p = torch.softmax(torch.einsum("hd,nhd->hn", qq, k) * hd ** -0.5, dim=-1)
+        ref = torch.einsum("hn,nhd->hd", p, v).reshape(-1)
+        err = (out[b].float() - ref).abs().max().item()
+        assert err <= 2e-2 * max(ref.abs().max().item(), 1.0), (b, err)
+    assert torch.isfinite(out.float()).all()

@@ -19,6 +19,8 @@ SHAPES = [  # (name, form, M, N, K)
     ("lm_head dgrad", "nn", M, 2048, 151936),
     ("qkv wgrad", "tn", 4096, 2048, M), ("gate|up wgrad", "tn", 12288, 2048, M), ("down wgrad", "tn", 2048, 6144, M),
     ("lm_head wgrad", "tn", 151936, 2048, M),
+    ("head fwd 4k", "nt", 4096, 151936, 2048), ("head dgrad 4k", "nn", 4096, 2048, 151936),
+    ("head wgrad 4k", "tn", 151936, 2048, 4096),
     ("esm qkv", "nt", 4096, 3840, 1280), ("esm ffn1", "nt", 4096, 5120, 1280), ("esm ffn2", "nt", 4096, 1280, 5120),
 ]
 

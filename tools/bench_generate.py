@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Prefill + greedy-decode throughput of `OmicsOne.generate`'s engine (BASELINE config 5 shape: left-padded prompts with one
+protein span, KV-cache decode).  Random-init weights, synthetic prompts; times the GenerationSession directly with HIP events.
+    python tools/bench_generate.py --model 8b --batch 32 --prompt 3072 --new 64"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="1.7b")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--prompt", type=int, default=3072)
+    ap.add_argument("--k-protein", type=int, default=1024)
+    ap.add_argument("--new", type=int, default=64)
+    args = ap.parse_args()
+    import molly_amd
+    from molly_amd import config as C
+    from molly_amd.generate import GenerationSession
+    from molly_amd.synth import synth_batch
+    dev = torch.device("cuda", 0)
+    cfg = C.molly(args.model, k_tokens=args.k_protein)
+    m = molly_amd.OmicsOne(cfg)
+    m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)
+    m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
+    m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
+    m.prepare(dev, train_llm=False, train_mlp=False, random_init_seed=1234)
+    B, T = args.batch, args.prompt
+    b = synth_batch(B, T, [("protein", args.k_protein)], seed=1)
+    res = {}
+    for rep in range(2):                                   # first pass warms allocations
+        sess = GenerationSession(m, args.new)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        logits = sess.prefill(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"])
+        e1.record()
+        for _ in range(args.new):
+            logits = sess.step(logits.argmax(-1))
+        e2.record()
+        torch.cuda.synchronize()
+        res = {"model": args.model, "batch": B, "prompt_len": T, "k_protein": args.k_protein, "new_tokens": args.new,
+               "prefill_ms": round(e0.elapsed_time(e1), 2), "prefill_tokens_per_s": round(B * T / e0.elapsed_time(e1) * 1e3, 1),
+               "decode_ms_per_step": round(e1.elapsed_time(e2) / args.new, 3),
+               "decode_tokens_per_s": round(B * args.new / e1.elapsed_time(e2) * 1e3, 1)}
+        del sess
+    n_par = sum(v.numel() for v in m._rt.base.views.values())
+    res["weight_stream_GBps_decode"] = round(2 * n_par / (res["decode_ms_per_step"] * 1e-3) / 1e9, 1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
