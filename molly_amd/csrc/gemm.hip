@@ -561,8 +561,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
 // out[m,n] (+)= sum_s slab[s][m][n]   (split-K combine; 4 elements per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long MN, int M, int N,
-                                                            void* C, int ldc, int out_f32, int accumulate) {
-    // slab = [M rows][N cols] of the OUTPUT matrix as stored (for transposed output the caller passes rows = N_gemm)
+                                                            void* C, int ldc, int out_f32, int accumulate,
+                                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            int ldres, int gelu) {
+    // slab = [M rows][N cols] of the OUTPUT matrix as stored (for transposed output the caller passes rows = N_gemm);
+    // the epilogue the one-pass kernel would have applied (bias -> GELU -> residual -> accumulate) is applied here
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long)gridDim.x * 1024) {
         f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
         for (int s = 1; s < splits; ++s) {
@@ -571,6 +574,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         const long m = i / N;
         const int n = (int)(i % N);
+        if (bias) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(bias + n);
+            a[0] += bflo(b[0]); a[1] += bfhi(b[0]); a[2] += bflo(b[1]); a[3] += bfhi(b[1]);
+        }
+        if (gelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = gelu_erf(a[e]);
+        }
+        if (res) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(res + m * ldres + n);
+            a[0] += bflo(b[0]); a[1] += bfhi(b[0]); a[2] += bflo(b[1]); a[3] += bfhi(b[1]);
+        }
         if (out_f32) {
             float* c = reinterpret_cast<float*>(C) + m * ldc + n;
             if (accumulate) {
@@ -625,8 +640,9 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             // 128x128 grid would leave CUs empty.  Such a problem is bound by streaming the big operand once, so what
             // matters is blocks (and bytes in flight) on every CU: split K finer (>= 8 K-tiles per slice) and further.
             const long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, BN);
-            const bool skinny = (p.M < 256 || p.N < 256) && p.M >= 64 && p.N >= 64 && t128 < 256;
-            const int min_kt = skinny ? 8 : 16;
+            // (decode GEMMs, M = batch rows: a pure weight stream — slices down to 4 K-tiles)
+            const bool skinny = (p.M < 256 || p.N < 256) && t128 < 256;
+            const int min_kt = skinny ? ((p.M < 64 || p.N < 64) ? 4 : 8) : 16;
             int best = 0;
             double best_score = 0.0;
             for (int sp : {2, 3, 4, 6, 8, 12, 16, 24, 32}) {
@@ -636,7 +652,8 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
                 if (skinny && eff(t256 * sp) > best_score + 1e-9) { best_score = eff(t256 * sp); best = -sp; }
             }
             if (best < 0) best = skinny && best_score > eff(t128) ? -best : 0;   // nothing fills the chip: the fullest
-            if (best && plain_epilogue && p.N % 4 == 0 && ((p.M >= 256 && p.N >= 256) || skinny)) {
+            // the slab path applies bias/GELU/residual in its reduce kernel (not for the transposed-output form)
+            if (best && (plain_epilogue || !TO) && p.N % 4 == 0 && ((p.M >= 256 && p.N >= 256) || skinny)) {
                 force_tile = 512;
                 p.splits = best;
                 p.ws = g_ws;
@@ -662,7 +679,9 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             const long MN = (long)p.M * p.N;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, p.ws,
                                p.splits, MN, TO ? p.N : p.M, TO ? p.M : p.N, p.C, p.ldc,
-                               (p.flags & MOLLY_GEMM_OUT_F32) ? 1 : 0, (p.flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0);
+                               (p.flags & MOLLY_GEMM_OUT_F32) ? 1 : 0, (p.flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0,
+                               (p.flags & MOLLY_GEMM_BIAS) ? p.bias : nullptr, (p.flags & MOLLY_GEMM_RESIDUAL) ? p.res : nullptr,
+                               p.ldres, (p.flags & MOLLY_GEMM_GELU) ? 1 : 0);
         }
     } else if constexpr (TO) {
         molly_set_error("gemm: transposed output is only built into the 256x256 kernel");

@@ -99,6 +99,8 @@ class GenerationSession:
                       xn2=z(B, e.h), gu=z(B, 2 * e.ff), act=z(B, e.ff), hn=z(B, e.h))
         self.hi = torch.empty(B, dtype=torch.int32, device=dev)
         self.dec_ws = ops.attn_decode_workspace(B, e.nh, e.hd, dev)
+        # decode GEMMs are M = B rows against whole weight matrices: the library splits K over the chip and needs slab space
+        ops.ensure_gemm_workspace(32 * 4 * max(B, 8) * max(2 * e.ff, e.nqkv), dev)
 
     def _head(self, x):
         e = self.eng

@@ -523,3 +523,28 @@ def test_attn_decode_flash_decoding(hd, nh, nkv, B, Tmax, use_ws):
         err = (out[b].float() - ref).abs().max().item()
         assert err <= 2e-2 * max(ref.abs().max().item(), 1.0), (b, err)
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 2048), (8, 12288, 2048), (32, 2048, 6144), (1, 2048, 2048), (48, 64, 4096)])
+def test_gemm_decode_rows_splitk_with_epilogue(M, N, K):
+    """M = batch rows (decode): the heuristic streams the weight through the 256x256 kernel with K split over the chip;
+    bias / GELU / residual are then applied by the slab-reduce kernel — same results as the one-pass epilogue."""
+    from molly_amd import ops
+    from molly_amd._lib import lib
+    ops.ensure_gemm_workspace(64 << 20)
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g).bfloat16()
+    res = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    for kw in (dict(), dict(res=res), dict(bias=bias, gelu=True), dict(bias=bias, res=res)):
+        out = ops.gemm_nt(a, w, **kw)
+        cfg = lib().query("molly_gemm_last_config")
+        lib().call("molly_gemm_force_tile", 128)
+        ref = ops.gemm_nt(a, w, **kw)
+        lib().call("molly_gemm_force_tile", 0)
+        if N >= 2048:
+            assert cfg // 1000 > 1 and cfg % 1000 == 512, cfg                 # went through the split-K slab path
+        assert (out.float() - ref.float()).abs().max().item() <= 2e-2 * max(ref.float().abs().max().item(), 1.0), kw.keys()
+    r32 = a.float() @ w.float().t()
+    assert (ops.gemm_nt(a, w).float() - r32).abs().max().item() <= 2e-2 * r32.abs().max().item()
