@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--k-protein", type=int, default=512)
     ap.add_argument("--model", default="1.7b")
-    ap.add_argument("--train-mode", choices=("full", "lora", "mlp"), default="full",
+    ap.add_argument("--train-mode", choices=("full", "lora", "mlp", "bio"), default="full",
                     help="full = headline (--train-llm --train-mlp); lora = --use-lora r=64; mlp = projectors only (side figures)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", nargs=3, type=int, metavar=("LLM_LAYERS", "ENC_LAYERS", "THREADS"))
@@ -158,8 +158,8 @@ def main():
     m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
     m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
     torch.manual_seed(1234)
-    if args.train_mode == "full":
-        m.prepare(dev, random_init_seed=1234)          # same seed on every rank: replicas start identical
+    if args.train_mode in ("full", "bio"):
+        m.prepare(dev, random_init_seed=1234, train_bio=args.train_mode == "bio")   # same seed on every rank: replicas start identical
     else:
         from molly_amd.lora import LoraConfig
         m.prepare(dev, random_init_seed=1234, train_llm=False, train_mlp=True,
@@ -242,9 +242,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Molly-{args.model.upper()} (Qwen3-{args.model.upper()} + NT-500M + ESM2-650M) train step, "
                                    f"seq_len {T} text + {K}-residue protein span per sample, {B} samples/GPU, GA=1, "
-                                   + {"full": "LLM+projectors trainable", "lora": "LoRA r=64 adapters+projectors trainable, base frozen",
+                                   + {"full": "LLM+projectors trainable", "bio": "LLM+projectors+encoders trainable (--train-bio)", "lora": "LoRA r=64 adapters+projectors trainable, base frozen",
                                       "mlp": "projectors trainable, LLM frozen"}[args.train_mode] +
-                                   f", encoders frozen, ZeRO-2 dp{world}",
+                                   ("" if args.train_mode == "bio" else ", encoders frozen") + f", ZeRO-2 dp{world}",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "scored_token_fraction": 0.25,
                        "note": "prompt = 75% of each sample with labels -100 (SURVEY 8d); lm_head+CE run on the scored rows only "

@@ -88,7 +88,7 @@ int molly_norm_rope_bwd_blocks(void);
 int molly_norm_rope_bwd(void* stream, const void* src, const void* g, void* dsrc, const void* q_norm_w,
                         const void* k_norm_w, const float* cos, const float* sin, const int* positions, void* dq_w,
                         void* dk_w, int dw_f32, int dw_accumulate, float* workspace, int M, int T, int n_q_heads,
-                        int n_k_heads, int head_dim, int ld_src, int ld_g, int ld_out, float eps);
+                        int n_k_heads, int head_dim, int ld_src, int ld_g, int ld_out, float eps, float q_scale);
 
 /* SwiGLU — HF:models/qwen3/modeling_qwen3.py:82 (Liger swiglu): out = silu(gate) * up, gate_up = [gate | up] per row. */
 int molly_swiglu_fwd(void* stream, const void* gate_up, void* out, long rows, int ff);
@@ -102,7 +102,7 @@ int molly_copy_rows(void* stream, const void* src, const int64_t* src_idx64, con
 /* embedding backward through a sorted index: for unique id u, dE[uid[u]] += sum_k g[order[k]],
  * k in [seg_start[u], seg_start[u+1]); uid < 0 skips.  Deterministic (no atomics). */
 int molly_embed_bwd(void* stream, const void* g, const int* order, const int* seg_start, const int64_t* uid,
-                    int n_unique, void* dE, int H, int ld_g);
+                    int n_unique, void* dE, int H, int ld_g, const float* row_scale);
 
 /* cross-entropy on bf16 logits, in place -> d(logits) — HF:loss/loss_utils.py:32-71 (ForCausalLMLoss; Liger
  * fused-linear-CE when --use_liger).  `labels` are already shifted (row r is scored against labels[r]);
@@ -115,6 +115,16 @@ int molly_sum_f32(void* stream, const float* x, long n, const float* scale_or_nu
 /* LayerNorm forward (affine, eps 1e-5) — ESM pre-LN blocks and emb_layer_norm_after: HF:models/esm/
  * modeling_esm.py:429,518,552. */
 int molly_layernorm_fwd(void* stream, const void* x, const void* w, const void* b, void* y, int rows, int H, float eps);
+/* LayerNorm backward of the ESM blocks (encoder training, reference `--train-bio`: src/utils/tools.py:326-330):
+ * dx = rstd (g w - mean(g w) - xhat mean(g w xhat)) (+ dres); dw (+)= sum_rows g xhat, db (+)= sum_rows g.
+ * workspace: 2 * molly_layernorm_bwd_blocks(rows) * H floats. */
+int molly_layernorm_bwd_blocks(int rows);
+int molly_layernorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres, void* dx, void* dw,
+                        void* db, int dw_f32, int dw_accumulate, float* workspace, int rows, int H, float eps);
+/* erf-GELU on a stored pre-activation and its backward (ESM intermediate activation, HF:models/esm/modeling_esm.py:56-60);
+ * training keeps z, so the forward GEMM runs without the fused GELU epilogue. */
+int molly_gelu_fwd(void* stream, const void* z, void* out, long n);
+int molly_gelu_bwd(void* stream, const void* z, const void* dout, void* dz, long n);
 
 /* ESM embeddings — HF:models/esm/modeling_esm.py:224-271 (+ position ids :1050-1063): word embedding,
  * token-dropout rescale, optional learned absolute positions (pos_emb NULL for rotary models), x mask.

@@ -308,6 +308,7 @@ struct RopeBwdArgs {
     int M, T, nq, nk, hd, ld_src, ld_g, ld_out;
     float eps;
     long items_per_blk;
+    float q_scale;                           // forward multiplied the q heads by this (ESM: hd^-0.5 before rotary)
 };
 
 __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
                 const float t1 = g1[e] * c[e] + g2[e] * sn[e], t2 = g2[e] * c[e] - g1[e] * sn[e];
                 g1[e] = t1; g2[e] = t2;
             }
+        }
+        if (isq && p.q_scale != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g1[e] *= p.q_scale; g2[e] *= p.q_scale; }
         }
         const bf16_t* w = isq ? p.qw : p.kw;
         float d1[4], d2[4];
@@ -482,7 +487,8 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
 // One wave per unique id -> deterministic, no atomics.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict__ g, const int* __restrict__ order,
                                                         const int* __restrict__ seg_start, const long* __restrict__ uid,
-                                                        int n_unique, bf16_t* __restrict__ dE, int H, int ld_g) {
+                                                        int n_unique, bf16_t* __restrict__ dE, int H, int ld_g,
+                                                        const float* __restrict__ row_scale) {
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u >= n_unique) return;
@@ -494,8 +500,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = b; k < e; ++k) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(g + (size_t)order[k] * ld_g + c * 8);
+            const float rs = row_scale ? row_scale[order[k]] : 1.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[2 * j] += bflo(v[j]); acc[2 * j + 1] += bfhi(v[j]); }
+            for (int j = 0; j < 4; ++j) { acc[2 * j] += rs * bflo(v[j]); acc[2 * j + 1] += rs * bfhi(v[j]); }
         }
         u32x4* dp = reinterpret_cast<u32x4*>(dE + (size_t)id * H + c * 8);
         const u32x4 o = *dp;
@@ -651,6 +658,150 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
                                 (bfhi(v[i][e]) - mean) * rstd * bfhi(wv[e]) + bfhi(bv[e]));
             yr[c] = o;
         }
+    }
+}
+
+// LayerNorm backward (HF nn.LayerNorm in the ESM blocks, HF:models/esm/modeling_esm.py:417,449,552): one wave per row, the
+// row stays in registers; dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat)) (+ dres); per-block fp32 partials of
+// dw = sum g*xhat and db = sum g, reduced by colsum_kernel (deterministic, no atomics).  Encoder backward: `--train-bio`.
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ g, const bf16_t* __restrict__ dres,
+                                                            bf16_t* __restrict__ dx, float* __restrict__ part, int rows, int H,
+                                                            float eps, int nb) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    float* sdw = reinterpret_cast<float*>(sm_raw);          // [4 waves][64 lanes][8]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = H >> 3;
+    float dwacc[NC][8], dbacc[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dwacc[i][e] = 0.f; dbacc[i][e] = 0.f; }
+    const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)row * H);
+        const u32x4* gr = reinterpret_cast<const u32x4*>(g + (size_t)row * H);
+        u32x4 xv[NC], gv[NC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                xv[i] = xr[c];
+                gv[i] = gr[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += bflo(xv[i][e]) + bfhi(xv[i][e]);
+            }
+        }
+        const float mean = wave_sum(s) / (float)H;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = bflo(xv[i][e]) - mean, b = bfhi(xv[i][e]) - mean;
+                    ss += a * a + b * b;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+        float s1 = 0.f, s2 = 0.f;                               // sum(g*w), sum(g*w*xhat)
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                const u32x4 wv = wr[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ha = (bflo(xv[i][e]) - mean) * rstd, hb = (bfhi(xv[i][e]) - mean) * rstd;
+                    const float ga = bflo(gv[i][e]) * bflo(wv[e]), gb = bfhi(gv[i][e]) * bfhi(wv[e]);
+                    s1 += ga + gb;
+                    s2 += ga * ha + gb * hb;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        u32x4* dxr = reinterpret_cast<u32x4*>(dx + (size_t)row * H);
+        const u32x4* rr = dres ? reinterpret_cast<const u32x4*>(dres + (size_t)row * H) : nullptr;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                const u32x4 wv = wr[c];
+                u32x4 rv = u32x4{0, 0, 0, 0};
+                if (rr) rv = rr[c];
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ha = (bflo(xv[i][e]) - mean) * rstd, hb = (bfhi(xv[i][e]) - mean) * rstd;
+                    const float ga = bflo(gv[i][e]), gb = bfhi(gv[i][e]);
+                    float da = rstd * (ga * bflo(wv[e]) - s1 - ha * s2);
+                    float db = rstd * (gb * bfhi(wv[e]) - s1 - hb * s2);
+                    if (rr) { da += bflo(rv[e]); db += bfhi(rv[e]); }
+                    o[e] = pack_bf2(da, db);
+                    dwacc[i][2 * e] += ga * ha; dwacc[i][2 * e + 1] += gb * hb;
+                    dbacc[i][2 * e] += ga;      dbacc[i][2 * e + 1] += gb;
+                }
+                dxr[c] = o;
+            }
+        }
+    }
+    // 4 waves -> block partial through LDS; part = [dw: nb x H][db: nb x H]
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + i * 64;
+            __syncthreads();
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sdw[(wave * 64 + lane) * 8 + e] = which ? dbacc[i][e] : dwacc[i][e];
+            }
+            __syncthreads();
+            if (wave == 0 && c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    part[((size_t)which * nb + blockIdx.x) * H + c * 8 + e] =
+                        sdw[(0 * 64 + lane) * 8 + e] + sdw[(1 * 64 + lane) * 8 + e] + sdw[(2 * 64 + lane) * 8 + e] +
+                        sdw[(3 * 64 + lane) * 8 + e];
+            }
+        }
+    }
+}
+
+// erf-GELU (HF ACT2FN["gelu"], the ESM intermediate activation: HF:models/esm/modeling_esm.py:56-60) on a stored
+// pre-activation, and its derivative  0.5 (1 + erf(z/sqrt2)) + z exp(-z^2/2) / sqrt(2 pi)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ z, bf16_t* __restrict__ out, long nch) {
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < nch; t += (long)gridDim.x * 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(z + t * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bflo(v[e]), b = bfhi(v[e]);
+            o[e] = pack_bf2(0.5f * a * (1.f + erff(a * 0.70710678118654752f)), 0.5f * b * (1.f + erff(b * 0.70710678118654752f)));
+        }
+        *reinterpret_cast<u32x4*>(out + t * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ dout,
+                                                       bf16_t* __restrict__ dz, long nch) {
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < nch; t += (long)gridDim.x * 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(z + t * 8);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(dout + t * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bflo(v[e]), b = bfhi(v[e]);
+            const float ga = 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * __expf(-0.5f * a * a) * 0.3989422804014327f;
+            const float gb = 0.5f * (1.f + erff(b * 0.70710678118654752f)) + b * __expf(-0.5f * b * b) * 0.3989422804014327f;
+            o[e] = pack_bf2(bflo(d[e]) * ga, bfhi(d[e]) * gb);
+        }
+        *reinterpret_cast<u32x4*>(dz + t * 8) = o;
     }
 }
 
@@ -890,7 +1041,7 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
                                    const void* k_norm_w, const float* cos, const float* sin, const int* positions,
                                    void* dq_w, void* dk_w, int dw_f32, int dw_accumulate, float* workspace, int M, int T,
                                    int n_q_heads, int n_k_heads, int head_dim, int ld_src, int ld_g, int ld_out,
-                                   float eps) {
+                                   float eps, float q_scale) {
     MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0, "norm_rope_bwd: head_dim=%d",
                 head_dim);
     MOLLY_CHECK(workspace, "norm_rope_bwd: workspace of molly_norm_rope_bwd_blocks()*2*head_dim floats required");
@@ -900,7 +1051,7 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
     long ipb = (items + nb - 1) / nb;
     ipb = (ipb + hpi - 1) / hpi * hpi;
     RopeBwdArgs p{(const bf16_t*)src, (const bf16_t*)g, (bf16_t*)dsrc, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w,
-                  cos, sin, positions, workspace, M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_g, ld_out, eps, ipb};
+                  cos, sin, positions, workspace, M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_g, ld_out, eps, ipb, q_scale};
     hipLaunchKernelGGL(norm_rope_bwd_kernel, dim3(nb), dim3(256), 2 * head_dim * sizeof(float), ST, p);
     MOLLY_LAUNCH_CHECK();
     if (q_norm_w) {
@@ -942,11 +1093,11 @@ extern "C" int molly_copy_rows(void* stream, const void* src, const int64_t* src
 }
 
 extern "C" int molly_embed_bwd(void* stream, const void* g, const int* order, const int* seg_start, const int64_t* uid,
-                               int n_unique, void* dE, int H, int ld_g) {
+                               int n_unique, void* dE, int H, int ld_g, const float* row_scale) {
     MOLLY_CHECK(H % 8 == 0 && ld_g % 8 == 0, "embed_bwd: H must be a multiple of 8");
     if (n_unique <= 0) return 0;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(n_unique, 4)), dim3(256), 0, ST, (const bf16_t*)g, order, seg_start,
-                       (const long*)uid, n_unique, (bf16_t*)dE, H, ld_g);
+                       (const long*)uid, n_unique, (bf16_t*)dE, H, ld_g, row_scale);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }
@@ -982,6 +1133,42 @@ extern "C" int molly_layernorm_fwd(void* stream, const void* x, const void* w, c
                        (const bf16_t*)b, (bf16_t*)y, rows, H, eps)
     NC_DISPATCH(H, LN_FWD);
 #undef LN_FWD
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_layernorm_bwd_blocks(int rows) { return grid_for(rows, 4, 512); }
+
+extern "C" int molly_layernorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres, void* dx,
+                                   void* dw, void* db, int dw_f32, int dw_accumulate, float* workspace, int rows, int H,
+                                   float eps) {
+    MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "layernorm_bwd: bad H=%d", H);
+    MOLLY_CHECK(workspace && dw && db, "layernorm_bwd: workspace of 2*molly_layernorm_bwd_blocks(rows)*H floats, dw, db required");
+    const int nb = molly_layernorm_bwd_blocks(rows);
+#define LN_BWD(NC)                                                                                                   \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NC>, dim3(nb), dim3(256), 4 * 64 * 8 * sizeof(float), ST, (const bf16_t*)x, \
+                       (const bf16_t*)w, (const bf16_t*)g, (const bf16_t*)dres, (bf16_t*)dx, workspace, rows, H, eps, nb)
+    NC_DISPATCH(H, LN_BWD);
+#undef LN_BWD
+    MOLLY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 32)), dim3(256), 0, ST, workspace, nb, H, H, dw, dw_f32, dw_accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 32)), dim3(256), 0, ST, workspace + (size_t)nb * H, nb, H, H, db, dw_f32,
+                       dw_accumulate);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_gelu_fwd(void* stream, const void* z, void* out, long n) {
+    MOLLY_CHECK(n > 0 && n % 8 == 0, "gelu_fwd: n=%ld must be a positive multiple of 8", n);
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, ST, (const bf16_t*)z, (bf16_t*)out, n / 8);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_gelu_bwd(void* stream, const void* z, const void* dout, void* dz, long n) {
+    MOLLY_CHECK(n > 0 && n % 8 == 0, "gelu_bwd: n=%ld must be a positive multiple of 8", n);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, ST, (const bf16_t*)z, (const bf16_t*)dout,
+                       (bf16_t*)dz, n / 8);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -248,7 +248,7 @@ class OmicsOne(nn.Module):
 
     # ---- runtime --------------------------------------------------------------------------------------------
     def prepare(self, device="cuda", train_llm=True, train_mlp=True, ce_chunk_rows=16384, rope_table_dtype=BF16,
-                random_init_seed: Optional[int] = None, lora=None):
+                random_init_seed: Optional[int] = None, lora=None, train_bio=False):
         """Re-home all tensors into flat bf16 HBM buffers and build the HIP engines.
 
         Trainable group (what `rt.P` / `rt.G` / `n_decay` describe and the ZeRO-2 optimizer steps) — reference
@@ -257,7 +257,8 @@ class OmicsOne(nn.Module):
           lora=LoraConfig (`--use-lora`) -> rank-r adapters on every LLM Linear except lm_head + the projectors; base frozen
           train_mlp only                 -> the two projectors; the LLM is frozen (backward only propagates through it)
           neither                        -> nothing (inference)
-        The encoders are always frozen buffers (`--train-bio` is SURVEY.md §8f-4)."""
+          train_bio (`--train-bio`)      -> adds both encoders (all their parameters) to whichever group the above selects;
+                                            otherwise the encoders are frozen buffers, never communicated."""
         assert self.model is not None and self.dna_rna_model is not None and self.protein_model is not None, \
             "attach .model / .dna_rna_model / .protein_model first (reference: src/train.py:127,143,152)"
         dev = torch.device(device)
@@ -270,27 +271,39 @@ class OmicsOne(nn.Module):
         sd = self.state_dict()
         pw, pb = projector_specs(self.text_config, self.dna_rna_config, self.protein_config)
         full = bool(train_llm)
-        adapters = (lora is not None) or (train_mlp and not train_llm)
+        adapters = (lora is not None) or ((train_mlp or train_bio) and not train_llm)
+        enc_specs = {pre: enc_param_specs(cfg, pre) for pre, cfg in (("dna_rna_model.", self.dna_rna_config),
+                                                                     ("protein_model.", self.protein_config))}
+        enc_d, enc_nd = [], []
+        if train_bio:
+            # encoder tensors join the trainable group, split like everything else into decayed matrices / no-decay
+            # gains+biases; q|k|v weights (and biases) stay adjacent inside their part, so the fused views still exist
+            for specs in enc_specs.values():
+                enc_d += [(n, sh) for n, sh in specs if not is_no_decay(n)]
+                enc_nd += [(n, sh) for n, sh in specs if is_no_decay(n)]
         Q = None
         if full or not adapters:
             decay, no_decay = trainable_specs(self.text_config, self.dna_rna_config, self.protein_config)
-            base = FlatBuffer(decay + no_decay, dev, pad_to=8 * 64)
+            base = FlatBuffer(decay + enc_d + no_decay + enc_nd, dev, pad_to=8 * 64)
             n_decay = base.offsets[no_decay[0][0]]
         else:
-            # frozen LLM in one buffer, the small trainable group (adapters + projectors) in another
-            base = FlatBuffer(llm_param_specs(self.text_config) + llm_norm_specs(self.text_config), dev)
-            q_decay = pw
+            # frozen LLM in one buffer, the small trainable group (adapters + projectors [+ encoders]) in another
+            base = FlatBuffer(llm_param_specs(self.text_config) + llm_norm_specs(self.text_config) +
+                              ([] if (train_mlp or lora is not None) else pw + pb), dev)
+            q_decay = pw if (train_mlp or lora is not None) else []
+            q_nd = pb if (train_mlp or lora is not None) else []
             if lora is not None:
                 from .lora import lora_specs
-                q_decay = lora_specs(self.text_config, lora) + pw
-            Q = FlatBuffer(q_decay + pb, dev, pad_to=8 * 64)
-            n_decay = Q.offsets[pb[0][0]]
+                q_decay = lora_specs(self.text_config, lora) + q_decay
+            Q = FlatBuffer(q_decay + enc_d + q_nd + enc_nd, dev, pad_to=8 * 64)
+            n_decay = Q.offsets[(q_nd + enc_nd)[0][0]]
         self.n_decay = n_decay
         enc = {}
-        for pre, cfg in (("dna_rna_model.", self.dna_rna_config), ("protein_model.", self.protein_config)):
-            enc[pre] = FlatBuffer(enc_param_specs(cfg, pre), dev)
+        for pre, specs in enc_specs.items():
+            # frozen encoders own a buffer each; trained ones live in the trainable group
+            enc[pre] = (base if (full or not adapters) else Q) if train_bio else FlatBuffer(specs, dev)
         gen = None
-        bufs = [base] + ([Q] if Q is not None else []) + list(enc.values())
+        bufs = [base] + ([Q] if Q is not None else []) + ([] if train_bio else list(enc.values()))
         for buf in bufs:
             for n, v in buf.views.items():
                 if ".lora_" in n:
@@ -330,6 +343,7 @@ class OmicsOne(nn.Module):
         rt = type("Runtime", (), {})()
         rt.dev, rt.base, rt.enc = dev, base, enc
         rt.full, rt.train_llm, rt.train_mlp = full, bool(train_llm), bool(train_mlp or lora is not None)
+        rt.train_bio = bool(train_bio)
         if full:
             rt.P, rt.G = base, base.like()
         elif Q is not None:
@@ -348,8 +362,9 @@ class OmicsOne(nn.Module):
             lora_rt.init_gaussian(gen)
         rt.llm = Qwen3Engine(self.text_config, base, rt.G if full else None, dev, ce_chunk_rows=ce_chunk_rows,
                              rope_table_dtype=rope_table_dtype, lora=lora_rt, backward=rt.G is not None)
-        rt.dna = EsmEngine(self.dna_rna_config, enc["dna_rna_model."], dev, "dna_rna_model.", rope_table_dtype)
-        rt.prot = EsmEngine(self.protein_config, enc["protein_model."], dev, "protein_model.", rope_table_dtype)
+        eg = rt.G if train_bio else None
+        rt.dna = EsmEngine(self.dna_rna_config, enc["dna_rna_model."], dev, "dna_rna_model.", rope_table_dtype, grads=eg)
+        rt.prot = EsmEngine(self.protein_config, enc["protein_model."], dev, "protein_model.", rope_table_dtype, grads=eg)
         self._rt = rt
         return self
 
@@ -385,7 +400,7 @@ class OmicsOne(nn.Module):
                     f"out-of-range token: {ids[ids >= eng.cfg.vocab_size]}"
                 check_trailing_pad(ids, 1)
                 try:
-                    enc_out = eng.forward(ids.to(rt.dev, non_blocking=True))
+                    enc_out = eng.forward(ids.to(rt.dev, non_blocking=True), training=keep_for_backward and rt.train_bio)
                 except Exception as e:  # reference re-wraps encoder failures (omics_one.py:89-90)
                     raise RuntimeError(f"Error processing omic sequences: {e}")
                 emb = ops.gemm_nt(enc_out, rt.W[proj + ".weight"], bias=rt.W[proj + ".bias"])
@@ -393,7 +408,7 @@ class OmicsOne(nn.Module):
                 ops.copy_rows(emb, hs, emb.shape[0], dst_idx32=dst_dev)
                 valid = dst.numpy() >= 0
                 overwritten[dst.numpy()[valid]] = True
-                saved[name] = (enc_out, dst_dev, proj)
+                saved[name] = (enc_out, dst_dev, proj, eng)
         return hs, overwritten, saved
 
     @staticmethod
@@ -457,20 +472,32 @@ class OmicsOne(nn.Module):
             if len(uid):
                 ops.embed_bwd(d_hs, torch.from_numpy(order).to(rt.dev), torch.from_numpy(seg).to(rt.dev),
                               torch.from_numpy(uid).to(rt.dev), len(uid), rt.llm.d_embed)
-        if rt.train_mlp:
-            for name, (enc_out, dst_dev, proj) in saved.items():
-                N = enc_out.shape[0]
-                d_emb = torch.zeros(N, self.text_config.hidden_size, dtype=BF16, device=rt.dev)
-                ops.copy_rows(d_hs, d_emb, N, src_idx32=dst_dev)
+        for name, (enc_out, dst_dev, proj, eng) in saved.items():
+            if not (rt.train_mlp or rt.train_bio):
+                break
+            N = enc_out.shape[0]
+            d_emb = torch.zeros(N, self.text_config.hidden_size, dtype=BF16, device=rt.dev)
+            ops.copy_rows(d_hs, d_emb, N, src_idx32=dst_dev)
+            if rt.train_mlp:
                 ops.gemm(d_emb, enc_out, out=rt.G.views[proj + ".weight"], accumulate=accumulate, a_kmajor=True,
                          b_kmajor=True)
                 ops.colsum(d_emb, rt.G.views[proj + ".bias"], accumulate=accumulate)
+            if rt.train_bio:
+                # d(encoder output) = d_emb W_proj, then the encoder's own backward (reference `--train-bio`)
+                eng.backward(ops.gemm(d_emb, rt.W[proj + ".weight"], b_kmajor=True), accumulate=accumulate)
         if not accumulate:
-            # projector of a modality absent from this batch still owns grad slots: they must read as zero
-            for name, proj in (("dna_rna", "dna_rna_projector"), ("protein", "protein_projector")):
-                if name not in saved:
+            # parameters of a modality absent from this batch still own grad slots: they must read as zero
+            for name, proj, pre in (("dna_rna", "dna_rna_projector", "dna_rna_model."),
+                                    ("protein", "protein_projector", "protein_model.")):
+                if name in saved:
+                    continue
+                if rt.train_mlp:
                     rt.G.views[proj + ".weight"].zero_()
                     rt.G.views[proj + ".bias"].zero_()
+                if rt.train_bio:
+                    for n, v in rt.G.views.items():
+                        if n.startswith(pre):
+                            v.zero_()
         return rt.llm.scal[2]
 
     def process_omic_sequences(self, hidden_states, omic_ids_list, omic_info_list, device=None):

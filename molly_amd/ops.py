@@ -126,14 +126,14 @@ def norm_rope_fwd(src, dst, nq, nk, hd, T, qw=None, kw=None, cos=None, sin=None,
 
 
 def norm_rope_bwd(src, g, dsrc, nq, nk, hd, T, qw, kw, cos, sin, dqw, dkw, positions=None, eps=1e-6,
-                  dw_accumulate=True, workspace=None):
+                  dw_accumulate=True, workspace=None, q_scale=1.0):
     M = src.shape[0]
     nb = lib().query("molly_norm_rope_bwd_blocks")
     if workspace is None:
         workspace = torch.empty(nb * 2 * hd, dtype=torch.float32, device=src.device)
     lib().call("molly_norm_rope_bwd", _stream(), src, g, dsrc, qw, kw, cos, sin, positions, dqw, dkw,
                int(dqw.dtype == torch.float32) if dqw is not None else 0, int(dw_accumulate), workspace, M, T, nq, nk, hd,
-               src.stride(0), g.stride(0), dsrc.stride(0), float(eps))
+               src.stride(0), g.stride(0), dsrc.stride(0), float(eps), float(q_scale))
     return dsrc
 
 
@@ -168,6 +168,37 @@ def layernorm_fwd(x, w, b, eps, out=None):
         out = torch.empty_like(x)
     lib().call("molly_layernorm_fwd", _stream(), x, w, b, out, rows, H, float(eps))
     return out
+
+
+def layernorm_bwd(x, w, g, dw, db, eps, dres=None, dx=None, dw_accumulate=False, workspace=None):
+    rows, H = x.shape
+    assert x.is_contiguous() and g.is_contiguous()
+    if dx is None:
+        dx = torch.empty_like(x)
+    nb = lib().query("molly_layernorm_bwd_blocks", rows)
+    if workspace is None:
+        workspace = torch.empty(2 * nb * H, dtype=torch.float32, device=x.device)
+    assert workspace.numel() >= 2 * nb * H
+    lib().call("molly_layernorm_bwd", _stream(), x, w, g, dres, dx, dw, db, int(dw.dtype == torch.float32), int(dw_accumulate),
+               workspace, rows, H, float(eps))
+    return dx
+
+
+def gelu_fwd(z, out=None):
+    _chk(z, BF16, "z")
+    assert z.is_contiguous()
+    if out is None:
+        out = torch.empty_like(z)
+    lib().call("molly_gelu_fwd", _stream(), z, out, z.numel())
+    return out
+
+
+def gelu_bwd(z, dout, dz=None):
+    assert z.is_contiguous() and dout.is_contiguous()
+    if dz is None:
+        dz = torch.empty_like(z)
+    lib().call("molly_gelu_bwd", _stream(), z, dout, dz, z.numel())
+    return dz
 
 
 def attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, kv_lo=None, kv_hi=None, out=None, lse=None):
@@ -214,8 +245,9 @@ def esm_embed(ids, word_emb, pos_emb, out, pos_ids, kv_len, pad_id, mask_id, tok
     return out
 
 
-def embed_bwd(g, order, seg_start, uid, n_unique, dE):
-    lib().call("molly_embed_bwd", _stream(), g, order, seg_start, uid, n_unique, dE, dE.shape[1], g.stride(0))
+def embed_bwd(g, order, seg_start, uid, n_unique, dE, row_scale=None):
+    """dE[uid[u]] += sum over k in [seg_start[u], seg_start[u+1]) of row_scale[order[k]] * g[order[k]]."""
+    lib().call("molly_embed_bwd", _stream(), g, order, seg_start, uid, n_unique, dE, dE.shape[1], g.stride(0), row_scale)
 
 
 def sqnorm(g, out, workspace, accumulate=False):

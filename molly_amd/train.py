@@ -56,8 +56,6 @@ def main(argv=None):
               "--skip-eval", "--use-lora"):
         ap.add_argument(f, action="store_true")
     a = ap.parse_args(argv)
-    if a.train_bio:
-        raise NotImplementedError("--train-bio (encoder backward) is not built yet: SURVEY.md §8f-4")
     lora = None
     if a.use_lora:
         # reference src/train.py:654-657 -> pre_train_lora (src/utils/tools.py:345-396): base + encoders frozen, adapters on
@@ -92,7 +90,7 @@ def main(argv=None):
                 raise FileNotFoundError(f"{f}: no weights; pass --no-load-pretrained for random init")
             sub.load_state_dict(torch.load(f, map_location="cpu"), strict=False, assign=True)
     m.prepare(torch.device("cuda", local), train_llm=a.train_llm and lora is None, train_mlp=a.train_mlp or lora is not None,
-              random_init_seed=1234, lora=lora)
+              random_init_seed=1234, lora=lora, train_bio=a.train_bio)
     # tokenizers: the real ones need vocab files (none offline) -> the deterministic stand-ins of molly_amd.data
     dcfg = DatasetConfig(max_len=a.max_len, max_src_len=a.max_src_len, mode=a.mode, cal_metric_pos=None,
                          dna_rna_k_tokens=a.dna_rna_k_tokens, protein_k_tokens=a.protein_k_tokens)
