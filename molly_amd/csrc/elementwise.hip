@@ -198,24 +198,30 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 // block = 32 columns x 8 row groups (fixed summation tree), grid = H/32 blocks
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nb, int H, int row_stride,
                                                      void* out, int out_f32, int accumulate) {
-    __shared__ float red[8][33];
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + c;
-    float s = 0.f;
+    // block = 32 columns as 8 float4 quads x 32 row groups (16-B loads, 128 B contiguous per row); H % 4 == 0
+    __shared__ float red[32][33];
+    const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const int j = blockIdx.x * 32 + cq * 4;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     if (j < H)
-        for (int b = rg; b < nb; b += 8) s += part[(size_t)b * row_stride + j];
-    red[rg][c] = s;
+        for (int b = rg; b < nb; b += 32) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)b * row_stride + j);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg][cq * 4 + e] = s[e];
     __syncthreads();
-    if (rg == 0 && j < H) {
+    const int c = threadIdx.x, jj = blockIdx.x * 32 + c;
+    if (c < 32 && jj < H) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) t += red[g][c];
+        for (int g = 0; g < 32; ++g) t += red[g][c];
         if (out_f32) {
             float* o = reinterpret_cast<float*>(out);
-            o[j] = accumulate ? o[j] + t : t;
+            o[jj] = accumulate ? o[jj] + t : t;
         } else {
             bf16_t* o = reinterpret_cast<bf16_t*>(out);
-            o[j] = f2bf(accumulate ? bf2f(o[j]) + t : t);
+            o[jj] = f2bf(accumulate ? bf2f(o[jj]) + t : t);
         }
     }
 }
@@ -1223,7 +1229,8 @@ extern "C" int molly_colsum_parts(int rows) { return rows >= 1024 ? 64 : (rows >
 
 extern "C" int molly_colsum_bf16(void* stream, const void* x, int rows, int H, int ld, void* out, int out_f32,
                                  int accumulate, float* workspace) {
-    MOLLY_CHECK(rows > 0 && H > 0 && workspace, "colsum: bad shape or missing workspace (molly_colsum_parts(rows)*H floats)");
+    MOLLY_CHECK(rows > 0 && H > 0 && H % 4 == 0 && workspace,
+                "colsum: H=%d must be a positive multiple of 4; workspace of molly_colsum_parts(rows)*H floats required", H);
     const int np = molly_colsum_parts(rows);
     const int rpp = cdiv(rows, np);
     hipLaunchKernelGGL(colsum_bf16_part_kernel, dim3(cdiv(H, 256), np), dim3(256), 0, ST, (const bf16_t*)x, rows, H, ld,
