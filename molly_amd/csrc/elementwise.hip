@@ -595,7 +595,10 @@ __global__ __launch_bounds__(1024) void count_valid_kernel(const long* __restric
     c = block_sum(c, red);
     if (threadIdx.x == 0) {
         *count_out = c;
-        *scale_out = 1.f / fmaxf(c, 1.f);
+        // no scored token: the reference's mean over zero tokens is NaN (HF:loss/loss_utils.py:32-47, reduction="mean").
+        // The LOSS reproduces that; the gradients stay exactly zero (ignored rows write literal zeros), where the reference
+        // would hand NaN gradients to the optimizer — a deliberate, documented difference.
+        *scale_out = c > 0.f ? 1.f / c : __builtin_nanf("");
     }
 }
 
