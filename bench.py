@@ -237,7 +237,7 @@ def main():
                           K * (enc_flops_per_token(cfg.protein_config, K) + 3 * 2 * cfg.protein_config.hidden_size *
                                cfg.text_config.hidden_size))
         out = {
-            "metric": "training tokens/sec Molly-1.7B bf16", "value": round(tokens / dt, 1), "unit": "tokens/s",
+            "metric": f"training tokens/sec Molly-{args.model.upper()} bf16", "value": round(tokens / dt, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Molly-{args.model.upper()} (Qwen3-{args.model.upper()} + NT-500M + ESM2-650M) train step, "
