@@ -35,33 +35,9 @@ def test_decode_logits_match_oracle_reforward(tiny_meta):
     llm, dna, prot = R.cfgs_from_meta(c)
     sd = tiny_state_dict(tiny_meta)
 
-    def oracle_last_logits(new_tokens):
-        """full forward over prompt + new tokens with HF generate's position ids (cumsum(mask)-1)."""
-        B = ids.shape[0]
-        hs = R.omics_inputs_embeds(sd, llm, dna, prot, {"input_ids": ids, "omic_ids": omic, "omic_info_list": info},
-                                   {"dna_rna": c["K"], "protein": c["K"]})
-        full_mask = mask
-        if new_tokens.shape[1]:
-            hs = torch.cat([hs, torch.nn.functional.embedding(new_tokens, sd["model.model.embed_tokens.weight"])], 1)
-            full_mask = torch.cat([mask, torch.ones(B, new_tokens.shape[1], dtype=torch.long)], 1)
-        T = hs.shape[1]
-        pos = (full_mask.cumsum(1) - 1).clamp(min=0)
-        outs = []
-        for b in range(B):                       # per-sample positions: run each sample with its own rope table
-            cos, sin = R.rope_cos_sin(pos[b], llm.head_dim, llm.rope_theta)
-            bias = R.causal_pad_bias(full_mask[b:b + 1], 1, T, torch.float32)
-            h = hs[b:b + 1]
-            for i in range(llm.num_hidden_layers):
-                lp = f"model.model.layers.{i}."
-                r_ = h
-                h = R.rmsnorm(h, sd[lp + "input_layernorm.weight"], llm.rms_norm_eps)
-                h = r_ + R.qwen3_attention(sd, lp + "self_attn.", llm, h, cos, sin, bias)
-                r_ = h
-                h = R.rmsnorm(h, sd[lp + "post_attention_layernorm.weight"], llm.rms_norm_eps)
-                h = r_ + R.qwen3_mlp(sd, lp + "mlp.", h)
-            h = R.rmsnorm(h, sd["model.model.norm.weight"], llm.rms_norm_eps)
-            outs.append(torch.nn.functional.linear(h[:, -1], sd["model.model.embed_tokens.weight"]))
-        return torch.cat(outs, 0)
+    batch = {"input_ids": ids, "attention_mask": mask, "omic_ids": omic, "omic_info_list": info}
+    oracle_last_logits = lambda new_tokens: R.generate_last_logits(sd, llm, dna, prot, batch, new_tokens,
+                                                                   {"dna_rna": c["K"], "protein": c["K"]})
 
     new = torch.empty(2, 0, dtype=torch.long)
     for step in range(5):
@@ -128,3 +104,42 @@ def test_lora_adapter_merge_peft_layout(tiny_meta, tiny_gold, tmp_path):
     valid = batch["attention_mask"].bool()
     err = (out.logits.float().cpu() - ref)[valid].abs().max().item()
     assert err <= 3e-2 * ref.abs().max().item(), err
+
+
+def test_greedy_decode_follows_the_reference_generate_golden(tiny_meta):
+    """G7: the 8 tokens the REFERENCE's `OmicsOne.generate(do_sample=False)` produced for three left-padded prompts of
+    different lengths (tests/golden/generate_g7.json, made by tests/golden/gen_golden_generate.py).  Teacher-forced with the
+    reference's tokens: the HIP path's argmax must be the reference's token wherever the reference's own top-1/top-2 margin
+    is not a near-tie under bf16 (0.05), and in its top-2 otherwise."""
+    import json
+    import os
+    from molly_amd.generate import GenerationSession
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "generate_g7.json")))
+    m = build_tiny(tiny_meta)
+    ids, mask = torch.tensor(g["input_ids"]), torch.tensor(g["attention_mask"])
+    omic, info = torch.tensor(g["omic_ids"]), g["omic_info_list"]
+    ref, margins = torch.tensor(g["new_tokens"]), torch.tensor(g["margins"])           # [B, n], [n, B]
+    sess = GenerationSession(m, g["n_new"])
+    logits = sess.prefill(ids, mask, omic, info)
+    strict = 0
+    for t in range(g["n_new"]):
+        top2 = logits.float().topk(2, dim=-1).indices.cpu()
+        for b in range(ids.shape[0]):
+            if margins[t, b] > 0.05:
+                assert top2[b, 0] == ref[b, t], (t, b, top2[b].tolist(), int(ref[b, t]))
+                strict += 1
+            else:
+                assert int(ref[b, t]) in top2[b].tolist(), (t, b)
+        if t + 1 < g["n_new"]:
+            logits = sess.step(ref[:, t].cuda())
+    assert strict >= 12
+    # free-running API call: same tokens as long as no near-tie was crossed
+    with torch.no_grad():
+        out = m.generate(input_ids=ids, attention_mask=mask, omic_ids=omic, omic_info_list=info, do_sample=False,
+                         max_new_tokens=g["n_new"]).cpu()
+    assert out.shape == ref.shape
+    for b in range(ids.shape[0]):
+        for t in range(g["n_new"]):
+            if margins[t, b] <= 0.05:
+                break
+            assert out[b, t] == ref[b, t], (b, t)

@@ -78,3 +78,28 @@ def test_index_outputs_bit_exact():
 def test_group_omics_errors():
     with pytest.raises(ValueError):
         R.group_omics([[torch.ones(4, dtype=torch.long)]], [[{"type": "lipid", "start": 3}]])
+
+
+def test_oracle_greedy_decode_reproduces_the_reference_generate(tiny_meta):
+    """G7: tokens produced by the REFERENCE's `OmicsOne.generate(do_sample=False)` on left-padded prompts
+    (tests/golden/generate_g7.json <- tests/golden/gen_golden_generate.py).  The oracle's re-forward with HF generate's
+    position ids must pick the same token at every step, and see the same top-1/top-2 margin."""
+    import json
+    import os
+    import torch
+    from conftest import tiny_state_dict
+    from oracle import molly_ref as R
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "generate_g7.json")))
+    c = tiny_meta["config"]
+    llm, dna, prot = R.cfgs_from_meta(c)
+    sd = tiny_state_dict(tiny_meta)
+    batch = {"input_ids": torch.tensor(g["input_ids"]), "attention_mask": torch.tensor(g["attention_mask"]),
+             "omic_ids": torch.tensor(g["omic_ids"]), "omic_info_list": g["omic_info_list"]}
+    ref = torch.tensor(g["new_tokens"])
+    with torch.no_grad():
+        for t in range(g["n_new"]):
+            lg = R.generate_last_logits(sd, llm, dna, prot, batch, ref[:, :t], {"dna_rna": c["K"], "protein": c["K"]})
+            top = lg.topk(2, dim=-1)
+            assert torch.equal(top.indices[:, 0], ref[:, t]), t
+            margin = top.values[:, 0] - top.values[:, 1]
+            assert torch.allclose(margin, torch.tensor(g["margins"][t]), atol=2e-3), (t, margin)
