@@ -131,3 +131,37 @@ def test_train_bio_steps_reduce_loss_and_move_encoders(tiny_meta):
     for n, off in rt.P.offsets.items():
         if n.startswith(("dna_rna_model.", "protein_model.")):
             assert (off >= m.n_decay) == (n.endswith("bias") or "norm" in n.lower()), n
+
+
+def test_encoder_gradients_vs_reference_golden(tiny_meta, tiny_gold):
+    """The same gradients from the REFERENCE's autograd (tests/golden/tiny_trainbio.npz) on the golden batch."""
+    import os
+    import numpy as np
+    from conftest import GOLD, tiny_batch
+    g = dict(np.load(os.path.join(GOLD, "tiny_trainbio.npz"), allow_pickle=False))
+    m = _build(tiny_meta, train_bio=True)
+    b = tiny_batch(tiny_gold, tiny_meta)
+    loss = m.forward_backward(*_args(b))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) <= 3e-3
+    G = m._rt.G.views
+    names = [k[len("gnorm/"):] for k in g if k.startswith("gnorm/")]
+    worst = 0.0
+    for n in names:
+        got = G[n].float().cpu()
+        head = torch.from_numpy(g["ghead/" + n])
+        ref_norm = float(g["gnorm/" + n])
+        scale = head.abs().max().item()
+        if n.endswith("key.bias"):               # ~zero by construction (see the oracle test above): query-bias scale
+            scale = max(scale, float(np.abs(g["ghead/" + n.replace("key.bias", "query.bias")]).max()))
+            assert (got.flatten()[:256] - head).abs().max().item() <= 0.25 * scale, n
+            continue
+        if scale == 0.0:
+            continue
+        # the stored head is 256 entries: judge it on the tensor's own scale (its rms from the stored norm) as well
+        scale = max(scale, 4.0 * ref_norm / got.numel() ** 0.5)
+        rel = (got.flatten()[:256] - head).abs().max().item() / scale
+        worst = max(worst, rel)
+        assert rel < 8e-2, (n, rel)
+        assert abs(got.double().norm().item() - ref_norm) <= 4e-2 * ref_norm + 1e-6, n
+    print("worst relative error vs the reference's gradients", worst)

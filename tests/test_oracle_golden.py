@@ -103,3 +103,30 @@ def test_oracle_greedy_decode_reproduces_the_reference_generate(tiny_meta):
             assert torch.equal(top.indices[:, 0], ref[:, t]), t
             margin = top.values[:, 0] - top.values[:, 1]
             assert torch.allclose(margin, torch.tensor(g["margins"][t]), atol=2e-3), (t, margin)
+
+
+def test_oracle_encoder_gradients_match_reference_trainbio_golden(tiny_meta, tiny_gold):
+    """Gradients of every encoder tensor from the REFERENCE's autograd (tests/golden/tiny_trainbio.npz <-
+    gen_golden_trainbio.py, `--train-bio` semantics) against the oracle's autograd on the same batch."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLD, tiny_batch, tiny_state_dict
+    from oracle import molly_ref as R
+    g = dict(np.load(os.path.join(GOLD, "tiny_trainbio.npz"), allow_pickle=False))
+    sd = tiny_state_dict(tiny_meta)
+    names = [k[len("gnorm/"):] for k in g if k.startswith("gnorm/")]
+    assert len(names) >= 60 and all(n in sd for n in names)
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd.update(leaves)
+    c = tiny_meta["config"]
+    llm, dna, prot = R.cfgs_from_meta(c)
+    loss, _ = R.omics_forward(sd, llm, dna, prot, tiny_batch(tiny_gold, tiny_meta), {"dna_rna": c["K"], "protein": c["K"]})
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-5
+    for n in names:
+        got = leaves[n].grad
+        ref_norm = float(g["gnorm/" + n])
+        assert abs(got.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + 1e-9, n
+        head = torch.from_numpy(g["ghead/" + n])
+        assert (got.flatten()[:256] - head).abs().max().item() <= 2e-4 * max(head.abs().max().item(), 1e-9) + 1e-9, n
