@@ -114,7 +114,13 @@ class Zero2Optimizer:
         self.P_out = flat_params                # AdamW writes here; the all-gather publishes into P (same buffer in production)
         self.hooked = False                     # set by OmicsOne.attach_optimizer: somebody will call wait_params()
         if self.overlap:
-            self.cstream = torch.cuda.Stream(device=dev)
+            if self.world > 1:
+                # RCCL's collective kernels hold CUs for milliseconds.  The persistent GEMM launches exactly one block per
+                # CU, each owning 1/256 of the tiles: with a few CUs taken, the blocks that cannot start wait for a whole
+                # share to finish and the launch takes twice as long.  One block per tile degrades by the CUs taken only.
+                from .. import ops
+                ops.lib().call("molly_gemm_set_persistent_blocks", 0)
+            self.cstream = torch.cuda.Stream(device=dev, priority=-1)     # collectives first whenever CUs free up
             self._rs_done = [False] * len(self.buckets)
             self._ag_events = [None] * len(self.buckets)
             self._ag_waited = [True] * len(self.buckets)
