@@ -17,7 +17,9 @@ BF16 = torch.bfloat16
 
 
 class GenerationSession:
-    def __init__(self, model, max_new_tokens: int):
+    def __init__(self, model, max_new_tokens: int, use_graph: bool = None):
+        import os
+        self.use_graph = (os.environ.get("MOLLY_DECODE_GRAPH", "1") != "0") if use_graph is None else use_graph
         self.m = model
         self.rt = model._runtime()
         self.eng = self.rt.llm
@@ -97,7 +99,13 @@ class GenerationSession:
         z = lambda *s: torch.empty(*s, dtype=BF16, device=dev)
         self.s = dict(x=z(B, e.h), xn=z(B, e.h), qkv=z(B, e.nqkv), qk=z(B, e.nqk), attn=z(B, e.nh * e.hd), x2=z(B, e.h),
                       xn2=z(B, e.h), gu=z(B, 2 * e.ff), act=z(B, e.ff), hn=z(B, e.h))
-        self.hi = torch.empty(B, dtype=torch.int32, device=dev)
+        # static per-step state (device): token ids, position ids, cache slot and visible-key bound of the step's token
+        self.tok = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.pos = self.n_valid.clone()                                        # position id = number of valid tokens so far
+        self.slot = torch.arange(B, device=dev, dtype=torch.int32) * self.Tmax + self.cur_len
+        self.hi = torch.full((B,), self.cur_len + 1, dtype=torch.int32, device=dev)
+        self.logits = torch.empty(B, e.V, dtype=torch.float32, device=dev)
+        self._graph, self._steps_done = None, 0
         self.dec_ws = ops.attn_decode_workspace(B, e.nh, e.hd, dev)
         # decode GEMMs are M = B rows against whole weight matrices: the library splits K over the chip and needs slab space
         ops.ensure_gemm_workspace(32 * 4 * max(B, 8) * max(2 * e.ff, e.nqkv), dev)
@@ -108,19 +116,12 @@ class GenerationSession:
         return ops.gemm_nt(hn, e.head, out_dtype=torch.float32)
 
     # ---- one decode step ------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def step(self, token_ids: torch.Tensor) -> torch.Tensor:
-        """token_ids int64 [B] (the tokens chosen from the previous logits).  Returns next-token logits [B, V] fp32."""
+    def _step_body(self) -> torch.Tensor:
+        """All device work of one step, reading/writing only the session's static tensors (tok, pos, slot, hi, caches), so
+        the launch sequence is identical every step and can be replayed from a hipGraph."""
         e, s, B = self.eng, self.s, self.B
-        dev = self.rt.dev
-        t = self.cur_len                                                       # cache slot of this token
-        assert t < self.Tmax, "generation budget exhausted"
-        ops.copy_rows(e.embed, s["x"], B, src_idx64=token_ids.to(dev))
-        positions = self.n_valid.clone()                                       # position id = number of valid tokens so far
-        self.n_valid += 1
-        self.hi.fill_(t + 1)
-        slot = (torch.arange(B, device=dev, dtype=torch.int32) * self.Tmax + t)
         nq, nkvd = e.nh * e.hd, e.nkv * e.hd
+        ops.copy_rows(e.embed, s["x"], B, src_idx64=self.tok)
         x = s["x"]
         for i in range(e.L):
             w = e.W[i]
@@ -130,11 +131,11 @@ class GenerationSession:
             self._lora(i, "k_proj", s["xn"], s["qkv"][:, nq:nq + nkvd])
             self._lora(i, "v_proj", s["xn"], s["qkv"][:, nq + nkvd:])
             ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin,
-                              positions=positions, eps=e.cfg.rms_norm_eps)
-            ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=slot)
-            ops.copy_rows(s["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B, dst_idx32=slot)
+                              positions=self.pos, eps=e.cfg.rms_norm_eps)
+            ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
+            ops.copy_rows(s["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
             ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
-                            e.hd ** -0.5, kv_len_hint=t + 1, workspace=self.dec_ws)
+                            e.hd ** -0.5, kv_len_hint=self.Tmax, workspace=self.dec_ws)
             ops.gemm_nt(s["attn"], w["o"], out=s["x2"], res=x)
             self._lora(i, "o_proj", s["attn"], s["x2"])
             ops.rmsnorm_fwd(s["x2"], w["ln2"], e.cfg.rms_norm_eps, out=s["xn2"])
@@ -145,8 +146,32 @@ class GenerationSession:
             ops.gemm_nt(s["act"], w["down"], out=s["x"], res=s["x2"])
             self._lora(i, "down_proj", s["act"], s["x"])
             x = s["x"]
+        ops.rmsnorm_fwd(x, e.norm_w, e.cfg.rms_norm_eps, out=s["hn"])
+        ops.gemm_nt(s["hn"], e.head, out=self.logits)
+        # advance the per-sample position / cache slot / visible-key bound for the next step (device-side, graph-replayable)
+        self.pos += 1
+        self.slot += 1
+        self.hi += 1
+        return self.logits
+
+    @torch.no_grad()
+    def step(self, token_ids: torch.Tensor) -> torch.Tensor:
+        """token_ids int64 [B] (the tokens chosen from the previous logits).  Returns next-token logits [B, V] fp32 (a
+        buffer that the next step overwrites).  The first step runs eagerly (it also sizes workspaces and sets kernel
+        attributes), the second is captured into a hipGraph, later steps replay it: ~340 launches become one."""
+        assert self.cur_len < self.Tmax, "generation budget exhausted"
+        self.tok.copy_(token_ids.to(self.rt.dev), non_blocking=True)
         self.cur_len += 1
-        return self._head(x)
+        self._steps_done += 1
+        if not self.use_graph or self._steps_done == 1:
+            return self._step_body()
+        if self._graph is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body()
+            self._graph = g          # capture does not execute: fall through to the replay
+        self._graph.replay()
+        return self.logits
 
 
 def _process_logits(logits, generated, temperature, top_k, top_p, repetition_penalty):
