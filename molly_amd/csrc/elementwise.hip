@@ -319,15 +319,13 @@ struct RopeBwdArgs {
 
 __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char sm_raw[];
-    float* sdw = reinterpret_cast<float*>(sm_raw);          // [2][hd]
+    float* sdw = reinterpret_cast<float*>(sm_raw);          // [256 / (hd/8) sub-groups][2 * hd] = 4096 floats
     const int half = p.hd >> 1;
     const int tph = half >> 2;
     const int heads_per_it = 256 / tph;
     const int i = (threadIdx.x % tph) * 4, sub = threadIdx.x / tph;
     const int nh = p.nq + p.nk;
     const long total = (long)p.M * nh;
-    for (int t = threadIdx.x; t < 2 * p.hd; t += 256) sdw[t] = 0.f;
-    __syncthreads();
     float dwq1[4] = {0, 0, 0, 0}, dwq2[4] = {0, 0, 0, 0}, dwk1[4] = {0, 0, 0, 0}, dwk2[4] = {0, 0, 0, 0};
     const long begin = (long)blockIdx.x * p.items_per_blk;
     const long end = min(begin + p.items_per_blk, total);
@@ -397,15 +395,24 @@ __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
             *reinterpret_cast<u32x2*>(d + i + half) = u32x2{pack_bf2(d2[0], d2[1]), pack_bf2(d2[2], d2[3])};
         }
     }
+    // block partial of the gain gradients, in a FIXED order (no LDS atomics: their arrival order would make the fp32 sums —
+    // and once in a while a bf16 rounding of the result — differ from run to run): every thread parks its 16 sums in its own
+    // row [sub][2*hd], then 2*hd threads add the rows top to bottom
+    __syncthreads();
+    float* row = sdw + (size_t)sub * 2 * p.hd;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        atomicAdd(&sdw[i + e], dwq1[e]);
-        atomicAdd(&sdw[i + e + half], dwq2[e]);
-        atomicAdd(&sdw[p.hd + i + e], dwk1[e]);
-        atomicAdd(&sdw[p.hd + i + e + half], dwk2[e]);
+        row[i + e] = dwq1[e];
+        row[i + e + half] = dwq2[e];
+        row[p.hd + i + e] = dwk1[e];
+        row[p.hd + i + e + half] = dwk2[e];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 2 * p.hd; t += 256) p.dw_part[(size_t)blockIdx.x * 2 * p.hd + t] = sdw[t];
+    for (int t = threadIdx.x; t < 2 * p.hd; t += 256) {
+        float acc = 0.f;
+        for (int sb = 0; sb < heads_per_it; ++sb) acc += sdw[(size_t)sb * 2 * p.hd + t];
+        p.dw_part[(size_t)blockIdx.x * 2 * p.hd + t] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1061,7 +1068,7 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
     ipb = (ipb + hpi - 1) / hpi * hpi;
     RopeBwdArgs p{(const bf16_t*)src, (const bf16_t*)g, (bf16_t*)dsrc, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w,
                   cos, sin, positions, workspace, M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_g, ld_out, eps, ipb, q_scale};
-    hipLaunchKernelGGL(norm_rope_bwd_kernel, dim3(nb), dim3(256), 2 * head_dim * sizeof(float), ST, p);
+    hipLaunchKernelGGL(norm_rope_bwd_kernel, dim3(nb), dim3(256), 4096 * sizeof(float), ST, p);
     MOLLY_LAUNCH_CHECK();
     if (q_norm_w) {
         MOLLY_CHECK(dq_w && dk_w, "norm_rope_bwd: gain gradients requested without output pointers");
