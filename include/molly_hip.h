@@ -192,7 +192,7 @@ int molly_dropout_bf16(void* stream, const void* x, void* out, long n, float p, 
 int molly_scale_bf16(void* stream, void* x, long n, float s);
 
 /* ------------------------------------------------------------------------------------------------
- * layout / instruction probes (used by tests/test_gpu_probes.py to pin the gfx950 operand maps the
+ * layout / instruction probes (used by tests/test_gpu_kernels.py::test_probe_* to pin the gfx950 operand maps the
  * kernels rely on; not part of the product path) */
 int molly_probe_mfma16(void* stream, const void* A16x32, const void* B16x32, float* D16x16);
 int molly_probe_tr16(void* stream, const void* tile_in, void* lanes_out /* [64][4] u16 */, int row_stride_elems);
