@@ -175,7 +175,6 @@ def main():
         b = batches[i % len(batches)]
         loss = m.forward_backward(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"], b["labels"])
         opt.step(lr=3e-5)
-        rt.llm.refresh_transposed_weights()
         return loss
 
     for i in range(args.warmup):

@@ -53,14 +53,14 @@ int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const v
 /* fp32 scratch the GEMM may use for split-K partial slabs (wgrad shapes whose 256x256 grid would not fill the chip);
  * caller-owned device memory, stays valid until replaced; NULL / 0 disables split-K. */
 int molly_gemm_set_workspace(void* ptr, long bytes);
-/* configuration the most recent GEMM call used: 128 | 256 | 512 (= the 256x256 ping-pong kernel) + 1000 * split-K factor */
+/* configuration the most recent GEMM call used: 128 (128x128 kernel) | 512 (the 256x256 ping-pong kernel) + 1000 * split-K factor */
 int molly_gemm_last_config(void);
 /* tuning hook: M-tiles per group in the 256x256 kernel's tile walk (L2 locality; default 4) */
 int molly_gemm_set_group_m(int g);
 /* tuning hook: resident blocks of the persistent 256x256 kernel (default 256 = one per CU; multiple of 8);
  * 0 = launch one block per tile. */
 int molly_gemm_set_persistent_blocks(int n);
-/* tuning/test hook: 0 = heuristic tile choice, 128 / 256 = force that BM tile configuration of the GEMM kernel. */
+/* tuning/test hook: 0 = heuristic, 128 = force the 128x128 kernel, 512 = force the 256x256 kernel. */
 int molly_gemm_force_tile(int bm);
 
 /* out[C,R] = in[R,C]^T (bf16).  Used to keep W^T copies for dgrad and X^T / dY^T for wgrad. */

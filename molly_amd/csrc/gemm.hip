@@ -9,11 +9,12 @@
 // k-major tiles are staged row-major [64 k][cols] and their MFMA fragments are gathered with ds_read_b64_tr_b16
 // (guide T10), so no operand is ever transposed in HBM.
 //
-// Two tile configurations of one kernel template:
-//   <BM=256, 3 stages>  8 waves (4x2, 64x64 each), 144 KiB LDS ring, ONE raw s_barrier per K-step, tiles t+1 and t+2
-//                       in flight behind a COUNTED s_waitcnt vmcnt(6) (guide §5 "Pipelining across barriers": LDS-DMA
-//                       spans the barrier, never drained to 0 in the loop).  Used when the grid fills the chip.
-//   <BM=128, 2 stages>  4 waves (2x2), 64 KiB LDS, 2 blocks/CU — small / skinny problems.
+// Two kernels:
+//   gemm256_kernel  256x256x64 tile, 8 waves, all 160 KiB of LDS, persistent, ping-pong wave groups (described at the
+//                   kernel) — every grid that fills the chip, and through split-K the long-K / skinny ones.
+//   gemm_kernel     128x128x64 tile, 4 waves (2x2, 64x64 each), 64 KiB LDS, 2 blocks per CU — what is left.
+//                   (A 256x128 3-stage ring and a BK=32 variant of this template were built and measured slower than
+//                   both on every step shape; they are not instantiated.)
 // Common: mfma_f32_16x16x32_bf16, global_load_lds 16 B/lane staging with the swizzle on the SOURCE address (LDS image
 // is lane-linear), XOR-swizzled chunks (conflict-free ds_read_b128 / tr reads), XCD-aware tile order, MFMA operands
 // passed swapped so every lane owns 4 CONSECUTIVE n of one row m (8-byte bf16 / 16-byte fp32 stores).
@@ -614,11 +615,9 @@ __device__ bf16_t g_zero_page[64];      // zero-initialised device memory (k-row
 
 template <bool AT, bool BT, bool TO = false>
 int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
-    // force_tile: 0 heuristic | 128 = <128,2 stages,BK64> | 256 = <256,3 stages,BK64> | 32 = <128,2 stages,BK32>
+    // force_tile: 0 heuristic | 128 = gemm_kernel<128, 2 stages, BK 64> | 512 = gemm256_kernel
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 256, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  3 * (256 + BN) * 64 * 2);
         (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 128, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * (128 + BN) * 64 * 2);
         attr_set = true;
@@ -686,14 +685,6 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
     } else if constexpr (TO) {
         molly_set_error("gemm: transposed output is only built into the 256x256 kernel");
         return 1;
-    } else if (force_tile == 256) {
-        p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, BN);
-        hipLaunchKernelGGL((gemm_kernel<AT, BT, 256, 3, 64>), dim3(p.tiles_m * p.tiles_n), dim3(512),
-                           3 * (256 + BN) * 64 * sizeof(bf16_t), st, p);
-    } else if (force_tile == 32) {
-        p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, BN);
-        hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 32>), dim3(p.tiles_m * p.tiles_n), dim3(256),
-                           2 * (128 + BN) * 32 * sizeof(bf16_t), st, p);
     } else {
         p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, BN);
         hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
@@ -787,7 +778,7 @@ extern "C" int molly_gemm_set_persistent_blocks(int n) {
 
 // tuning/test hook: 0 = heuristic, 128 or 256 = force that BM tile configuration
 extern "C" int molly_gemm_force_tile(int bm) {
-    MOLLY_CHECK(bm == 0 || bm == 128 || bm == 256 || bm == 32 || bm == 512, "gemm_force_tile: %d not in {0,32,128,256,512}", bm);
+    MOLLY_CHECK(bm == 0 || bm == 128 || bm == 512, "gemm_force_tile: %d not in {0,128,512}", bm);
     g_force_tile = bm;
     return 0;
 }

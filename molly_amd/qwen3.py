@@ -8,7 +8,9 @@ autograd graph and no tracing; every saved activation lives in a pre-allocated H
 
 GEMM forms: forward  y = x W^T          -> A=x k-contiguous, B=W k-contiguous
                         dgrad    dx = dy W           -> A=dy k-contiguous, B=W k-major        (no W^T copy)
-                        wgrad    dW = dy^T x         -> A=dy k-major, B=x k-major, K = tokens (no activation transposes)
+                        wgrad    dW = dy^T x         -> the narrower operand transposed once (tr-read kernel), then
+                                                        k-contiguous A x k-major B with the result stored transposed;
+                                                        token counts that are not a multiple of 64: both operands k-major
 """
 from __future__ import annotations
 
@@ -86,10 +88,6 @@ class Qwen3Engine:
             self.d_embed = self.G.views[self.pre + "model.embed_tokens.weight"]
             self.d_head = self.d_embed if self.cfg.tie_word_embeddings else self.G.views[self.pre + "lm_head.weight"]
             self.d_norm_w = self.G.views[self.pre + "model.norm.weight"]
-
-    def refresh_transposed_weights(self):
-        """kept for API stability: the dgrad GEMMs read W in place (k-major operand), nothing to refresh."""
-        return
 
     # ---- activation slabs -----------------------------------------------------------------------------------
     def reserve(self, M: int, B: int, T: int, training: bool):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GEMM micro-benchmark on the shapes of Molly-1.7B's train step (random data, HIP events, interleaved rounds in one
-process — guide §5.4 rules 24/25).  python tools/bench_gemm.py [--tiles 128 256]"""
+process — guide §5.4 rules 24/25).  python tools/bench_gemm.py [--tiles 0 128 512] [--torch]"""
 import argparse
 import os
 import sys
@@ -27,7 +27,7 @@ SHAPES = [  # (name, form, M, N, K)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tiles", type=int, nargs="+", default=[128, 256])
+    ap.add_argument("--tiles", type=int, nargs="+", default=[0, 128])
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--torch", action="store_true", help="add a torch.matmul (hipBLASLt/rocBLAS) column for orientation")
