@@ -60,6 +60,9 @@ int molly_gemm_set_group_m(int g);
 /* tuning hook: resident blocks of the persistent 256x256 kernel (default 256 = one per CU; multiple of 8);
  * 0 = launch one block per tile. */
 int molly_gemm_set_persistent_blocks(int n);
+/* tuning hook: barrier schedule of the 256x256 kernel: 0 = four phases (16 MFMAs each) per K-tile, 1 = two phases (32 MFMAs),
+ * -1 (default) = two phases for the forms with a k-major B operand, four for the rest (what measured faster). */
+int molly_gemm_set_schedule(int mode);
 /* tuning/test hook: 0 = heuristic, 128 = force the 128x128 kernel, 512 = force the 256x256 kernel. */
 int molly_gemm_force_tile(int bm);
 

@@ -288,9 +288,10 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 // Arithmetic intensity 128 flop/B of L2->LDS traffic (2x the 128² tile): the per-CU vector-memory path (64 B/clk) and
 // the matrix pipe are no longer at a 1:1 ridge.
 // ================================================================================================
-template <bool AT, bool BT, bool TO = false>
+template <bool AT, bool BT, bool TO = false, bool P2 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
+    constexpr int NWI = P2 ? 4 : 8;                   // waves that stage one operand
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);   // [buf][A0|A1|B0|B1][HT]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -329,14 +330,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // LDS = 10 half-tile slots (all 160 KiB): A triple-buffered [3][A0|A1], then B double-buffered [2][B0|B1]
     // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; ktl is slice-local
     auto issue = [&](int ktl, int which) {
+        // P2 schedule: wave group 0 stages the A half-tiles, group 1 the B half-tiles (8 LDS-DMA per wave per K-tile either way)
+        if (P2 && ((which < 2) != (wr == 0))) return;
+        const int wi = P2 ? wc : wave;
         const int kt = kt0 + ktl;
         bf16_t* dst = which < 2 ? smem + ((ktl % 3) * 2 + which) * HT : smem + (6 + (ktl & 1) * 2 + (which - 2)) * HT;
         if (which < 2) {
-            if (AT) stage_km<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, p.K, p.zeros, dst, wave, lane);
-            else stage_kc<128, 8, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, dst, wave, lane);
+            if (AT) stage_km<128, NWI, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, p.K, p.zeros, dst, wi, lane);
+            else stage_kc<128, NWI, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, dst, wi, lane);
         } else {
-            if (BT) stage_km<128, 8, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, p.K, p.zeros, dst, wave, lane);
-            else stage_kc<128, 8, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, dst, wave, lane);
+            if (BT) stage_km<128, NWI, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, p.K, p.zeros, dst, wi, lane);
+            else stage_kc<128, NWI, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, dst, wi, lane);
         }
     };
     const int fr = lane & 15, fq = lane >> 4;
@@ -406,6 +410,45 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // K-tile T+1 — has landed; its first ds_read happens in the next phase, behind a barrier both groups have passed.
     bf16x8 af[2][4], b0[2][2], b1[2][2];
     int abuf = 0;
+    if constexpr (P2) {
+        // TWO phases per K-tile (32 MFMAs per compute segment, 4 barriers per K-tile instead of 8):
+        //   LA: read B(n0), B(n1), A(m0)                              | CA: quadrants (m0,n0), (m0,n1)
+        //   LB: read A(m1); stage own operand of K-tile T+2; counted  | CB: quadrants (m1,n1), (m1,n0)
+        //       wait -> own pieces of T+1 have landed
+        // Group 0 stages A (slot (T+2)%3 = slot of T-1: its last reads, group 1's LB(T-1), returned two barriers ago), group 1
+        // stages B (slot of T: last read in its own LA(T), returned before its CA(T), one barrier ago; group 0's a segment
+        // earlier still).  Each piece is waited for by the wave that issued it one K-tile later, in front of a barrier every
+        // reader passes before its first read.  Measured against the 4-phase schedule in one process (tools/bench_gemm.py
+        // --sched): +3-4 % on the forms whose B operand is k-major (dgrad, wgrad; +13 % on TN), -1...-6 % on NT — the
+        // launcher picks per form.  (Staging B from group 1's LA — more flight time — was slower and races with group 0's
+        // reads of that slot, which only return during the same segment.)
+        for (int T = 0; T < nk; ++T) {
+            const int bbuf = T & 1;
+            readB(bbuf, 0, b0);
+            readB(bbuf, 1, b1);
+            readA(abuf, 0, af);
+            SEG_BARRIER();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MMA_QUAD(0, 0, af, b0);
+            MMA_QUAD(0, 1, af, b1);
+            SEG_BARRIER();
+            readA(abuf, 1, af);
+            if (T + 2 < nk) {
+                issue(T + 2, 0); issue(T + 2, 1); issue(T + 2, 2); issue(T + 2, 3);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            SEG_BARRIER();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MMA_QUAD(1, 1, af, b1);
+            MMA_QUAD(1, 0, af, b0);
+            SEG_BARRIER();
+            abuf = abuf == 2 ? 0 : abuf + 1;
+        }
+    } else {
     for (int T = 0; T < nk; ++T) {
         const int bbuf = T & 1;
         // ---- P0: quadrant (m0,n0)
@@ -443,6 +486,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         MMA_QUAD(1, 0, af, b0);
         SEG_BARRIER();
         abuf = abuf == 2 ? 0 : abuf + 1;
+    }
     }
     if (wr == 0) SEG_BARRIER();               // balance the stagger barrier (every LDS read of this tile has returned)
 
@@ -606,6 +650,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int g_group_m = 4;
+int g_schedule = -1;              // 256x256 kernel: -1 = per form, 0 = four phases per K-tile, 1 = two phases per K-tile
 int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile
 int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 float* g_ws = nullptr;
@@ -665,7 +710,8 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
     if (force_tile == 512) {
         static bool a2 = false;
         if (!a2) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             a2 = true;
         }
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
@@ -673,7 +719,9 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
         // persistent: at most g_persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
         const int grid = g_persist_blocks > 0 ? min(nwork, g_persist_blocks) : nwork;
-        hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO>), dim3(grid), dim3(512), 163840, st, p);
+        // two-phase schedule where it measured faster: a k-major B operand (dgrad, wgrad); -1 = this choice, 0 / 1 = forced
+        if (g_schedule == 1 || (g_schedule < 0 && BT)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
+        else hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false>), dim3(grid), dim3(512), 163840, st, p);
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, p.ws,
@@ -767,6 +815,12 @@ extern "C" int molly_gemm_last_config(void) { return g_last_cfg; }
 extern "C" int molly_gemm_set_group_m(int g) {
     MOLLY_CHECK(g >= 1 && g <= 64, "gemm_set_group_m: %d", g);
     g_group_m = g;
+    return 0;
+}
+
+extern "C" int molly_gemm_set_schedule(int mode) {
+    MOLLY_CHECK(mode >= -1 && mode <= 1, "gemm_set_schedule: %d not in {-1,0,1}", mode);
+    g_schedule = mode;
     return 0;
 }
 

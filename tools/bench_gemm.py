@@ -31,12 +31,16 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--torch", action="store_true", help="add a torch.matmul (hipBLASLt/rocBLAS) column for orientation")
+    ap.add_argument("--sched", type=int, nargs="+", default=None,
+                    help="compare barrier schedules of the 256x256 kernel: 0 four-phase, 1 two-phase, -1 per-form default")
     ap.add_argument("--persist", type=int, nargs="+", default=None,
                     help="compare resident-block counts of the persistent 256x256 kernel (0 = one block per tile)")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
+    if args.sched is not None:
+        args.tiles = [800000 + 10 + x for x in args.sched]     # column key = 512 kernel with that schedule
     if args.persist is not None:
         args.tiles = [512000 + pv for pv in args.persist]      # column key = 512 kernel with that resident-block count
     print(f"{'shape':16s} {'form':4s} {'M':>7s} {'N':>7s} {'K':>7s} " + " ".join(f"{'BM' + str(t) + ' TF/s':>12s}" for t in args.tiles))
@@ -56,7 +60,10 @@ def main():
         best = {t: 1e9 for t in args.tiles}
         for r in range(args.rounds):
             for t in args.tiles:
-                if t >= 512000:
+                if t >= 800000:
+                    lib().call("molly_gemm_force_tile", 0)
+                    lib().call("molly_gemm_set_schedule", t - 800010)
+                elif t >= 512000:
                     lib().call("molly_gemm_force_tile", 512)
                     lib().call("molly_gemm_set_persistent_blocks", t - 512000)
                 else:
@@ -71,6 +78,7 @@ def main():
                 best[t] = min(best[t], e0.elapsed_time(e1) / 3)
         lib().call("molly_gemm_force_tile", 0)
         lib().call("molly_gemm_set_persistent_blocks", 256)
+        lib().call("molly_gemm_set_schedule", -1)
         fl = 2.0 * m * n * k
         tcol = ""
         if args.torch:
