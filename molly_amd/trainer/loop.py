@@ -54,7 +54,11 @@ def save_model(model, output_dir: str):
     """reference: OmicsTrainer.save_model (src/trainer/omics_trainer.py:85-105): under LoRA the PEFT adapter + the two
     projector .bin files; otherwise `pytorch_model.bin` with the reference's keys."""
     os.makedirs(output_dir, exist_ok=True)
-    if model._runtime().llm.lora is not None:
+    rt = model._runtime()
+    if getattr(rt, "opt", None) is not None:
+        rt.opt.wait_all_params()              # an overlapped all-gather of the last step may still be publishing parameters
+    torch.cuda.synchronize()
+    if rt.llm.lora is not None:
         from ..lora import save_adapter
         save_adapter(model, output_dir)
         return
