@@ -52,8 +52,9 @@ def main(argv=None):
     for f, d in [("--num_train_epochs", 1.0), ("--learning_rate", 3e-5), ("--warmup_ratio", 0.1), ("--weight-decay", 1e-2),
                  ("--eps", 1e-8)]:
         ap.add_argument(f, type=float, default=d)
+    ap.add_argument("--metric-for-best-model", default="eval_loss")
     for f in ("--train-mlp", "--train-llm", "--train-bio", "--bf16", "--no-load-pretrained", "--swanlab", "--save_only_model",
-              "--skip-eval", "--use-lora"):
+              "--skip-eval", "--use-lora", "--load_best_model_at_end", "--greater_is_better"):
         ap.add_argument(f, action="store_true")
     a = ap.parse_args(argv)
     lora = None
@@ -100,8 +101,18 @@ def main(argv=None):
                       gradient_accumulation_steps=a.gradient_accumulation_steps, num_train_epochs=a.num_train_epochs,
                       max_steps=a.train_iters, learning_rate=a.learning_rate, weight_decay=a.weight_decay,
                       warmup_ratio=a.warmup_ratio, adam_epsilon=a.eps, logging_steps=a.logging_steps, save_steps=a.save_steps,
-                      save_total_limit=a.save_total_limit or None, seed=a.seed)
-    tr = Trainer(m, ds, qwen_omics_collate_fn, targs)
+                      save_total_limit=a.save_total_limit or None, seed=a.seed,
+                      per_device_eval_batch_size=a.per_device_eval_batch_size, eval_steps=a.eval_steps,
+                      early_stopping_patience=a.early_stopping_patience, load_best_model_at_end=a.load_best_model_at_end)
+    eval_ds = None
+    if not a.skip_eval and a.eval_dataset_path:                  # reference: src/train.py:206-231
+        if a.metric_for_best_model != "eval_loss" or a.greater_is_better:
+            raise NotImplementedError("only eval_loss (lower is better) is tracked — the reference's default")
+        ecfg = DatasetConfig(max_len=a.eval_max_len, max_src_len=a.eval_max_src_len, mode=a.mode, cal_metric_pos=None,
+                             dna_rna_k_tokens=a.dna_rna_k_tokens, protein_k_tokens=a.protein_k_tokens)
+        eval_ds = OmicsDataset(a.eval_dataset_path, ToyTextTokenizer(), ecfg, dna_rna_tokenizer=ToyOmicTokenizer("dna"),
+                               protein_tokenizer=ToyOmicTokenizer("protein"), read_nums=a.eval_read_nums or None)
+    tr = Trainer(m, ds, qwen_omics_collate_fn, targs, eval_dataset=eval_ds)
     tr.train()
     if (not dist.is_initialized()) or dist.get_rank() == 0:
         save_model(m, a.output_dir)

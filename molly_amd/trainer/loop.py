@@ -48,6 +48,13 @@ class TrainArgs:
     save_steps: int = 0
     save_total_limit: Optional[int] = None
     seed: int = 42
+    # evaluation (HF `eval_strategy="steps"`; reference example: --eval_steps 25000 --eval_strategy steps)
+    per_device_eval_batch_size: int = 1
+    eval_steps: int = 0                       # 0 = never
+    early_stopping_patience: int = 0          # evaluations without improvement of eval_loss before stopping (0 = off);
+    #                                           the reference registers EarlyStoppingCallback(patience), which HF only
+    #                                           honours together with load_best_model_at_end (its scripts leave that off)
+    load_best_model_at_end: bool = False
 
 
 def save_model(model, output_dir: str):
@@ -71,8 +78,11 @@ def save_model(model, output_dir: str):
 
 
 class Trainer:
-    def __init__(self, model, train_dataset, collate_fn: Callable, args: TrainArgs, log_fn: Callable = print):
+    def __init__(self, model, train_dataset, collate_fn: Callable, args: TrainArgs, log_fn: Callable = print,
+                 eval_dataset=None):
         self.model, self.ds, self.collate, self.args, self.log = model, train_dataset, collate_fn, args, log_fn
+        self.eval_ds = eval_dataset
+        self.best_metric, self.best_step, self._bad_evals = None, None, 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         rt = model._runtime()
@@ -93,6 +103,47 @@ class Trainer:
         for mb in range(self.rank, n_micro - (n_micro % self.world if self.world > 1 else 0), self.world):
             idx = perm[mb * B:(mb + 1) * B]
             yield self.collate([self.ds[i] for i in idx])
+
+    @torch.no_grad()
+    def evaluate(self) -> float:
+        """HF `Trainer.evaluate` semantics for eval_loss (HF:trainer.py evaluation_loop): every batch's loss (its own token
+        mean) counts once per SAMPLE of the batch, the mean runs over all samples of all ranks.  Batches are dealt to ranks
+        round-robin, tail batch included."""
+        a, m = self.args, self.model
+        B = a.per_device_eval_batch_size
+        n = len(self.eval_ds)
+        acc = torch.zeros(2, dtype=torch.float64, device=m._rt.dev)              # [sum loss * samples, samples]
+        for mb, i0 in enumerate(range(0, n, B)):
+            if mb % self.world != self.rank:
+                continue
+            batch = self.collate([self.eval_ds[i] for i in range(i0, min(n, i0 + B))])
+            out = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], omic_ids=batch["omic_ids"],
+                    omic_info_list=batch["omic_info_list"], labels=batch["labels"])
+            k = batch["input_ids"].shape[0]
+            acc[0] += out.loss.double() * k
+            acc[1] += k
+        if self.world > 1:
+            dist.all_reduce(acc)
+        return float((acc[0] / acc[1]).item())
+
+    def _maybe_evaluate(self, step: int) -> bool:
+        """-> True when early stopping fires.  Tracks the best eval_loss (lower is better: the reference's
+        --metric-for-best-model default, src/train.py:543-548)."""
+        a = self.args
+        if self.eval_ds is None or not a.eval_steps or step % a.eval_steps:
+            return False
+        v = self.evaluate()
+        rec = {"step": step, "eval_loss": round(v, 4)}
+        self.history.append(rec)
+        if self.rank == 0:
+            self.log(json.dumps(rec))
+        if self.best_metric is None or v < self.best_metric:
+            self.best_metric, self.best_step, self._bad_evals = v, step, 0
+            if a.load_best_model_at_end and self.rank == 0:
+                save_model(self.model, os.path.join(a.output_dir, "best"))
+        else:
+            self._bad_evals += 1
+        return bool(a.early_stopping_patience) and a.load_best_model_at_end and self._bad_evals >= a.early_stopping_patience
 
     def train(self):
         a, m = self.args, self.model
@@ -137,6 +188,8 @@ class Trainer:
                         self.log(json.dumps(rec))
                 if a.save_steps and step % a.save_steps == 0 and self.rank == 0:
                     self._save_checkpoint(step)
+                if self._maybe_evaluate(step):
+                    total = step                                   # early stopping: leave both loops
                 if step >= total:
                     break
             epoch += 1

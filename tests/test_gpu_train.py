@@ -155,3 +155,44 @@ def test_overlapped_comm_schedule_equals_synchronous(tiny_meta, tiny_gold):
     assert torch.equal(l0, l1), (l0, l1)
     assert torch.equal(p0, p1)
     assert l0[-1] < l0[0]
+
+
+def test_trainer_evaluation_eval_loss_and_early_stopping(tiny_meta, tmp_path):
+    """HF eval semantics: eval_loss = sample-weighted mean of the per-batch token-mean losses (tail batch smaller); records
+    every eval_steps; early stopping (with load_best_model_at_end, as HF requires) stops after `patience` non-improving
+    evaluations and leaves the best parameters under <output_dir>/best."""
+    from molly_amd.data import DatasetConfig, OmicsDataset, ToyOmicTokenizer, ToyTextTokenizer, qwen_omics_collate_fn
+    from molly_amd.trainer import TrainArgs, Trainer
+    mk = lambda n, off: [dict(task="Solubility-Solubility", input=f"Is <protein>{'MKTAYIAKQR' * (1 + (i + off) % 3)}</protein> soluble?",
+                              think="", output="Yes." if (i + off) % 2 else "No.", label=str(i % 2), kind="protein", task_num=i)
+                         for i in range(n)]
+    cfg = DatasetConfig(max_len=192, cal_metric_pos=None, dna_rna_k_tokens=64, protein_k_tokens=64)
+    tok = dict(dna_rna_tokenizer=ToyOmicTokenizer("dna"), protein_tokenizer=ToyOmicTokenizer("protein"))
+    train_ds = OmicsDataset(mk(16, 0), ToyTextTokenizer(), cfg, **tok)
+    eval_ds = OmicsDataset(mk(7, 1), ToyTextTokenizer(), cfg, **tok)           # 7 samples, batch 3 -> 3 + 3 + 1
+    m = build_tiny(tiny_meta)
+    args = TrainArgs(output_dir=str(tmp_path), per_device_train_batch_size=4, num_train_epochs=3, learning_rate=2e-3,
+                     logging_steps=100, per_device_eval_batch_size=3, eval_steps=2)
+    tr = Trainer(m, train_ds, qwen_omics_collate_fn, args, log_fn=lambda s: None, eval_dataset=eval_ds)
+    v = tr.evaluate()
+    with torch.no_grad():
+        per = []
+        for i0 in range(0, 7, 3):
+            b = qwen_omics_collate_fn([eval_ds[i] for i in range(i0, min(7, i0 + 3))])
+            per.append((m(input_ids=b["input_ids"], attention_mask=b["attention_mask"], omic_ids=b["omic_ids"],
+                          omic_info_list=b["omic_info_list"], labels=b["labels"]).loss.item(), b["input_ids"].shape[0]))
+    want = sum(l * k for l, k in per) / 7
+    assert abs(v - want) < 1e-5 and abs(v - sum(l for l, _ in per) / 3) > 1e-6      # weighted by samples, not by batches
+    hist = tr.train()
+    ev = [h for h in hist if "eval_loss" in h]
+    assert [h["step"] for h in ev] == [2, 4, 6, 8, 10, 12]
+    assert ev[-1]["eval_loss"] < ev[0]["eval_loss"] and tr.best_step is not None
+    # early stopping: a learning rate of 0 never improves after the first evaluation -> stops at the 1 + patience-th one
+    m2 = build_tiny(tiny_meta)
+    args2 = TrainArgs(output_dir=str(tmp_path / "es"), per_device_train_batch_size=4, num_train_epochs=10, learning_rate=0.0,
+                      weight_decay=0.0, logging_steps=100, per_device_eval_batch_size=4, eval_steps=1,
+                      early_stopping_patience=2, load_best_model_at_end=True)
+    tr2 = Trainer(m2, train_ds, qwen_omics_collate_fn, args2, log_fn=lambda s: None, eval_dataset=eval_ds)
+    h2 = tr2.train()
+    assert [h["step"] for h in h2 if "eval_loss" in h] == [1, 2, 3]
+    assert os.path.exists(os.path.join(str(tmp_path / "es"), "best", "pytorch_model.bin"))
