@@ -105,8 +105,13 @@ class Qwen3Engine:
             if self.lora is not None:
                 # s * (dropout(x) A^T) of every target, kept for the adapter gradients
                 self.A[-1]["lt"] = {m: e(M, self.lora.rp) for m in LORA_TARGETS}
+                if training and self.lora.p > 0.0:
+                    # dropout(x) of every target as well (0.6 GB per layer at 16 Ki tokens of Molly-1.7B — HBM is 288 GB):
+                    # the backward then reads it instead of regenerating the mask in another pass over x
+                    dims = {"q_proj": h, "k_proj": h, "v_proj": h, "o_proj": self.nh * self.hd, "gate_proj": h, "up_proj": h,
+                            "down_proj": ff}
+                    self.A[-1]["lxd"] = {m: e(M, d) for m, d in dims.items()}
         if self.lora is not None:
-            self.lora_xd = e(M * max(h, ff, self.nh * self.hd))       # dropout(x) of the target being processed
             self.lora_dt = e(M, self.lora.rp)
         self.x_out = e(M, h)
         self.hn = e(M, h)
@@ -205,18 +210,17 @@ class Qwen3Engine:
         return loss, logits_all
 
     # ---- LoRA branch (PEFT lora.Linear.forward: result + lora_B(lora_A(dropout(x))) * scaling) --------------------
-    def _lora_xd(self, i: int, mod: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+    def _lora_xd(self, i: int, a: dict, mod: str, x: torch.Tensor, training: bool) -> torch.Tensor:
         lo = self.lora
         if not (training and lo.p > 0.0):
             return x
-        xd = self.lora_xd[:x.numel()].view(x.shape)
-        return ops.dropout(x, lo.p, lo.mask_seed(i, mod), out=xd)
+        return ops.dropout(x, lo.p, lo.mask_seed(i, mod), out=a["lxd"][mod])
 
     def _lora_fwd(self, i: int, a: dict, mod: str, x: torch.Tensor, y: torch.Tensor, training: bool):
         """y += s * (dropout(x) A^T) B^T; keeps t = s * dropout(x) A^T for the backward."""
         lo = self.lora
         t = a["lt"][mod]
-        ops.gemm_nt(self._lora_xd(i, mod, x, training), lo.A[i][mod], out=t)
+        ops.gemm_nt(self._lora_xd(i, a, mod, x, training), lo.A[i][mod], out=t)
         if lo.scale != 1.0:
             ops.scale_(t, lo.scale)
         ops.gemm_nt(t, lo.B[i][mod], out=y, accumulate=True)
@@ -229,10 +233,10 @@ class Qwen3Engine:
         self._dgrad(dy, lo.B[i][mod], dt)
         if lo.scale != 1.0:
             ops.scale_(dt, lo.scale)
-        xd = self._lora_xd(i, mod, x, True)
+        xd = a["lxd"][mod] if lo.p > 0.0 else x                    # the forward's dropout(x), kept
         self._wgrad(dt, xd, lo.dA[i][mod], accumulate)
         if lo.p > 0.0:
-            tmp = self.lora_xd[:x.numel()].view(x.shape)           # dropout(x) is dead after the dA GEMM
+            tmp = xd                                               # dropout(x) is dead after the dA GEMM
             ops.gemm(dt, lo.A[i][mod], out=tmp, b_kmajor=True)
             ops.dropout(tmp, lo.p, lo.mask_seed(i, mod), out=dx, accumulate=True)
         else:
