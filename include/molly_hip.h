@@ -159,7 +159,9 @@ int molly_cast_bf16_to_f32(void* stream, const void* in, float* out, long n);
  * bidirectional hd=64 with key-padding mask (HF:models/esm/modeling_esm.py:292-317).
  * Q/K/V/O are token-major: row (b*T + t) with row stride ld*, head h at column h*head_dim.
  * mask = (causal ? key <= query : all) AND kv_lo[b] <= key < kv_hi[b]  (NULL = whole sequence).
- * lse2[B, n_heads, T] = log2-domain log-sum-exp of the scaled scores (saved for the backward). */
+ * lse2[B, n_heads, T] = log2-domain log-sum-exp of the scaled scores (saved for the backward).
+ * head_dim 64 | 128: MFMA kernel.  head_dim 8..48 (multiples of 8): a plain forward-only kernel for the mini encoders of the
+ * reference's plumbing config (ESM2-t6-8M has 320 / 20 = 16); molly_attn_bwd exists for 64 and 128 only. */
 int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2, const int* kv_lo,
                    const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv,
                    int ldo, float scale, int causal);

@@ -275,6 +275,61 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
 
 // ================================================================================================
+// Small head dims (8 <= hd <= 64, hd % 8 == 0, not 64): the mini encoders of the reference's plumbing config (ESM2-t6-8M:
+// 320 hidden / 20 heads = 16).  Forward only, plain VALU: one thread per query row, K/V tiles of 64 keys staged in LDS as
+// fp32 (every thread reads the same key row: LDS broadcast), online softmax in the exp2 domain.  Not a performance path.
+// ================================================================================================
+template <int HD>
+__global__ __launch_bounds__(128) void attn_fwd_small_kernel(AttnArgs p) {
+    __shared__ float sK[64][HD], sV[64][HD];
+    const int head = blockIdx.x % p.nh, b = blockIdx.x / p.nh;
+    const int kvh = head / (p.nh / p.nkv);
+    const int T = p.T;
+    const int lo = p.kv_lo ? p.kv_lo[b] : 0;
+    const int hi = p.kv_hi ? p.kv_hi[b] : T;
+    const int q = blockIdx.y * 128 + threadIdx.x;
+    const bool q_ok = q < T;
+    float qf[HD], acc[HD];
+    {
+        const bf16_t* qp = p.Q + ((size_t)b * T + (q_ok ? q : T - 1)) * p.ldq + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { qf[d] = bf2f(qp[d]) * p.scale_log2; acc[d] = 0.f; }
+    }
+    float m = -INFINITY, l = 0.f;
+    const int q_last = min(blockIdx.y * 128 + 127, T - 1);
+    const int k_end = p.causal ? min(hi, q_last + 1) : hi;
+    for (int k0 = lo - (lo % 64); k0 < k_end; k0 += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * HD; i += 128) {
+            const int r = i / HD, d = i % HD;
+            const int key = min(k0 + r, T - 1);
+            sK[r][d] = bf2f(p.K[((size_t)b * T + key) * p.ldk + kvh * HD + d]);
+            sV[r][d] = bf2f(p.V[((size_t)b * T + key) * p.ldv + kvh * HD + d]);
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r) {
+            const int key = k0 + r;
+            if (key < lo || key >= hi || (p.causal && key > q)) continue;      // per-thread only through `q`: cheap divergence
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s += qf[d] * sK[r][d];
+            const float mn = fmaxf(m, s);
+            const float c = fast_exp2(m - mn), pe = fast_exp2(s - mn);
+            l = l * c + pe;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * c + pe * sV[r][d];
+            m = mn;
+        }
+    }
+    if (!q_ok) return;
+    bf16_t* op = p.O + ((size_t)b * T + q) * p.ldo + head * HD;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = f2bf(acc[d] * inv);
+    if (p.LSE) p.LSE[((size_t)b * p.nh + head) * T + q] = l > 0.f ? m + __log2f(l) : -INFINITY;
+}
+
+// ================================================================================================
 // backward.  Two kernels, both recomputing P from Q,K and the forward's LSE (no atomics, bitwise reproducible):
 //   dq kernel : grid like the forward (query blocks); per key tile  S^T = K Q^T, dP^T = V dO^T,
 //               dS^T = P^T ⊙ (dP^T − δ),  dQ^T += K^T dS^T          (K tile read by rows AND transposed)
@@ -568,13 +623,24 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
 extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
                               const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim,
                               int ldq, int ldk, int ldv, int ldo, float scale, int causal) {
-    MOLLY_CHECK(head_dim == 128 || head_dim == 64, "attn_fwd: head_dim=%d not built (64 and 128 are)", head_dim);
+    MOLLY_CHECK(head_dim == 128 || head_dim == 64 || head_dim == 16 || head_dim == 32 || head_dim == 8 || head_dim == 24 ||
+                    head_dim == 40 || head_dim == 48,
+                "attn_fwd: head_dim=%d not built (64 and 128 on the MFMA kernel; 8..48 in steps of 8 on the small-head kernel)",
+                head_dim);
     MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_fwd: n_heads %% n_kv_heads != 0");
     MOLLY_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attn_fwd: row strides must be multiples of 8");
     MOLLY_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0, "attn_fwd: alignment");
     MOLLY_CHECK(B > 0 && T > 0, "attn_fwd: empty problem");
     AttnArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, lse2, kv_lo, kv_hi, T, n_heads,
                n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal};
+    if (head_dim < 64) {
+        const dim3 g(n_heads * B, cdiv(T, 128));
+#define MOLLY_SMALL(HD_) case HD_: hipLaunchKernelGGL(attn_fwd_small_kernel<HD_>, g, dim3(128), 0, (hipStream_t)stream, p); break
+        switch (head_dim) { MOLLY_SMALL(8); MOLLY_SMALL(16); MOLLY_SMALL(24); MOLLY_SMALL(32); MOLLY_SMALL(40); MOLLY_SMALL(48); }
+#undef MOLLY_SMALL
+        MOLLY_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(n_heads * B, cdiv(T, BQ));
     const size_t lds = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
     static bool attr_set = false;

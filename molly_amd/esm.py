@@ -34,8 +34,11 @@ class EsmEngine:
         self.cfg, self.P, self.dev, self.pre = cfg, params, device, prefix + "esm."
         self.he, self.nh = cfg.hidden_size, cfg.num_attention_heads
         self.hd = self.he // self.nh
-        if self.hd not in (64, 128):
-            raise NotImplementedError(f"encoder head_dim={self.hd}: the attention kernel is built for 64 and 128")
+        if self.hd not in (8, 16, 24, 32, 40, 48, 64, 128):
+            raise NotImplementedError(f"encoder head_dim={self.hd}: attention is built for 64/128 (MFMA) and 8..48 (small)")
+        if grads is not None and self.hd not in (64, 128):
+            raise NotImplementedError(f"--train-bio with encoder head_dim={self.hd}: the attention backward is built for "
+                                      f"64 and 128 (mini encoders are forward-only)")
         self.ffe = cfg.intermediate_size
         self.rope_table_dtype = rope_table_dtype
         self.G = grads

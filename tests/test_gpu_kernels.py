@@ -237,7 +237,8 @@ def _attn_ref(q, k, v, B, T, nh, nkv, hd, scale, causal, lo=None, hi=None):
 
 @pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [
     (128, 4, 2, 256, True, False), (128, 4, 2, 200, True, True), (64, 2, 2, 64, False, True),
-    (64, 4, 4, 320, False, False), (128, 2, 1, 512, True, True)])
+    (64, 4, 4, 320, False, False), (128, 2, 1, 512, True, True),
+    (16, 20, 20, 200, False, True), (32, 4, 2, 130, True, True), (48, 2, 2, 64, False, False)])    # small-head kernel
 def test_attn_fwd(hd, nh, nkv, T, causal, ragged):
     B = 2
     M = B * T
