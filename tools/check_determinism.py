@@ -18,7 +18,7 @@ if len(sys.argv) > 1:
     lib().call("molly_gemm_set_persistent_blocks", int(sys.argv[1]))
 m.forward_backward(*args)
 ref = m._rt.G.flat.clone()
-for it in range(6):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     m.forward_backward(*args)
     torch.cuda.synchronize()
     bad = []
