@@ -135,11 +135,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (a one-GPU box can still run the multi-process path end to end): MOLLY_BENCH_DEVICE pins every rank to
+    # one device, MOLLY_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    if "MOLLY_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MOLLY_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MOLLY_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     import __graft_entry__ as ge

@@ -1,0 +1,77 @@
+"""GPU: the multi-rank training path end to end with TWO processes on the ONE GPU of the test box (gloo moves the bytes; RCCL
+refuses two ranks per device, and the 8-GPU run belongs to the driver): real HIP kernels, overlapped reduce-scatter /
+all-gather on the communication stream with the engine's per-layer hooks.  After two steps on different per-rank batches the
+replicas are bitwise identical, and equal a single process that averages the two micro-batch gradients."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(meta):
+    from test_gpu_lora import _build
+    return _build(meta)
+
+
+def _batches(meta):
+    from molly_amd.synth import synth_batch
+    sp = {k: tuple(v) for k, v in meta["config"]["special_ids"].items()}
+    return [synth_batch(2, 256, [("protein", 64)], seed=50 + r, text_vocab=1000, special_ids=sp, pad_id=1000) for r in range(2)]
+
+
+def _args(b):
+    return [b[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")]
+
+
+def _worker(rank, world, port, meta, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from molly_amd.trainer import Zero2Optimizer
+    m = _model(meta)
+    opt = Zero2Optimizer(m._rt.P.flat, m._rt.G.flat, m.n_decay, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0,
+                         chunk_elems=1 << 18)                              # several buckets even on the tiny model
+    assert opt.overlap and opt.world == 2 and len(opt.buckets) > 2
+    m.attach_optimizer(opt)
+    b = _batches(meta)[rank]
+    norms = []
+    for _ in range(2):
+        m.forward_backward(*_args(b))
+        norms.append(float(opt.step(lr=1e-3).item()))
+    opt.wait_all_params()
+    torch.cuda.synchronize()
+    ret[rank] = (m._rt.P.flat.cpu().clone(), norms)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_overlapped_zero2(tiny_meta):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, 29571, tiny_meta, ret), nprocs=2, join=True)
+    (P0, n0), (P1, n1) = ret[0], ret[1]
+    assert torch.equal(P0, P1) and n0 == n1                       # replicas bit-identical after the all-gather
+    # single process: same two micro-batches, gradients summed (GA semantics) then averaged by the 1/world the optimizer
+    # folds into its clip scale -> emulate with grad_scale through two accumulate steps and a halved gradient
+    from molly_amd.trainer import Zero2Optimizer
+    m = _model(tiny_meta)
+    opt = Zero2Optimizer(m._rt.P.flat, m._rt.G.flat, m.n_decay, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0)
+    b = _batches(tiny_meta)
+    norms = []
+    for _ in range(2):
+        m.forward_backward(*_args(b[0]))
+        m.forward_backward(*_args(b[1]), accumulate=True)
+        m._rt.G.flat.mul_(0.5)                                    # exact in bf16
+        norms.append(float(opt.step(lr=1e-3).item()))
+    torch.cuda.synchronize()
+    ref = m._rt.P.flat.cpu()
+    # the two-rank run sums bf16 gradients across ranks in the collective, the single process accumulates inside the
+    # kernels' fp32 epilogues: same mathematics, different rounding -> agree to bf16 resolution of a 1e-3 update
+    assert abs(norms[0] - n0[0]) <= 2e-2 * norms[0]
+    d = (P0.float() - ref.float()).abs()
+    assert (d <= 2 ** -7 * ref.float().abs() + 2.5e-3).all(), d.max().item()      # <= one bf16 step of the parameter
+    assert (P0 != ref).float().mean().item() < 0.35
