@@ -165,3 +165,28 @@ def test_encoder_gradients_vs_reference_golden(tiny_meta, tiny_gold):
         assert rel < 8e-2, (n, rel)
         assert abs(got.double().norm().item() - ref_norm) <= 4e-2 * ref_norm + 1e-6, n
     print("worst relative error vs the reference's gradients", worst)
+
+
+def test_lora_plus_train_bio_share_one_trainable_group(tiny_meta):
+    """`--use-lora --train-bio`: adapters, projectors and both encoders in ONE flat ZeRO group, base LLM frozen."""
+    from molly_amd.lora import LoraConfig
+    from molly_amd.trainer import Zero2Optimizer
+    m = _build(tiny_meta, train_llm=False, lora=LoraConfig(r=8, lora_alpha=16, lora_dropout=0.05, seed=2), train_bio=True)
+    rt = m._rt
+    names = list(rt.G.views)
+    assert any(".lora_A." in n for n in names) and any(n.startswith("protein_model.") for n in names)
+    assert "protein_projector.weight" in names and not any(n.endswith("mlp.down_proj.weight") for n in names)
+    base0 = rt.base.flat.clone()
+    opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=1e-3, max_grad_norm=1.0)
+    m.attach_optimizer(opt)
+    b = _batch(tiny_meta, seed=4)
+    losses = []
+    for _ in range(6):
+        losses.append(m.forward_backward(*_args(b)).clone())
+        assert torch.isfinite(rt.G.flat.float()).all()
+        opt.step(lr=1e-3)
+    assert torch.stack(losses)[-1] < losses[0] - 0.1
+    assert torch.equal(base0, rt.base.flat)
+    g = rt.G.views
+    assert torch.count_nonzero(g["protein_model.esm.encoder.layer.0.attention.self.query.weight"]) > 0
+    assert torch.count_nonzero(g["model.model.layers.0.self_attn.q_proj.lora_B.weight"]) > 0
