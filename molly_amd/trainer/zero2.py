@@ -196,7 +196,7 @@ class Zero2Optimizer:
 
     def grad_norm_and_clip(self):
         first = True
-        for start, per in self.buckets:
+        for start, per in (self.buckets if self.world > 1 else [(0, self.n)]):     # one rank: one pass over the buffer
             lo = start + self.rank * per
             self.k.sqnorm(self.G[lo:lo + per], self.scal[0:1], accumulate=not first)
             first = False
@@ -212,7 +212,14 @@ class Zero2Optimizer:
         self.reduce_scatter_grads()
         self.grad_norm_and_clip()
         pos = 0
-        for start, per in self.buckets:
+        if self.world == 1:
+            # one rank owns everything in flat order: one launch per decay class instead of one per bucket (elementwise, so
+            # bit-identical to the bucketed launches; the bucket structure only exists to pipeline the exchange)
+            for a, b, wd in ((0, self.n_decay, self.wd), (self.n_decay, self.n, 0.0)):
+                if b > a:
+                    self.k.adamw(self.master[a:b], self.m[a:b], self.v[a:b], self.G[a:b], self.P_out[a:b], lr,
+                                 self.betas[0], self.betas[1], self.eps, wd, self.t, self.scal[2:3])
+        for start, per in (self.buckets if self.world > 1 else ()):
             lo, hi = start + self.rank * per, start + (self.rank + 1) * per
             # split at the decay / no-decay boundary of the flat layout
             for a, b, wd in ((lo, min(hi, self.n_decay), self.wd), (max(lo, self.n_decay), hi, 0.0)):
