@@ -113,6 +113,12 @@ class Zero2Optimizer:
         self.overlap = self.overlap and flat_params.is_cuda
         self.P_out = flat_params                # AdamW writes here; the all-gather publishes into P (same buffer in production)
         self.hooked = False                     # set by OmicsOne.attach_optimizer: somebody will call wait_params()
+        # one rank, hooked: nothing to exchange, but the AdamW pass itself (HBM-bound, 28 B per parameter) can run on a side
+        # stream under the NEXT step's first layers (MFMA-bound), bucket by bucket in the order the forward consumes
+        # parameters; the forward's wait_params() calls then wait for AdamW events exactly as they wait for all-gather events
+        self.async_update = self.world == 1 and comm is None and flat_params.is_cuda and kernels is None
+        self._async_armed = False
+        self.ustream = None
         if self.overlap:
             if self.world > 1:
                 # RCCL's collective kernels hold CUs for milliseconds.  The persistent GEMM launches exactly one block per
@@ -144,8 +150,9 @@ class Zero2Optimizer:
             self._rs_done[b] = True
 
     def wait_params(self, lo: int, hi: int):
-        """Make the current stream wait until parameters with flat offsets in [lo, hi) have been all-gathered."""
-        if not self.overlap:
+        """Make the current stream wait until parameters with flat offsets in [lo, hi) have been all-gathered (or, on one
+        rank, updated by the side-stream AdamW)."""
+        if not (self.overlap or self._async_armed):
             return
         for b, (start, per) in enumerate(self.buckets):
             if self._ag_waited[b] or start >= hi or start + per * self.world <= lo:
@@ -212,6 +219,9 @@ class Zero2Optimizer:
         self.reduce_scatter_grads()
         self.grad_norm_and_clip()
         pos = 0
+        if self.world == 1 and self.async_update and self.hooked:
+            self._update_on_side_stream(lr)
+            return self.scal[1]
         if self.world == 1:
             # one rank owns everything in flat order: one launch per decay class instead of one per bucket (elementwise, so
             # bit-identical to the bucketed launches; the bucket structure only exists to pipeline the exchange)
@@ -230,6 +240,30 @@ class Zero2Optimizer:
             pos += per
         self.all_gather_params()
         return self.scal[1]
+
+    def _update_on_side_stream(self, lr: float):
+        if self.ustream is None:
+            self.ustream = torch.cuda.Stream(device=self.P.device)
+            self._ag_events = [None] * len(self.buckets)
+            self._ag_waited = [True] * len(self.buckets)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())                       # clip coefficient and final gradients are ready
+        self.ustream.wait_event(ev)
+        # gains/biases (tail of the flat buffer) are read by the very first kernel of the next forward: update them first
+        order = [len(self.buckets) - 1] + list(range(len(self.buckets) - 1))
+        with torch.cuda.stream(self.ustream):
+            for b in order:
+                lo, per = self.buckets[b]
+                hi = lo + per
+                for a, e, wd in ((lo, min(hi, self.n_decay), self.wd), (max(lo, self.n_decay), hi, 0.0)):
+                    if e > a:
+                        self.k.adamw(self.master[a:e], self.m[a:e], self.v[a:e], self.G[a:e], self.P_out[a:e], lr,
+                                     self.betas[0], self.betas[1], self.eps, wd, self.t, self.scal[2:3])
+                done = torch.cuda.Event()
+                done.record(self.ustream)
+                self._ag_events[b] = done
+                self._ag_waited[b] = False
+        self._async_armed = True
 
     def comm_bytes_per_step(self) -> int:
         """bytes each rank sends (= receives) per optimizer step: RS + AG of bf16, (world-1)/world of the buffer each."""
