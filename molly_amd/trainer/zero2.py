@@ -216,6 +216,10 @@ class Zero2Optimizer:
         """reduce-scatter -> global-norm clip -> AdamW on the owned chunks -> all-gather.  Returns the (device) grad norm."""
         self.t += 1
         lr = self.lr if lr is None else lr
+        if self.ustream is not None:
+            # the previous step's side-stream AdamW reads the clip coefficient this step is about to overwrite; in the training
+            # loop it finished long ago (the backward waited for every parameter), this only orders back-to-back step() calls
+            torch.cuda.current_stream().wait_stream(self.ustream)
         self.reduce_scatter_grads()
         self.grad_norm_and_clip()
         pos = 0
