@@ -50,5 +50,24 @@ def main():
     print(f"esm attn fwd     : {t * 1e3:8.1f} us  {4.0 * B2 * nh2 * T2 * T2 * hd2 / t / 1e9:7.1f} TF/s")
 
 
+    if "--torch" in sys.argv:
+        # orientation only: torch's fused SDPA (whatever backend this build ships) on the same problem
+        import torch.nn.functional as F
+        q4 = q.reshape(B, T, nh, hd).transpose(1, 2).contiguous().requires_grad_(True)
+        k4 = k.reshape(B, T, nkv, hd).transpose(1, 2).contiguous().requires_grad_(True)
+        v4 = v.reshape(B, T, nkv, hd).transpose(1, 2).contiguous().requires_grad_(True)
+        try:
+            f = lambda: F.scaled_dot_product_attention(q4, k4, v4, is_causal=True, enable_gqa=True)
+            with torch.no_grad():
+                t = timeit(f)
+            print(f"torch sdpa fwd   : {t * 1e3:8.1f} us  {fwd_fl / t / 1e9:7.1f} TF/s")
+            out = f()
+            g4 = torch.randn_like(out)
+            t = timeit(lambda: torch.autograd.grad(f(), (q4, k4, v4), g4))
+            print(f"torch sdpa fwd+bwd: {t * 1e3:8.1f} us  {3.5 * fwd_fl / t / 1e9:7.1f} TF/s")
+        except Exception as e:      # noqa: BLE001
+            print("torch sdpa unavailable:", type(e).__name__, str(e)[:200])
+
+
 if __name__ == "__main__":
     main()
