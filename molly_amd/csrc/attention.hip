@@ -176,23 +176,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     // online softmax of one half (keys kbase .. kbase+31) + O^T += V^T P^T
     auto softmax_pv = [&](f32x16& sc, int kbase, const bf16x8 (&vf)[2][ND]) {
         const bool need_mask = (p.causal && (kbase + 31 > q0)) || (kbase < lo) || (kbase + 32 > hi);
+        // the scores stay RAW here: the softmax scale (> 0) commutes with max and is folded into the exponent's fma below
         float mx = -INFINITY;
         if (need_mask) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;      // accumulator row -> key index
                 const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
-                sc[e] = ok ? sc[e] * p.scale_log2 : -INFINITY;
+                sc[e] = ok ? sc[e] : -INFINITY;
                 mx = fmaxf(mx, sc[e]);
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                sc[e] *= p.scale_log2;
-                mx = fmaxf(mx, sc[e]);
-            }
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[e]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
         // deferred rescale (guide T13): keep the old reference max unless some row's max grew by > RESCALE_THR.  The
         // decision precedes every exponentiation of this half (textbook order), so nothing is ever half-scaled.
         if (!__all(mx - m_run <= RESCALE_THR)) {
@@ -207,13 +205,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                 for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
         }
         const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
-        float rs = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            sc[e] = fast_exp2(sc[e] - m_ref);
-            rs += sc[e];
-        }
-        l_run += rs;                                                    // per-half-wave partial; merged at the end
+        for (int e = 0; e < 16; ++e) sc[e] = fast_exp2(sc[e] * p.scale_log2 - m_ref);       // one fma + one exp2 per score
+        // row sum as a tree (a 16-deep dependent add chain would serialise on the add latency)
+        float rs[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) rs[g4] = (sc[4 * g4] + sc[4 * g4 + 1]) + (sc[4 * g4 + 2] + sc[4 * g4 + 3]);
+        l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);                                                    // per-half-wave partial; merged at the end
         const bf16x8 p0 = acc_to_frag(sc, 0), p1 = acc_to_frag(sc, 8);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
@@ -439,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
         if (!skip) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                const int kbase = k0 + 32 * sub;
+                if (p.causal && kbase > q0 + 31) continue;           // half entirely above the diagonal (wave-uniform)
                 f32x16 sT, dpT;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { sT[e] = 0.f; dpT[e] = 0.f; }
@@ -447,12 +447,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
                     sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, 32 * sub + r, s, h), qf[s], sT, 0, 0, 0);
                     dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, 32 * sub + r, s, h), dof[s], dpT, 0, 0, 0);
                 }
+                // masks are needed only where the half touches the causal diagonal or the [lo, hi) edges (wave-uniform test):
+                // the interior halves — most of them — run 4 VALU per element (fma, exp2, sub, mul) instead of ~10
+                const bool need_mask = (p.causal && kbase + 31 > q0) || kbase < lo || kbase + 32 > hi;
+                if (need_mask) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = k0 + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
-                    const float pr = ok ? fast_exp2(sT[e] * p.scale_log2 - lse) : 0.f;
-                    sT[e] = pr * (dpT[e] - dlt);                    // dS^T (unscaled)
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
+                        const float pr = ok ? fast_exp2(sT[e] * p.scale_log2 - lse) : 0.f;
+                        sT[e] = pr * (dpT[e] - dlt);                // dS^T (unscaled)
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sT[e] = fast_exp2(sT[e] * p.scale_log2 - lse) * (dpT[e] - dlt);
                 }
                 const bf16x8 f0 = acc_to_frag(sT, 0), f1 = acc_to_frag(sT, 8);
 #pragma unroll
@@ -559,6 +567,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
         if (!skip) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
+                const int qsub = qbase + 32 * sub;
+                if (p.causal && qsub + 31 < key0) continue;       // these 32 queries all precede this wave's keys (uniform)
                 f32x16 sA, dpA;                                   // [q rows (regs), key cols (lane)]
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { sA[e] = 0.f; dpA[e] = 0.f; }
@@ -568,15 +578,33 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
                     if (DO_DK)
                         dpA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sD, 32 * sub + r, s, h), vf[s], dpA, 0, 0, 0);
                 }
-                f32x16 pA;
+                // row statistics of the 4 consecutive query rows each accumulator group holds: one 16-byte LDS read each
+                f32x4 lse4[4], dl4[4];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ql = 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;   // row inside the tile
-                    const int q = qbase + ql;
-                    const bool ok = key_ok && q < T && (!p.causal || key <= q);
-                    const float pr = ok ? fast_exp2(sA[e] * p.scale_log2 - sL[ql]) : 0.f;
-                    pA[e] = pr;
-                    sA[e] = pr * (dpA[e] - sL[64 + ql]);                        // dS (unscaled)
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    lse4[g4] = *reinterpret_cast<const f32x4*>(sL + 32 * sub + 8 * g4 + 4 * h);
+                    if (DO_DK) dl4[g4] = *reinterpret_cast<const f32x4*>(sL + 64 + 32 * sub + 8 * g4 + 4 * h);
+                }
+                f32x16 pA;
+                // masks only where the 32 x 32 block touches the causal diagonal, the [lo, hi) key edges or the end of the
+                // sequence (wave-uniform test); interior blocks run the bare fma / exp2 / sub / mul
+                const bool need_mask = (p.causal && qsub < key0 + 31) || key0 < lo || key0 + 32 > hi || qsub + 32 > T;
+                if (need_mask) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int q = qsub + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const bool ok = key_ok && q < T && (!p.causal || key <= q);
+                        const float pr = ok ? fast_exp2(sA[e] * p.scale_log2 - lse4[e >> 2][e & 3]) : 0.f;
+                        pA[e] = pr;
+                        if (DO_DK) sA[e] = pr * (dpA[e] - dl4[e >> 2][e & 3]);  // dS (unscaled)
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float pr = fast_exp2(sA[e] * p.scale_log2 - lse4[e >> 2][e & 3]);
+                        pA[e] = pr;
+                        if (DO_DK) sA[e] = pr * (dpA[e] - dl4[e >> 2][e & 3]);
+                    }
                 }
                 if (DO_DV) {
                     const bf16x8 p0 = acc_to_frag(pA, 0), p1 = acc_to_frag(pA, 8);
