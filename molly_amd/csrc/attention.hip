@@ -55,6 +55,7 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
                                          int lane) {
     constexpr int NCB = HD / 16;
     constexpr int NINST = BKV * HD * 2 / 1024;   // 1 KiB per wave-instruction
+    const char* base = reinterpret_cast<const char*>(g + (size_t)key0 * ld);
 #pragma unroll
     for (int i = 0; i < NINST / 4; ++i) {
         const int inst = wave * (NINST / 4) + i;
@@ -64,10 +65,12 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
         const int b0 = rowblk & 1, b1 = (rowblk >> 1) & 1;
         const int row = rowblk * 4 + (cin >> 1);
         const int col = ((cbs ^ b0) << 4) + (((cin & 1) ^ b1) << 3);
-        int key = key0 + row;
-        key = key < T ? key : T - 1;             // clamp; out-of-range rows are masked by index
-        const bf16_t* src = g + (size_t)key * ld + col;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + inst * 512), 16, 0, 0);
+        // wave-uniform 64-bit base (tile row 0: scalar registers) + one 32-bit per-lane byte offset; rows past the end of
+        // the sequence re-read the last valid row (masked by index later).  key0 < T at every call site.
+        const int last = max(T - 1 - key0, 0);
+        const int rel = row < last ? row : last;
+        const unsigned off = ((unsigned)rel * (unsigned)ld + (unsigned)col) * 2u;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds + inst * 512), 16, 0, 0);
     }
 }
 
