@@ -27,6 +27,21 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)(pack_bf2(x, 0.f) & 0xffffu); }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 step): one v_rcp, one v_exp, a 5-term Horner —
+// a third of libm erff's instruction count; the GELU epilogue of the ESM FFN GEMM is VALU-bound on it.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = 1.0f - poly * t * e;
+    return copysignf(r, x);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = bflo(v[e]), b = bfhi(v[e]);
-            o[e] = pack_bf2(0.5f * a * (1.f + erff(a * 0.70710678118654752f)), 0.5f * b * (1.f + erff(b * 0.70710678118654752f)));
+            o[e] = pack_bf2(0.5f * a * (1.f + fast_erf(a * 0.70710678118654752f)), 0.5f * b * (1.f + fast_erf(b * 0.70710678118654752f)));
         }
         *reinterpret_cast<u32x4*>(out + t * 8) = o;
     }
@@ -813,8 +813,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = bflo(v[e]), b = bfhi(v[e]);
-            const float ga = 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * __expf(-0.5f * a * a) * 0.3989422804014327f;
-            const float gb = 0.5f * (1.f + erff(b * 0.70710678118654752f)) + b * __expf(-0.5f * b * b) * 0.3989422804014327f;
+            const float ga = 0.5f * (1.f + fast_erf(a * 0.70710678118654752f)) + a * __expf(-0.5f * a * a) * 0.3989422804014327f;
+            const float gb = 0.5f * (1.f + fast_erf(b * 0.70710678118654752f)) + b * __expf(-0.5f * b * b) * 0.3989422804014327f;
             o[e] = pack_bf2(bflo(d[e]) * ga, bfhi(d[e]) * gb);
         }
         *reinterpret_cast<u32x4*>(dz + t * 8) = o;

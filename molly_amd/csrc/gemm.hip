@@ -123,7 +123,7 @@ __device__ __forceinline__ bf16x8 frag_km(const bf16_t* lds_tile, int kk, int co
     return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 
 template <bool AT, bool BT, int BM, int NSTAGE, int BK>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
