@@ -130,3 +130,38 @@ def test_oracle_encoder_gradients_match_reference_trainbio_golden(tiny_meta, tin
         assert abs(got.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + 1e-9, n
         head = torch.from_numpy(g["ghead/" + n])
         assert (got.flatten()[:256] - head).abs().max().item() <= 2e-4 * max(head.abs().max().item(), 1e-9) + 1e-9, n
+
+
+def test_oracle_lora_branch_equals_merged_weights(tiny_meta, tiny_gold):
+    """oracle/molly_ref.py::lora_linear (PEFT's y = W x + (alpha/r) B A x): an adapter on every target gives the same
+    logits as the base model with W + (alpha/r) B A merged in — the identity `merge_lora_adapter` relies on."""
+    import torch
+    from conftest import tiny_batch, tiny_state_dict
+    from molly_amd.lora import TARGETS, lora_name, target_dims
+    from molly_amd.config import LlmConfig
+    from oracle import molly_ref as R
+    c = tiny_meta["config"]
+    llm, dna, prot = R.cfgs_from_meta(c)
+    sd = tiny_state_dict(tiny_meta)
+    dims = target_dims(LlmConfig.from_dict(c["text"]))
+    g = torch.Generator().manual_seed(0)
+    r, scaling = 8, 2.0
+    lora, merged = dict(sd), dict(sd)
+    lora["lora.scaling"] = scaling
+    for i in range(llm.num_hidden_layers):
+        for mod in TARGETS:
+            fin, fout = dims[mod]
+            A = torch.randn(r, fin, generator=g) * 0.05
+            B = torch.randn(fout, r, generator=g) * 0.05
+            lora[lora_name(i, mod, "A")] = A
+            lora[lora_name(i, mod, "B")] = B
+            wname = lora_name(i, mod, "A").replace(".lora_A.weight", ".weight")
+            merged[wname] = sd[wname] + scaling * (B @ A)
+    b = tiny_batch(tiny_gold, tiny_meta)
+    k = {"dna_rna": c["K"], "protein": c["K"]}
+    with torch.no_grad():
+        l0, g0 = R.omics_forward(sd, llm, dna, prot, b, k)
+        l1, g1 = R.omics_forward(lora, llm, dna, prot, b, k)
+        l2, g2 = R.omics_forward(merged, llm, dna, prot, b, k)
+    assert (g1 - g2).abs().max().item() <= 2e-4 * g2.abs().max().item() and abs(l1.item() - l2.item()) <= 1e-5
+    assert (g1 - g0).abs().max().item() > 1e-2                       # and the adapter really changes the function
