@@ -1017,7 +1017,7 @@ extern "C" int molly_rmsnorm_fwd(void* stream, const void* x, const void* w, voi
     return 0;
 }
 
-extern "C" int molly_rmsnorm_bwd_blocks(int rows) { return grid_for(rows, 4, 512); }
+extern "C" int molly_rmsnorm_bwd_blocks(int rows) { return grid_for(rows, 4, 1024); }
 
 extern "C" int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres, void* dx,
                                  void* dw, int dw_f32, int dw_accumulate, float* workspace, int rows, int H, float eps) {
@@ -1153,7 +1153,7 @@ extern "C" int molly_layernorm_fwd(void* stream, const void* x, const void* w, c
     return 0;
 }
 
-extern "C" int molly_layernorm_bwd_blocks(int rows) { return grid_for(rows, 4, 512); }
+extern "C" int molly_layernorm_bwd_blocks(int rows) { return grid_for(rows, 4, 1024); }
 
 extern "C" int molly_layernorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres, void* dx,
                                    void* dw, void* db, int dw_f32, int dw_accumulate, float* workspace, int rows, int H,
