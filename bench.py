@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--model", default="1.7b")
     ap.add_argument("--train-mode", choices=("full", "lora", "mlp", "bio"), default="full",
                     help="full = headline (--train-llm --train-mlp); lora = --use-lora r=64; mlp = projectors only (side figures)")
+    ap.add_argument("--zero-stage", type=int, default=2, choices=(0, 2),
+                    help="2 = ZeRO-2 (reduce-scatter / sharded AdamW / all-gather); 0 = the reference's ds_z0 fallback (all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", nargs=3, type=int, metavar=("LLM_LAYERS", "ENC_LAYERS", "THREADS"))
     args = ap.parse_args()
@@ -170,7 +172,8 @@ def main():
         m.prepare(dev, random_init_seed=1234, train_llm=False, train_mlp=True,
                   lora=LoraConfig(r=64, lora_alpha=64, lora_dropout=0.05, seed=42) if args.train_mode == "lora" else None)
     rt = m._rt
-    opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0)
+    opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0,
+                         stage=args.zero_stage)
     m.attach_optimizer(opt)
 
     B, T, K = args.batch, args.seq, args.k_protein
@@ -248,7 +251,7 @@ def main():
                                    f"seq_len {T} text + {K}-residue protein span per sample, {B} samples/GPU, GA=1, "
                                    + {"full": "LLM+projectors trainable", "bio": "LLM+projectors+encoders trainable (--train-bio)", "lora": "LoRA r=64 adapters+projectors trainable, base frozen",
                                       "mlp": "projectors trainable, LLM frozen"}[args.train_mode] +
-                                   ("" if args.train_mode == "bio" else ", encoders frozen") + f", ZeRO-2 dp{world}",
+                                   ("" if args.train_mode == "bio" else ", encoders frozen") + f", ZeRO-{args.zero_stage} dp{world}",
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "scored_token_fraction": 0.25,
                        "note": "prompt = 75% of each sample with labels -100 (SURVEY 8d); lm_head+CE run on the scored rows only "

@@ -9,6 +9,7 @@ Cosmetic flags of the reference (swanlab, report_to, enable-list, attn_impl, use
 import argparse
 import json
 import os
+import re
 import sys
 
 import torch
@@ -30,6 +31,24 @@ def _preset(path, kind):
                 "protein": C.EncConfig.from_dict(meta["protein"])}[kind]
     cfg = C._load_json_config(path)
     return C.LlmConfig.from_dict(cfg) if kind == "text" else C.EncConfig.from_dict(cfg)
+
+
+def zero_stage_of(deepspeed_config):
+    """ZeRO stage named by the reference's `--deepspeed_config src/configs/ds_z{0,1,2}_config.json` (the JSON's
+    zero_optimization.stage when the file exists, else the z<N> in its name; no flag = the ZeRO-2 default of the examples).
+    Stage 1 (sharded optimizer state, all-reduced gradients) steps to the same parameters as stage 2 and runs as stage 2;
+    stage 3 (sharded parameters) is outside the hot path."""
+    if not deepspeed_config:
+        return 2
+    stage = None
+    if os.path.exists(deepspeed_config):
+        stage = json.load(open(deepspeed_config)).get("zero_optimization", {}).get("stage")
+    if stage is None:
+        m = re.search(r"z(\d)", os.path.basename(deepspeed_config))
+        stage = int(m.group(1)) if m else 2
+    if stage not in (0, 1, 2):
+        raise ValueError(f"--deepspeed_config {deepspeed_config}: ZeRO stage {stage} is not supported (0, 1, 2 are)")
+    return 0 if stage == 0 else 2
 
 
 def main(argv=None):
@@ -103,7 +122,8 @@ def main(argv=None):
                       warmup_ratio=a.warmup_ratio, adam_epsilon=a.eps, logging_steps=a.logging_steps, save_steps=a.save_steps,
                       save_total_limit=a.save_total_limit or None, seed=a.seed,
                       per_device_eval_batch_size=a.per_device_eval_batch_size, eval_steps=a.eval_steps,
-                      early_stopping_patience=a.early_stopping_patience, load_best_model_at_end=a.load_best_model_at_end)
+                      early_stopping_patience=a.early_stopping_patience, load_best_model_at_end=a.load_best_model_at_end,
+                      zero_stage=zero_stage_of(a.deepspeed_config))
     eval_ds = None
     if not a.skip_eval and a.eval_dataset_path:                  # reference: src/train.py:206-231
         if a.metric_for_best_model != "eval_loss" or a.greater_is_better:

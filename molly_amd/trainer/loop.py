@@ -55,6 +55,7 @@ class TrainArgs:
     #                                           the reference registers EarlyStoppingCallback(patience), which HF only
     #                                           honours together with load_best_model_at_end (its scripts leave that off)
     load_best_model_at_end: bool = False
+    zero_stage: int = 2                       # 2 = ZeRO-2 (ds_z2_config.json), 0 = plain DP all-reduce (ds_z0_config.json)
 
 
 def save_model(model, output_dir: str):
@@ -88,7 +89,7 @@ class Trainer:
         rt = model._runtime()
         self.opt = Zero2Optimizer(rt.P.flat, rt.G.flat, model.n_decay, lr=args.learning_rate,
                                   betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
-                                  weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm)
+                                  weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, stage=args.zero_stage)
         model.attach_optimizer(self.opt)
         self.history: List[dict] = []
 

@@ -12,6 +12,12 @@ region (no staging copies), and on the fully connected 8-GPU xGMI mesh each of t
 of the 7 links concurrently.  Default chunk = 16 Mi elements (32 MiB bf16 per link per bucket).
 World size 1 skips the collectives and keeps the same code path.
 
+`stage=0` is the reference's ZeRO-0 fallback (what examples/run_train_1B_z2_b1.sh:63 selects for the 1.7B model: plain
+data parallelism): the same buckets are ALL-REDUCED in place instead of reduce-scattered, every rank keeps the whole fp32
+master / moment set and runs AdamW over the whole buffer, and nothing is all-gathered.  Same hooks, same overlap; with
+two ranks the summed gradients are bit-identical to stage 2 (a two-term bf16 sum does not depend on the reduction order);
+the gradient norm is one pass over the buffer instead of per-shard partial sums (last fp32 bits).
+
 Overlap (default on for world > 1): collectives run on a dedicated communication stream.
   * reduce-scatter: the backward reports "gradients in [lo, hi) are final" layer by layer (engine hook); every bucket that
     is fully covered is reduce-scattered immediately, beside the backward of the earlier layers.  The reference's
@@ -50,6 +56,9 @@ class _DistComm:
     def all_reduce(self, t):
         dist.all_reduce(t, group=self.group)
 
+    def all_reduce_region(self, region):
+        dist.all_reduce(region, group=self.group)
+
 
 class _HipKernels:
     """The shard arithmetic: HIP kernels through the C ABI (no CPU fallback in the product)."""
@@ -73,7 +82,9 @@ class Zero2Optimizer:
     def __init__(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, n_decay: int, lr: float = 3e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_grad_norm: float = 1.0,
                  group=None, chunk_elems: int = 16 * 1024 * 1024, kernels=None, overlap: Optional[bool] = None,
-                 comm=None):
+                 comm=None, stage: int = 2):
+        assert stage in (0, 2), "stage: 2 = sharded optimizer state (ZeRO-2), 0 = replicated (plain DP all-reduce)"
+        self.stage = stage
         self.P, self.G = flat_params, flat_grads
         self.n = flat_params.numel()
         self.n_decay = n_decay
@@ -93,12 +104,14 @@ class Zero2Optimizer:
             self.buckets.append((off, per))
             off += per * self.world
         assert off == self.n
-        self.owned = sum(per for _, per in self.buckets)
+        self.owned = sum(per for _, per in self.buckets) if stage == 2 else self.n
         dev = flat_params.device
-        # fp32 master / moments for the owned chunks, packed
+        # fp32 master / moments for the owned chunks, packed (stage 0: the whole buffer, in flat order)
         self.master = torch.empty(self.owned, dtype=torch.float32, device=dev)
+        if stage == 0:
+            self.master.copy_(flat_params.float())
         pos = 0
-        for start, per in self.buckets:
+        for start, per in (self.buckets if stage == 2 else ()):
             lo = start + self.rank * per
             self.master[pos:pos + per].copy_(flat_params[lo:lo + per].float())
             pos += per
@@ -116,7 +129,7 @@ class Zero2Optimizer:
         # one rank, hooked: nothing to exchange, but the AdamW pass itself (HBM-bound, 28 B per parameter) can run on a side
         # stream under the NEXT step's first layers (MFMA-bound), bucket by bucket in the order the forward consumes
         # parameters; the forward's wait_params() calls then wait for AdamW events exactly as they wait for all-gather events
-        self.async_update = self.world == 1 and comm is None and flat_params.is_cuda and kernels is None
+        self.async_update = (self.world == 1 or stage == 0) and comm is None and flat_params.is_cuda and kernels is None
         self._async_armed = False
         self.ustream = None
         if self.overlap:
@@ -145,8 +158,7 @@ class Zero2Optimizer:
                 ev.record(torch.cuda.current_stream())
                 self.cstream.wait_event(ev)
             with torch.cuda.stream(self.cstream):
-                region = self.G[start:start + per * self.world]
-                self.comm.reduce_scatter(region[self.rank * per:(self.rank + 1) * per], region)
+                self._reduce_bucket(start, per)
             self._rs_done[b] = True
 
     def wait_params(self, lo: int, hi: int):
@@ -163,6 +175,13 @@ class Zero2Optimizer:
     def wait_all_params(self):
         self.wait_params(0, self.n)
 
+    def _reduce_bucket(self, start: int, per: int):
+        region = self.G[start:start + per * self.world]
+        if self.stage == 0:
+            self.comm.all_reduce_region(region)
+        else:
+            self.comm.reduce_scatter(region[self.rank * per:(self.rank + 1) * per], region)
+
     # ---- pieces (also used by the multi-process CPU tests) ---------------------------------------------------
     def reduce_scatter_grads(self):
         if self.overlap:
@@ -173,10 +192,11 @@ class Zero2Optimizer:
         if self.world == 1:
             return
         for start, per in self.buckets:
-            region = self.G[start:start + per * self.world]
-            self.comm.reduce_scatter(region[self.rank * per:(self.rank + 1) * per], region)
+            self._reduce_bucket(start, per)
 
     def all_gather_params(self):
+        if self.stage == 0:
+            return                                             # every rank updated every parameter itself
         if self.overlap:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -203,11 +223,12 @@ class Zero2Optimizer:
 
     def grad_norm_and_clip(self):
         first = True
-        for start, per in (self.buckets if self.world > 1 else [(0, self.n)]):     # one rank: one pass over the buffer
-            lo = start + self.rank * per
+        sharded = self.world > 1 and self.stage == 2
+        for start, per in (self.buckets if sharded else [(0, self.n)]):     # whole buffer here: one pass
+            lo = start + self.rank * per if sharded else 0
             self.k.sqnorm(self.G[lo:lo + per], self.scal[0:1], accumulate=not first)
             first = False
-        if self.world > 1:
+        if sharded:
             self.comm.all_reduce(self.scal[0:1])
         # gradients were SUMMED over ranks; DeepSpeed averages them: fold 1/world into the scale
         self.k.clip_coef(self.scal[0:1], self.max_norm, 1.0 / self.world, self.scal[1:2], self.scal[2:3])
@@ -223,17 +244,18 @@ class Zero2Optimizer:
         self.reduce_scatter_grads()
         self.grad_norm_and_clip()
         pos = 0
-        if self.world == 1 and self.async_update and self.hooked:
+        whole = self.world == 1 or self.stage == 0               # this rank updates the whole buffer
+        if whole and self.async_update and self.hooked:
             self._update_on_side_stream(lr)
             return self.scal[1]
-        if self.world == 1:
+        if whole:
             # one rank owns everything in flat order: one launch per decay class instead of one per bucket (elementwise, so
             # bit-identical to the bucketed launches; the bucket structure only exists to pipeline the exchange)
             for a, b, wd in ((0, self.n_decay, self.wd), (self.n_decay, self.n, 0.0)):
                 if b > a:
                     self.k.adamw(self.master[a:b], self.m[a:b], self.v[a:b], self.G[a:b], self.P_out[a:b], lr,
                                  self.betas[0], self.betas[1], self.eps, wd, self.t, self.scal[2:3])
-        for start, per in (self.buckets if self.world > 1 else ()):
+        for start, per in (self.buckets if not whole else ()):
             lo, hi = start + self.rank * per, start + (self.rank + 1) * per
             # split at the decay / no-decay boundary of the flat layout
             for a, b, wd in ((lo, min(hi, self.n_decay), self.wd), (max(lo, self.n_decay), hi, 0.0)):
@@ -258,7 +280,7 @@ class Zero2Optimizer:
         with torch.cuda.stream(self.ustream):
             for b in order:
                 lo, per = self.buckets[b]
-                hi = lo + per
+                hi = lo + per * self.world
                 for a, e, wd in ((lo, min(hi, self.n_decay), self.wd), (max(lo, self.n_decay), hi, 0.0)):
                     if e > a:
                         self.k.adamw(self.master[a:e], self.m[a:e], self.v[a:e], self.G[a:e], self.P_out[a:e], lr,
@@ -271,4 +293,5 @@ class Zero2Optimizer:
 
     def comm_bytes_per_step(self) -> int:
         """bytes each rank sends (= receives) per optimizer step: RS + AG of bf16, (world-1)/world of the buffer each."""
+        # (stage 0: one all-reduce = the same two passes over the ring)
         return 0 if self.world == 1 else 2 * 2 * self.n * (self.world - 1) // self.world

@@ -26,7 +26,7 @@ class TorchKernels:
         param_out.copy_(master.to(param_out.dtype))
 
 
-def _worker(rank, world, port, n, n_decay, chunk, ret):
+def _worker(rank, world, port, n, n_decay, chunk, ret, stage=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from molly_amd.trainer.zero2 import Zero2Optimizer
@@ -35,7 +35,7 @@ def _worker(rank, world, port, n, n_decay, chunk, ret):
     P = p0.clone().bfloat16()
     grads = [torch.randn(n, generator=torch.Generator().manual_seed(10 + r)).bfloat16() for r in range(world)]
     G = grads[rank].clone()
-    opt = Zero2Optimizer(P, G, n_decay, lr=1e-2, max_grad_norm=1.0, chunk_elems=chunk, kernels=TorchKernels())
+    opt = Zero2Optimizer(P, G, n_decay, lr=1e-2, max_grad_norm=1.0, chunk_elems=chunk, kernels=TorchKernels(), stage=stage)
     for _ in range(2):
         G.copy_(grads[rank])
         norm = opt.step()
@@ -69,6 +69,33 @@ def test_zero2_two_ranks_equals_single_process(chunk):
     ref = p.bfloat16().float()
     assert bool(((P0.float() - ref).abs() <= 2 ** -7 * ref.abs() + 1e-6).all())
     assert (P0.float() != ref).float().mean() < 0.05
+
+
+def test_zero0_fallback_equals_zero2():
+    """The reference's ds_z0 fallback (examples/run_train_1B_z2_b1.sh:63): all-reduced gradients, replicated
+    AdamW.  With two ranks the bf16 sum has one rounding whatever the collective, so the parameters match stage 2 bit for bit."""
+    n, n_decay, world = 1024, 768, 2
+    mgr = mp.Manager()
+    out = {}
+    for stage, port in ((2, 29561), (0, 29563)):
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, n, n_decay, 64, ret, stage), nprocs=world, join=True)
+        assert torch.equal(ret[0][0], ret[1][0]) and ret[0][1] == ret[1][1]
+        out[stage] = ret[0]
+    assert torch.equal(out[0][0], out[2][0])
+    assert abs(out[0][1] - out[2][1]) <= 1e-6 * out[2][1]      # norm: one pass over the buffer vs per-shard partial sums
+
+
+def test_zero_stage_of_deepspeed_config(tmp_path):
+    from molly_amd.train import zero_stage_of
+    assert zero_stage_of(None) == 2
+    assert zero_stage_of("src/configs/ds_z0_config.json") == 0          # file absent: the z<N> of the name
+    assert zero_stage_of("src/configs/ds_z1_config.json") == 2
+    f = tmp_path / "ds.json"
+    f.write_text('{"zero_optimization": {"stage": 0}}')
+    assert zero_stage_of(str(f)) == 0
+    with pytest.raises(ValueError):
+        zero_stage_of("src/configs/ds_z3_config.json")
 
 
 def test_bucket_partition_covers_buffer_once():
