@@ -113,6 +113,12 @@ int molly_embed_bwd(void* stream, const void* g, const int* order, const int* se
 int molly_count_valid(void* stream, const int64_t* labels, long n, int ignore_index, float* scale_out, float* count_out);
 int molly_ce_fwd_bwd(void* stream, void* logits, const int64_t* labels, float* row_loss, const float* scale, int rows,
                      int V, int ld, int ignore_index, int write_grad);
+/* classifier-head losses of the Enc-Head baselines — reference baselines/model.py:196-204: mode 0 = F.cross_entropy
+ * (int64 labels, ignore_index rows skipped), mode 1 = F.binary_cross_entropy_with_logits (fp32 targets [rows][V]).
+ * logits bf16 [rows][ld], any V <= ld; row_loss[r] = summed loss of row r; logits are overwritten by
+ * d(logits) * (*scale) when write_grad (padding columns V..ld-1 get 0). */
+int molly_cls_loss_fwd_bwd(void* stream, void* logits, const int64_t* labels, const float* targets, float* row_loss,
+                           const float* scale, int rows, int V, int ld, int mode, int ignore_index, int write_grad);
 int molly_sum_f32(void* stream, const float* x, long n, const float* scale_or_null, float* out, int accumulate);
 
 /* LayerNorm forward (affine, eps 1e-5) — ESM pre-LN blocks and emb_layer_norm_after: HF:models/esm/

@@ -527,6 +527,60 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Classifier-head losses of the Enc-Head baselines (reference: baselines/model.py:196-204): logits [rows][V] bf16 with
+// any V (row pitch ld >= V; columns V..ld-1 are padding and get zero gradient).  One wave per row.
+//   mode 0: F.cross_entropy(logits, labels)          labels int64 [rows] (ignore_index rows: zero loss / gradient)
+//   mode 1: F.binary_cross_entropy_with_logits(logits, targets)   targets fp32 [rows][V]
+// row_loss[r] = the row's summed loss; the logits are overwritten by d(logits) = dloss/dlogit * (*scale).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cls_loss_kernel(bf16_t* __restrict__ logits, const long* __restrict__ labels,
+                                                      const float* __restrict__ targets, float* __restrict__ row_loss,
+                                                      const float* __restrict__ scale, int V, int ld, int mode,
+                                                      int ignore_index, int write_grad) {
+    const long row = blockIdx.x;
+    const int lane = threadIdx.x;
+    bf16_t* lr = logits + (size_t)row * ld;
+    const float sc = write_grad ? *scale : 0.f;
+    float loss = 0.f;
+    if (mode == 0) {
+        const long lab = labels[row];
+        if (lab == ignore_index || lab < 0 || lab >= V) {
+            if (lane == 0) row_loss[row] = lab == ignore_index ? 0.f : __builtin_nanf("");   // torch asserts on a bad label
+            if (write_grad && lab == ignore_index)
+                for (int c = lane; c < ld; c += 64) lr[c] = 0;
+            return;
+        }
+        float mx = -INFINITY;
+        for (int c = lane; c < V; c += 64) mx = fmaxf(mx, bf2f(lr[c]));
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sm = 0.f;
+        for (int c = lane; c < V; c += 64) sm += __expf(bf2f(lr[c]) - mx);
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        const float lse = mx + __logf(sm);
+        loss = lse - bf2f(lr[lab]);
+        if (write_grad)
+            for (int c = lane; c < ld; c += 64) {
+                const float p = c < V ? __expf(bf2f(lr[c]) - lse) - (c == lab ? 1.f : 0.f) : 0.f;
+                lr[c] = f2bf(p * sc);
+            }
+    } else {
+        const float* t = targets + (size_t)row * V;
+        for (int c = lane; c < ld; c += 64) {
+            float g = 0.f;
+            if (c < V) {
+                const float x = bf2f(lr[c]), y = t[c];
+                // max(x, 0) - x y + log(1 + exp(-|x|))  (torch's stable form)
+                loss += fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)));
+                g = 1.f / (1.f + __expf(-x)) - y;
+            }
+            if (write_grad) lr[c] = f2bf(g * sc);
+        }
+        for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o, 64);
+    }
+    if (lane == 0) row_loss[row] = loss;
+}
+
+// ------------------------------------------------------------------------------------------------
 // cross-entropy on a chunk of bf16 logits, in place -> d(logits)   (HF:loss/loss_utils.py:32-71)
 // labels are ALREADY shifted (row r predicts labels[r]); ignore_index rows get zero grad / zero loss.
 // dlogits = (softmax - onehot) * (*scale)   with *scale = 1/n_valid computed on device beforehand.
@@ -1131,6 +1185,18 @@ extern "C" int molly_ce_fwd_bwd(void* stream, void* logits, const int64_t* label
     MOLLY_CHECK(rows > 0 && V % 8 == 0 && ld % 8 == 0, "ce: V=%d and ld=%d must be multiples of 8", V, ld);
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, ST, (bf16_t*)logits, (const long*)labels, row_loss,
                        scale, V, ld, ignore_index, write_grad);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_cls_loss_fwd_bwd(void* stream, void* logits, const int64_t* labels, const float* targets,
+                                     float* row_loss, const float* scale, int rows, int V, int ld, int mode,
+                                     int ignore_index, int write_grad) {
+    MOLLY_CHECK(rows > 0 && V > 0 && ld >= V, "cls_loss: rows=%d V=%d ld=%d", rows, V, ld);
+    MOLLY_CHECK(mode == 0 ? labels != nullptr : (mode == 1 && targets != nullptr), "cls_loss: mode %d without its labels", mode);
+    MOLLY_CHECK(!write_grad || scale, "cls_loss: gradient requested without a scale");
+    hipLaunchKernelGGL(cls_loss_kernel, dim3(rows), dim3(64), 0, ST, (bf16_t*)logits, (const long*)labels, targets, row_loss,
+                       scale, V, ld, mode, ignore_index, write_grad);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

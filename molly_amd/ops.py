@@ -229,6 +229,15 @@ def ce_fwd_bwd(logits, labels, row_loss, scale, ignore_index=-100, write_grad=Tr
                int(write_grad))
 
 
+def cls_loss_fwd_bwd(logits, V, row_loss, scale, labels=None, targets=None, ignore_index=-100, write_grad=True):
+    """Enc-Head baseline losses on logits [rows, ld >= V] (bf16), in place -> d(logits): labels (int64) = cross entropy,
+    targets (fp32 [rows, V]) = BCE with logits."""
+    rows, ld = logits.shape
+    assert logits.stride(1) == 1 and (labels is None) != (targets is None)
+    lib().call("molly_cls_loss_fwd_bwd", _stream(), logits, labels, targets, row_loss, scale, rows, V, logits.stride(0),
+               0 if labels is not None else 1, ignore_index, int(write_grad))
+
+
 def count_valid(labels, scale_out, count_out, ignore_index=-100):
     lib().call("molly_count_valid", _stream(), labels, labels.numel(), ignore_index, scale_out, count_out)
 

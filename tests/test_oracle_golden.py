@@ -165,3 +165,34 @@ def test_oracle_lora_branch_equals_merged_weights(tiny_meta, tiny_gold):
         l2, g2 = R.omics_forward(merged, llm, dna, prot, b, k)
     assert (g1 - g2).abs().max().item() <= 2e-4 * g2.abs().max().item() and abs(l1.item() - l2.item()) <= 1e-5
     assert (g1 - g0).abs().max().item() > 1e-2                       # and the adapter really changes the function
+
+
+def test_enc_head_baselines_match_reference(tiny_meta):
+    """Enc-Head baselines: the oracle's `cls_head_forward` against the reference's own
+    `BackboneWithClsHead` (tests/golden/gen_golden_baseline.py): logits, loss and every parameter gradient, all five
+    backbone combinations and the BCE (multi_answer) head."""
+    from _baseline_common import baseline_state_dict, case_inputs, load_gold
+    g, cases = load_gold()
+    assert len(cases) >= 6
+    for name, mtype, multi, nl in cases:
+        sd, _ = baseline_state_dict(tiny_meta, mtype, nl, int(g["meta/seed_w"]))
+        cfgs = [c for c in R.cfgs_from_meta(tiny_meta["config"])[1:]]                 # (dna_rna, protein) oracle configs
+        by_kind = {"NT": cfgs[0], "ESM": cfgs[1]}
+        ocfgs = [by_kind[t] for t in mtype.split("+")]
+        for v in sd.values():
+            v.requires_grad_(True)
+        xs, labels = case_inputs(g, name, mtype)
+        loss, logits = R.cls_head_forward(sd, mtype, ocfgs, xs, labels, multi_answer=bool(multi))
+        np.testing.assert_allclose(logits.detach().numpy(), g[f"{name}/logits"], rtol=0, atol=2e-5)
+        assert abs(loss.item() - float(g[f"{name}/loss"])) < 1e-5
+        loss.backward()
+        names = [k[len(name) + 7:] for k in g if k.startswith(name + "/gnorm/")]
+        assert len(names) >= 37
+        for n in names:
+            ref = float(g[f"{name}/gnorm/{n}"])
+            grad = sd[n].grad
+            got = 0.0 if grad is None else grad.double().norm().item()
+            assert abs(got - ref) <= 1e-4 * max(ref, 1e-6) + 1e-7, (name, n, got, ref)
+            if grad is not None:
+                np.testing.assert_allclose(grad.flatten()[:128].numpy(), g[f"{name}/ghead/{n}"], rtol=0,
+                                           atol=2e-6 + 1e-4 * np.abs(g[f"{name}/ghead/{n}"]).max())
