@@ -32,6 +32,18 @@ def tiny_gold_bf16():
     return dict(np.load(os.path.join(GOLD, "tiny_bf16.npz"), allow_pickle=False))
 
 
+@pytest.fixture(scope="session")
+def wide_meta():
+    """G4: one layer of every stack at the real widths of Molly-1.7B (tests/golden/gen_golden_wide.py)."""
+    with open(os.path.join(GOLD, "wide_meta.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def wide_gold():
+    return dict(np.load(os.path.join(GOLD, "wide_fp32.npz"), allow_pickle=False))
+
+
 def tiny_batch(gold, meta):
     return {
         "input_ids": torch.from_numpy(gold["in/input_ids"]),

@@ -1,0 +1,78 @@
+"""GPU: G4 of SURVEY.md 8(c) — one layer of every stack at the REAL widths of Molly-1.7B (Qwen3 2048 / 16q-8kv x 128 / 6144;
+encoders 1280 / 20 x 64 / 5120, absolute-position and rotary) through the HIP path against golden vectors of the reference's
+OmicsOne (fp32; tests/golden/gen_golden_wide.py).  Unlike the tiny fixture this one runs the production tile paths: the
+256x256 GEMM, head_dim-128 GQA attention, 20-head encoders, real-width norms.  Tolerance: the stated bf16 bound
+(max|dlogit| <= 3e-2 max|logit|); the reference's own bf16 CPU path is stored beside as the yardstick."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import tiny_batch, tiny_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(meta, **prep):
+    import molly_amd
+    from molly_amd.config import EncConfig, LlmConfig, OmicsModalConfig
+    c = meta["config"]
+    cfg = OmicsModalConfig(text_config=LlmConfig.from_dict(c["text"]), dna_rna_config=EncConfig.from_dict(c["dna_rna"]),
+                           protein_config=EncConfig.from_dict(c["protein"]))
+    cfg.dna_rna_project_token_num = cfg.protein_project_token_num = c["K"]
+    m = molly_amd.OmicsOne(cfg)
+    m.model = molly_amd.Qwen3ForCausalLM.from_config(cfg.text_config)
+    m.dna_rna_model = molly_amd.EsmForMaskedLM.from_config(cfg.dna_rna_config)
+    m.protein_model = molly_amd.EsmForMaskedLM.from_config(cfg.protein_config)
+    missing, _ = m.load_state_dict(tiny_state_dict(meta), strict=False)
+    assert not missing, missing
+    return m.prepare("cuda", **prep)
+
+
+def test_forward_at_real_widths_vs_reference(wide_meta, wide_gold):
+    m = _build(wide_meta)
+    g = wide_gold
+    batch = tiny_batch(g, wide_meta)
+    st, sh = wide_meta["sub"]
+    with torch.no_grad():
+        out = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], omic_ids=batch["omic_ids"],
+                omic_info_list=batch["omic_info_list"], labels=batch["labels"])
+    torch.cuda.synchronize()
+    logits = out.logits.float().cpu().numpy()[:, ::st, ::sh]
+    ref, refb = g["fwd/logits"], g["bf16/logits"]
+    valid = batch["attention_mask"].numpy()[:, ::st].astype(bool)
+    err = np.abs(logits - ref)[valid].max()
+    errb = np.abs(refb - ref)[valid].max()
+    tol = 3e-2 * np.abs(ref).max()
+    print(f"max|dlogit| ours {err:.4f}  reference-bf16 {errb:.4f}  tol {tol:.4f}")
+    assert err <= tol
+    assert abs(out.loss.item() - float(g["fwd/loss"])) <= 5e-3
+    assert abs(out.loss.item() - float(g["fwd/loss"])) <= 3 * abs(float(g["bf16/loss"]) - float(g["fwd/loss"])) + 1e-3
+
+
+def test_all_gradients_at_real_widths_vs_reference(wide_meta, wide_gold):
+    """LLM + projectors + both encoders trainable: the 56 gradient tensors of the fixture."""
+    m = _build(wide_meta, train_bio=True)
+    g = wide_gold
+    batch = tiny_batch(g, wide_meta)
+    loss = m.forward_backward(batch["input_ids"], batch["attention_mask"], batch["omic_ids"], batch["omic_info_list"],
+                              batch["labels"])
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["fwd/loss"])) <= 5e-3
+    G = m._rt.G.views
+    names = [k[len("gnorm/"):] for k in g if k.startswith("gnorm/") and k != "gnorm/model.lm_head.weight"]
+    assert len(names) >= 55
+    worst = 0.0
+    for n in names:
+        got = G[n].float().cpu()
+        ref_norm = float(g["gnorm/" + n])
+        head = torch.from_numpy(g["ghead/" + n])
+        if n.endswith("key.bias"):
+            continue                                   # ~0 by construction; judged in test_gpu_train_bio.py
+        # the stored head (first 256 entries) on its own largest entry plus the tensor's rms (rounding noise floor)
+        rms = ref_norm / got.numel() ** 0.5
+        err = (got.flatten()[:256] - head).abs().max().item()
+        bound = 3e-2 * head.abs().max().item() + 0.2 * rms + 1e-9
+        worst = max(worst, err / bound)
+        assert err <= bound, (n, err, bound)
+        assert abs(got.double().norm().item() - ref_norm) <= 2e-2 * ref_norm + 1e-7, (n, got.norm().item(), ref_norm)
+    print(f"{len(names)} tensors, worst error / bound {worst:.3f}")

@@ -196,3 +196,37 @@ def test_enc_head_baselines_match_reference(tiny_meta):
             if grad is not None:
                 np.testing.assert_allclose(grad.flatten()[:128].numpy(), g[f"{name}/ghead/{n}"], rtol=0,
                                            atol=2e-6 + 1e-4 * np.abs(g[f"{name}/ghead/{n}"]).max())
+
+
+def test_real_width_layer_matches_reference(wide_meta, wide_gold):
+    """G4: one layer of every stack at the real widths of Molly-1.7B (2048 / 16q-8kv x 128 / 6144; encoders
+    1280 / 20 x 64 / 5120), reference OmicsOne in fp32: forward tensors, loss, all 56 gradients (encoders included)."""
+    meta, g = wide_meta, wide_gold
+    llm, dna, prot = R.cfgs_from_meta(meta["config"])
+    sd = tiny_state_dict(meta)
+    for k, v in sd.items():
+        if "lm_head" not in k and "contact_head" not in k:
+            v.requires_grad_(True)
+    sd["model.lm_head.weight"] = sd["model.model.embed_tokens.weight"]
+    K = meta["config"]["K"]
+    st, sh = meta["sub"]
+    col = {}
+    loss, logits = R.omics_forward(sd, llm, dna, prot, tiny_batch(g, meta), {"dna_rna": K, "protein": K}, collect=col)
+    sub = lambda t: t.detach().numpy()[:, ::st, ::sh]
+    np.testing.assert_allclose(sub(col["enc"]["protein"]), g["fwd/enc_protein"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(sub(col["enc"]["dna_rna"]), g["fwd/enc_dna_rna"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(sub(col["inputs_embeds"]), g["fwd/inputs_embeds"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(sub(col["layers"][0]), g["fwd/layer0"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(sub(col["final_hidden"]), g["fwd/final_hidden"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(sub(logits), g["fwd/logits"], rtol=0, atol=1e-4)
+    assert abs(loss.item() - float(g["fwd/loss"])) < 1e-5
+    loss.backward()
+    names = [k[len("gnorm/"):] for k in g if k.startswith("gnorm/")]
+    assert len(names) == 56
+    for n in names:
+        grad = sd[n].grad
+        assert grad is not None, n
+        ref = float(g["gnorm/" + n])
+        assert abs(grad.double().norm().item() - ref) <= 1e-4 * max(ref, 1e-6) + 1e-7, (n, grad.norm().item(), ref)
+        np.testing.assert_allclose(grad.flatten()[:256].numpy(), g["ghead/" + n], rtol=0,
+                                   atol=2e-6 + 1e-4 * np.abs(g["ghead/" + n]).max())
