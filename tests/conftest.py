@@ -32,16 +32,14 @@ def tiny_gold_bf16():
     return dict(np.load(os.path.join(GOLD, "tiny_bf16.npz"), allow_pickle=False))
 
 
-@pytest.fixture(scope="session")
-def wide_meta():
-    """G4: one layer of every stack at the real widths of Molly-1.7B (tests/golden/gen_golden_wide.py)."""
-    with open(os.path.join(GOLD, "wide_meta.json")) as f:
-        return json.load(f)
+WIDE_TAGS = ("wide", "wide4b", "wide8b")      # Molly-1.7B / 4B / 8B decoder widths (tests/golden/gen_golden_wide.py)
 
 
-@pytest.fixture(scope="session")
-def wide_gold():
-    return dict(np.load(os.path.join(GOLD, "wide_fp32.npz"), allow_pickle=False))
+def wide_fixture(tag):
+    """G4: one layer of every stack at real widths -> (meta, golden arrays)."""
+    with open(os.path.join(GOLD, f"{tag}_meta.json")) as f:
+        meta = json.load(f)
+    return meta, dict(np.load(os.path.join(GOLD, f"{tag}_fp32.npz"), allow_pickle=False))
 
 
 def tiny_batch(gold, meta):

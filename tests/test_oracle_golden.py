@@ -198,16 +198,21 @@ def test_enc_head_baselines_match_reference(tiny_meta):
                                            atol=2e-6 + 1e-4 * np.abs(g[f"{name}/ghead/{n}"]).max())
 
 
-def test_real_width_layer_matches_reference(wide_meta, wide_gold):
-    """G4: one layer of every stack at the real widths of Molly-1.7B (2048 / 16q-8kv x 128 / 6144; encoders
-    1280 / 20 x 64 / 5120), reference OmicsOne in fp32: forward tensors, loss, all 56 gradients (encoders included)."""
-    meta, g = wide_meta, wide_gold
+@pytest.mark.parametrize("tag", ["wide", "wide4b", "wide8b"])
+def test_real_width_layer_matches_reference(tag):
+    """G4: one layer of every stack at real widths — Molly-1.7B (2048 / 16q-8kv x 128 / 6144, tied head),
+    4B (2560 / 32q-8kv / 9728) and 8B (4096 / 32q-8kv / 12288), untied heads; encoders 1280 / 20 x 64 / 5120 — reference
+    OmicsOne in fp32: forward tensors, loss, all 56 / 57 gradients (encoders included)."""
+    from conftest import wide_fixture
+    meta, g = wide_fixture(tag)
     llm, dna, prot = R.cfgs_from_meta(meta["config"])
     sd = tiny_state_dict(meta)
+    tied = meta["config"]["text"]["tie_word_embeddings"]
     for k, v in sd.items():
-        if "lm_head" not in k and "contact_head" not in k:
+        if ("lm_head" not in k and "contact_head" not in k) or (k == "model.lm_head.weight" and not tied):
             v.requires_grad_(True)
-    sd["model.lm_head.weight"] = sd["model.model.embed_tokens.weight"]
+    if tied:
+        sd["model.lm_head.weight"] = sd["model.model.embed_tokens.weight"]
     K = meta["config"]["K"]
     st, sh = meta["sub"]
     col = {}
@@ -222,7 +227,7 @@ def test_real_width_layer_matches_reference(wide_meta, wide_gold):
     assert abs(loss.item() - float(g["fwd/loss"])) < 1e-5
     loss.backward()
     names = [k[len("gnorm/"):] for k in g if k.startswith("gnorm/")]
-    assert len(names) == 56
+    assert len(names) == (56 if tied else 57)
     for n in names:
         grad = sd[n].grad
         assert grad is not None, n
