@@ -42,6 +42,19 @@ def wide_fixture(tag):
     return meta, dict(np.load(os.path.join(GOLD, f"{tag}_fp32.npz"), allow_pickle=False))
 
 
+def steps_fixture():
+    """G5: four optimizer steps x GA 2 of the reference's loop pieces on the tiny model (tests/golden/gen_golden_steps.py)."""
+    g = dict(np.load(os.path.join(GOLD, "tiny_steps.npz"), allow_pickle=False))
+    types = [["protein", "dna"], ["rna", "pad"]]                     # make_batch's span layout (gen_golden.py)
+
+    def batch(s, k):
+        b = {key: torch.from_numpy(g[f"in/{s}/{k}/{key}"]) for key in ("input_ids", "labels", "attention_mask", "omic_ids")}
+        b["omic_info_list"] = [[{"type": t, "start": int(st)} for t, st in zip(tr, sr)]
+                               for tr, sr in zip(types, g[f"in/{s}/{k}/starts"])]
+        return b
+    return g, batch
+
+
 def tiny_batch(gold, meta):
     return {
         "input_ids": torch.from_numpy(gold["in/input_ids"]),

@@ -235,3 +235,41 @@ def test_real_width_layer_matches_reference(tag):
         assert abs(grad.double().norm().item() - ref) <= 1e-4 * max(ref, 1e-6) + 1e-7, (n, grad.norm().item(), ref)
         np.testing.assert_allclose(grad.flatten()[:256].numpy(), g["ghead/" + n], rtol=0,
                                    atol=2e-6 + 1e-4 * np.abs(g["ghead/" + n]).max())
+
+
+def test_step_loop_trajectory_matches_reference_pieces(tiny_meta):
+    """G5: four optimizer steps with GA = 2 on the reference's OmicsOne driven by torch AdamW, torch
+    clip_grad_norm_ and HF's linear-warmup scheduler in the reference loop's order (gradients SUMMED over the window, lr 0 on
+    the first step).  The oracle's own loop pieces (clip_coef, adamw_step, linear_warmup_lr) must walk the same trajectory."""
+    import math
+    from conftest import steps_fixture
+    g, batch = steps_fixture()
+    GA, STEPS, TOTAL = (int(x) for x in g["meta"])
+    base = float(g["base_lr"])
+    llm, dna, prot = R.cfgs_from_meta(tiny_meta["config"])
+    sd = tiny_state_dict(tiny_meta)
+    names = [k[len("pnorm/"):] for k in g if k.startswith("pnorm/")]
+    for n in names:
+        sd[n].requires_grad_(True)
+    sd["model.lm_head.weight"] = sd["model.model.embed_tokens.weight"]
+    K = tiny_meta["config"]["K"]
+    state = {n: (torch.zeros_like(sd[n]), torch.zeros_like(sd[n])) for n in names}
+    warm = math.ceil(0.1 * TOTAL)
+    for s in range(STEPS):
+        for k in range(GA):
+            loss, _ = R.omics_forward(sd, llm, dna, prot, batch(s, k), {"dna_rna": K, "protein": K})
+            loss.backward()                                             # autograd adds into .grad: the GA sum
+            assert abs(loss.item() - g["loss"][s, k]) < 2e-5, (s, k, loss.item(), g["loss"][s, k])
+        total, coef = R.clip_coef([sd[n].grad for n in names], 1.0)
+        assert abs(total.item() - g["grad_norm"][s]) < 1e-4 * g["grad_norm"][s]
+        lr = R.linear_warmup_lr(s, base, warm, TOTAL)
+        assert abs(lr - g["lr"][s]) < 1e-12
+        with torch.no_grad():
+            for n in names:
+                m, v = state[n]
+                R.adamw_step(sd[n], sd[n].grad * coef, m, v, s + 1, lr, 0.0 if R.is_no_decay(n) else 1e-2)
+                sd[n].grad = None
+    for n in names:
+        ref = float(g["pnorm/" + n])
+        assert abs(sd[n].detach().double().norm().item() - ref) <= 1e-5 * ref + 1e-7, n
+        np.testing.assert_allclose(sd[n].detach().flatten()[:256].numpy(), g["phead/" + n], rtol=0, atol=2e-6)
