@@ -80,3 +80,46 @@ def test_all_gradients_at_real_widths_vs_reference(tag):
         assert err <= bound, (n, err, bound)
         assert abs(got.double().norm().item() - ref_norm) <= 2e-2 * ref_norm + 1e-7, (n, got.norm().item(), ref_norm)
     print(f"{len(names)} tensors, worst error / bound {worst:.3f}")
+
+
+@pytest.mark.parametrize("tag", ["wide", "wide4b"])
+def test_ragged_batch_at_real_widths_vs_oracle(tag):
+    """Fresh seeded batch whose token count is NOT a multiple of any tile (3 x 416 tokens, ragged right-padded text, ragged
+    omic spans) through the production kernels at real widths, against the oracle on the same inputs: partial 256- and
+    128-row tiles, partial attention blocks, the scored-row gather of lm_head + CE; loss and every gradient."""
+    from molly_amd.synth import synth_batch
+    from oracle import molly_ref as R
+    meta, _ = wide_fixture(tag)
+    c = meta["config"]
+    m = _build(meta, train_bio=True)
+    sp = {k: tuple(v) for k, v in c["special_ids"].items()}
+    batch = synth_batch(3, 416, [("protein", 64), ("rna", 64)], seed=11, text_vocab=1000, special_ids=sp, pad_id=1000, ragged=True)
+    loss = m.forward_backward(*[batch[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")])
+    torch.cuda.synchronize()
+    llm, dna, prot = R.cfgs_from_meta(c)
+    sd = tiny_state_dict(meta)
+    tied = c["text"]["tie_word_embeddings"]
+    names = [n for n in m._rt.G.views if not (tied and n == "model.lm_head.weight")]
+    for n in names:
+        sd[n].requires_grad_(True)
+    if tied:
+        sd["model.lm_head.weight"] = sd["model.model.embed_tokens.weight"]
+    ref_loss, _ = R.omics_forward(sd, llm, dna, prot, batch, {"dna_rna": 64, "protein": 64})
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 5e-3, (loss.item(), ref_loss.item())
+    G = m._rt.G.views
+    checked = 0
+    for n in names:
+        ref = sd[n].grad
+        got = G[n].float().cpu()
+        if ref is None or ref.abs().max().item() == 0.0:
+            assert torch.count_nonzero(got) == 0, n
+            continue
+        if n.endswith("key.bias"):
+            continue
+        scale = ref.abs().max().item()
+        rel = (got - ref).abs().max().item() / scale
+        assert rel < 6e-2, (n, rel)
+        assert abs(got.double().norm().item() - ref.double().norm().item()) <= 2e-2 * ref.norm().item() + 1e-7, n
+        checked += 1
+    assert checked >= 50
