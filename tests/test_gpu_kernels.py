@@ -238,6 +238,7 @@ def _attn_ref(q, k, v, B, T, nh, nkv, hd, scale, causal, lo=None, hi=None):
 @pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [
     (128, 4, 2, 256, True, False), (128, 4, 2, 200, True, True), (64, 2, 2, 64, False, True),
     (64, 4, 4, 320, False, False), (128, 2, 1, 512, True, True),
+    (128, 16, 8, 2048, True, False), (128, 8, 2, 4096, True, True), (64, 20, 20, 1024, False, True),   # the step's real lengths
     (16, 20, 20, 200, False, True), (32, 4, 2, 130, True, True), (48, 2, 2, 64, False, False)])    # small-head kernel
 def test_attn_fwd(hd, nh, nkv, T, causal, ragged):
     B = 2
@@ -262,7 +263,8 @@ def test_attn_fwd(hd, nh, nkv, T, causal, ragged):
 
 @pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [
     (128, 4, 2, 256, True, False), (128, 4, 2, 200, True, True), (64, 2, 2, 128, False, True),
-    (128, 2, 1, 320, True, True)])
+    (128, 2, 1, 320, True, True),
+    (128, 16, 8, 2048, True, False), (128, 8, 2, 4096, True, True), (64, 20, 20, 1024, False, False)])   # real lengths
 def test_attn_bwd(hd, nh, nkv, T, causal, ragged):
     B = 2
     M = B * T
