@@ -18,6 +18,7 @@
 // Common: mfma_f32_16x16x32_bf16, global_load_lds 16 B/lane staging with the swizzle on the SOURCE address (LDS image
 // is lane-linear), XOR-swizzled chunks (conflict-free ds_read_b128 / tr reads), XCD-aware tile order, MFMA operands
 // passed swapped so every lane owns 4 CONSECUTIVE n of one row m (8-byte bf16 / 16-byte fp32 stores).
+#include <type_traits>
 #include "common.h"
 #include "molly_hip.h"
 
@@ -35,6 +36,12 @@ struct GemmArgs {
     int splits;               // split-K factor of the 256x256 kernel (1 = none)
     int group_m;              // M-tiles per group in the tile walk of the 256x256 kernel
     float* ws;                // fp32 partial slabs [splits][M][N] when splits > 1
+    // grouped launch (gemm256_kernel<..., GRP>): up to 4 problems sharing K, layouts and epilogue flags; one work list
+    int ngroup;
+    struct Group {
+        const bf16_t* A; const bf16_t* B; void* C;
+        int M, N, lda, ldb, ldc, tiles_m, tiles_n, trans_out, work0;
+    } grp[4];
 };
 
 // ---- k-contiguous operand: tile [ROWS][64] bf16 (128-B LDS rows); one wave-instruction = 8 rows (1 KiB).
@@ -288,7 +295,11 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 // Arithmetic intensity 128 flop/B of L2->LDS traffic (2x the 128² tile): the per-CU vector-memory path (64 B/clk) and
 // the matrix pipe are no longer at a 1:1 ridge.
 // ================================================================================================
-template <bool AT, bool BT, bool TO = false, bool P2 = false>
+// GRP: grouped launch — the work list concatenates the tiles of up to 4 problems (p.grp) that share K, the operand layouts
+// and the epilogue flags; each keeps its own pointers, sizes and transposed-output choice (TO is ignored).  The weight-
+// gradient GEMMs of one decoder layer are 64 + 128 + 192 + 384 = 768 tiles = three full rounds of 256 CUs: one launch, no
+// split-K slabs, no reduce launches.
+template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
     constexpr int NWI = P2 ? 4 : 8;                   // waves that stage one operand
@@ -302,22 +313,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // is more than one round, so a block's XCD label v&7 never changes).  The first two K-tiles of the NEXT tile are issued
     // before the epilogue stores of the current one, so neither the prologue load latency nor the store tail idles the
     // matrix pipe between tiles.
-    const int nwork = p.tiles_m * p.tiles_n * p.splits;
-    const int ntile = p.tiles_m * p.tiles_n;
+    // the problem the block is working on (never changes outside a grouped launch)
+    const bf16_t* cA = p.A; const bf16_t* cB = p.B; void* cC = p.C;
+    int cM = p.M, cN = p.N, clda = p.lda, cldb = p.ldb, cldc = p.ldc, ctm = p.tiles_m, ctn = p.tiles_n;
+    bool cto = TO;
+    const int nwork = GRP ? p.grp[p.ngroup - 1].work0 + p.grp[p.ngroup - 1].tiles_m * p.grp[p.ngroup - 1].tiles_n
+                          : p.tiles_m * p.tiles_n * p.splits;
+    int ntile = p.tiles_m * p.tiles_n;
     const int nk_all = (p.K + BK - 1) / BK;
     int m0, n0, split, kt0, nk;
     auto decode = [&](int v) {
         const int q = nwork >> 3, r = nwork & 7, xcd = v & 7;
-        const int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        if constexpr (GRP) {
+            int gi = 0;
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
+                if (t < p.ngroup && work >= p.grp[t].work0) gi = t;
+            const GemmArgs::Group& G = p.grp[gi];
+            cA = G.A; cB = G.B; cC = G.C; cM = G.M; cN = G.N; clda = G.lda; cldb = G.ldb; cldc = G.ldc;
+            ctm = G.tiles_m; ctn = G.tiles_n; cto = G.trans_out != 0;
+            work -= G.work0;
+            ntile = ctm * ctn;
+        }
         // K-slice is the SLOWEST index: the work items that run side by side on one XCD then belong to one slice and
         // keep sharing operand panels through its L2 (slices of one tile share nothing: they read different K ranges)
         split = work / ntile;
         const int swz = work - split * ntile;
         const int GROUP_M = p.group_m;
-        const int per_group = GROUP_M * p.tiles_n;
+        const int per_group = GROUP_M * ctn;
         const int grp = swz / per_group;
         const int first_m = grp * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int gsz = min(ctm - first_m, GROUP_M);
         m0 = (first_m + (swz % per_group) % gsz) * 256;
         n0 = ((swz % per_group) / gsz) * 256;
         kt0 = (int)((long)nk_all * split / p.splits);
@@ -336,11 +363,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int kt = kt0 + ktl;
         bf16_t* dst = which < 2 ? smem + ((ktl % 3) * 2 + which) * HT : smem + (6 + (ktl & 1) * 2 + (which - 2)) * HT;
         if (which < 2) {
-            if (AT) stage_km<128, NWI, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, p.K, p.zeros, dst, wi, lane);
-            else stage_kc<128, NWI, BK>(p.A, p.lda, m0 + which * 128, p.M, kt * BK, dst, wi, lane);
+            if (AT) stage_km<128, NWI, BK>(cA, clda, m0 + which * 128, cM, kt * BK, p.K, p.zeros, dst, wi, lane);
+            else stage_kc<128, NWI, BK>(cA, clda, m0 + which * 128, cM, kt * BK, dst, wi, lane);
         } else {
-            if (BT) stage_km<128, NWI, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, p.K, p.zeros, dst, wi, lane);
-            else stage_kc<128, NWI, BK>(p.B, p.ldb, n0 + (which - 2) * 128, p.N, kt * BK, dst, wi, lane);
+            if (BT) stage_km<128, NWI, BK>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, p.K, p.zeros, dst, wi, lane);
+            else stage_kc<128, NWI, BK>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, dst, wi, lane);
         }
     };
     const int fr = lane & 15, fq = lane >> 4;
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-            acc[(MH) * 4 + i][(NH) * 2 + j] = TO                                                            \
+            acc[(MH) * 4 + i][(NH) * 2 + j] = TOQ                                                           \
                 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[kk][i], BF[kk][j], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0) \
                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[kk][j], AF[kk][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                      \
@@ -411,6 +438,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     bf16x8 af[2][4], b0[2][2], b1[2][2];
     int abuf = 0;
     if constexpr (P2) {
+        auto kloop = [&](auto to_tag) {
+        constexpr bool TOQ = decltype(to_tag)::value;
         // TWO phases per K-tile (32 MFMAs per compute segment, 4 barriers per K-tile instead of 8):
         //   LA: read B(n0), B(n1), A(m0)                              | CA: quadrants (m0,n0), (m0,n1)
         //   LB: read A(m1); stage own operand of K-tile T+2; counted  | CB: quadrants (m1,n1), (m1,n0)
@@ -448,7 +477,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             SEG_BARRIER();
             abuf = abuf == 2 ? 0 : abuf + 1;
         }
+        };
+        if constexpr (GRP) {
+            if (cto) kloop(std::true_type{});
+            else kloop(std::false_type{});
+        } else {
+            kloop(std::integral_constant<bool, TO>{});
+        }
     } else {
+    constexpr bool TOQ = TO;
     for (int T = 0; T < nk; ++T) {
         const int bbuf = T & 1;
         // ---- P0: quadrant (m0,n0)
@@ -492,6 +529,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
     // this tile's coordinates for the epilogue; then decode + prefetch the next tile BEFORE the stores
     const int em0 = m0, en0 = n0, esplit = split;
+    void* const eC = cC;
+    const int eM = cM, eN = cN, eldc = cldc;
+    const bool eto = cto;
     const int vnext = vcur + gridDim.x;
     const bool more = vnext < nwork;
     if (more) {
@@ -499,35 +539,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
         if (nk > 1) { issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3); }
     }
-    exact_stores = em0 + 256 <= p.M && en0 + 256 <= p.N &&
+    exact_stores = em0 + 256 <= eM && en0 + 256 <= eN &&
                    !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE));
 
-    if constexpr (TO) {
+    if (GRP ? eto : TO) {
         // transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr];
         // C^T is stored as [N][M] (ld = ldc), i.e. 4 consecutive m of one n -> 8-byte bf16 / 16-byte fp32 stores.
         const bool accum = p.flags & MOLLY_GEMM_ACCUMULATE, out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
         const int fr_ = lane & 15, fq_ = lane >> 4;
-        float* slab = p.splits > 1 ? p.ws + (size_t)esplit * p.M * p.N : nullptr;
+        float* slab = p.splits > 1 ? p.ws + (size_t)esplit * eM * eN : nullptr;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = em0 + wr * 128 + i * 16 + fq_ * 4;
-            if (m >= p.M) continue;                                   // M % 4 == 0 checked by the host
+            if (m >= eM) continue;                                   // M % 4 == 0 checked by the host
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = en0 + wc * 64 + j * 16 + fr_;
-                if (n >= p.N) continue;
+                if (n >= eN) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (slab) {
-                    *reinterpret_cast<f32x4*>(slab + (size_t)n * p.M + m) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(slab + (size_t)n * eM + m) = f32x4{v[0], v[1], v[2], v[3]};
                 } else if (out_f32) {
-                    float* c = reinterpret_cast<float*>(p.C) + (size_t)n * p.ldc + m;
+                    float* c = reinterpret_cast<float*>(eC) + (size_t)n * eldc + m;
                     if (accum) {
                         const f32x4 o = *reinterpret_cast<const f32x4*>(c);
                         v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
                     }
                     *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
-                    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)n * p.ldc + m;
+                    bf16_t* c = reinterpret_cast<bf16_t*>(eC) + (size_t)n * eldc + m;
                     if (accum) {
                         const u32x2 o = *reinterpret_cast<const u32x2*>(c);
                         v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
@@ -539,16 +579,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     } else if (p.splits > 1) {
         // split-K: plain fp32 partial slab of this slice; molly's splitk_reduce kernel sums the slabs (launch-boundary
         // reduce: cheaper than an in-launch combine at these slab sizes, guide §5 "Projection GEMM" item 2)
-        float* slab = p.ws + (size_t)esplit * p.M * p.N;
+        float* slab = p.ws + (size_t)esplit * eM * eN;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = em0 + wr * 128 + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
+            if (m >= eM) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = en0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-                if (n >= p.N) continue;
-                *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
+                if (n >= eN) continue;
+                *reinterpret_cast<f32x4*>(slab + (size_t)m * eN + n) = acc[i][j];
             }
         }
     } else {
@@ -560,11 +600,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = em0 + wr * 128 + i * 16 + fr;
-        if (m >= p.M) continue;
+        if (m >= eM) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = en0 + wc * 64 + j * 16 + fq * 4;
-            if (n >= p.N) continue;
+            if (n >= eN) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (has_bias) {
                 const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
@@ -579,14 +619,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
             }
             if (out_f32) {
-                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                float* c = reinterpret_cast<float*>(eC) + (size_t)m * eldc + n;
                 if (accum) {
                     const f32x4 o = *reinterpret_cast<const f32x4*>(c);
                     v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
                 }
                 *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
             } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+                bf16_t* c = reinterpret_cast<bf16_t*>(eC) + (size_t)m * eldc + n;
                 if (accum) {
                     const u32x2 o = *reinterpret_cast<const u32x2*>(c);
                     v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
@@ -759,6 +799,7 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)res;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres; p.flags = flags;
+    p.ngroup = 0;
     static const bf16_t* zeros = nullptr;
     if (!zeros) {
         void* zp = nullptr;
@@ -815,6 +856,51 @@ extern "C" int molly_gemm_last_config(void) { return g_last_cfg; }
 extern "C" int molly_gemm_set_group_m(int g) {
     MOLLY_CHECK(g >= 1 && g <= 64, "gemm_set_group_m: %d", g);
     g_group_m = g;
+    return 0;
+}
+
+extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {
+    MOLLY_CHECK(problems && count >= 1 && count <= 4, "gemm_grouped: 1..4 problems (count=%d)", count);
+    MOLLY_CHECK(K > 0 && !(flags & ~(MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_OUT_F32)),
+                "gemm_grouped: K=%d, flags 0x%x (accumulate / fp32 output only)", K, flags);
+    GemmArgs p{};
+    p.K = K; p.flags = flags; p.splits = 1; p.ws = nullptr; p.group_m = g_group_m; p.ngroup = count;
+    {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) {
+            molly_set_error("gemm_grouped: cannot resolve the zero page");
+            return 3;
+        }
+        p.zeros = (const bf16_t*)zp;
+    }
+    int work = 0;
+    for (int i = 0; i < count; ++i) {
+        const molly_gemm_problem& q = problems[i];
+        MOLLY_CHECK(q.A && q.B && q.C && q.M > 0 && q.N > 0, "gemm_grouped: problem %d is empty", i);
+        MOLLY_CHECK(q.N % 8 == 0 && q.M % 4 == 0, "gemm_grouped: problem %d: N=%d must be a multiple of 8, M=%d of 4", i, q.N, q.M);
+        MOLLY_CHECK(q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 4 == 0, "gemm_grouped: problem %d: lda/ldb multiples of 8, ldc of 4", i);
+        MOLLY_CHECK(((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0 && ((uintptr_t)q.C % 16) == 0,
+                    "gemm_grouped: problem %d: operands must be 16-byte aligned", i);
+        MOLLY_CHECK(K % 64 == 0, "gemm_grouped: K=%d must be a multiple of 64 (k-contiguous A)", K);
+        GemmArgs::Group& G = p.grp[i];
+        G.A = (const bf16_t*)q.A; G.B = (const bf16_t*)q.B; G.C = q.C;
+        G.M = q.M; G.N = q.N; G.lda = q.lda; G.ldb = q.ldb; G.ldc = q.ldc;
+        G.tiles_m = cdiv(q.M, 256); G.tiles_n = cdiv(q.N, 256); G.trans_out = q.trans_out; G.work0 = work;
+        work += G.tiles_m * G.tiles_n;
+    }
+    // the single-problem fields describe problem 0 (never read by the grouped kernel beyond its initial values)
+    p.A = p.grp[0].A; p.B = p.grp[0].B; p.C = p.grp[0].C; p.M = p.grp[0].M; p.N = p.grp[0].N;
+    p.lda = p.grp[0].lda; p.ldb = p.grp[0].ldb; p.ldc = p.grp[0].ldc; p.tiles_m = p.grp[0].tiles_m; p.tiles_n = p.grp[0].tiles_n;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, true, false, true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr = true;
+    }
+    const int grid = g_persist_blocks > 0 ? min(work, g_persist_blocks) : work;
+    g_last_cfg = 512 + 1000 + 100000 * count;
+    hipLaunchKernelGGL((gemm256_kernel<false, true, false, true, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
+    MOLLY_LAUNCH_CHECK();
     return 0;
 }
 

@@ -85,6 +85,37 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
+def gemm_grouped(problems, accumulate: bool = False):
+    """Up to 4 GEMMs out_i (+)= a_i @ b_i in ONE persistent launch (molly_gemm_grouped_bf16): a_i [M_i, K] k-contiguous, b_i [K, N_i]
+    k-major, all sharing K; `problems` = [(a, b, out, trans_out)], trans_out: out_i is [N_i, M_i].  No split-K, no reduce."""
+    assert 1 <= len(problems) <= 4
+    K = problems[0][0].shape[1]
+    desc = torch.empty(len(problems), 6, dtype=torch.int64)
+    flags = GEMM_ACCUMULATE if accumulate else 0
+    f32 = problems[0][2].dtype == torch.float32
+    for i, (a, b, out, to) in enumerate(problems):
+        _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, None, "out")
+        M, N = a.shape[0], b.shape[1]
+        assert a.shape[1] == K and b.shape[0] == K and tuple(out.shape) == ((N, M) if to else (M, N)), (a.shape, b.shape, out.shape, to)
+        assert (out.dtype == torch.float32) == f32
+        desc[i, 0], desc[i, 1], desc[i, 2] = a.data_ptr(), b.data_ptr(), out.data_ptr()
+        desc[i, 3] = M | (N << 32)
+        desc[i, 4] = a.stride(0) | (b.stride(0) << 32)
+        desc[i, 5] = out.stride(0) | (int(bool(to)) << 32)
+    if f32:
+        flags |= GEMM_OUT_F32
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib().call("molly_gemm_grouped_bf16", _stream(), desc.data_ptr(), len(problems), K, flags)
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append((e0, e1, sum(2.0 * a.shape[0] * b.shape[1] * K for a, b, _, _ in problems),
+                     lib().query("molly_gemm_last_config"), (False, True)))
+
+
 def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(x, BF16, "x")
     R, C = x.shape

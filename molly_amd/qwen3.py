@@ -14,6 +14,8 @@ GEMM forms: forward  y = x W^T          -> A=x k-contiguous, B=W k-c
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, Optional
 
@@ -59,6 +61,7 @@ class Qwen3Engine:
         self.rope_table_dtype = rope_table_dtype
         self.cap = 0
         self.tT = None
+        self.tTg, self._pend = None, []   # grouped per-layer weight gradients (reserve)
         self.grads_final_hook = None      # callable(lo, hi): flat-offset range of gradients that became final (ZeRO overlap)
         self.wait_params_hook = None      # callable(lo, hi): block the stream until those parameters are all-gathered
         self._views()
@@ -127,6 +130,15 @@ class Qwen3Engine:
             self.delta = e(B, self.nh, T, dt=torch.float32)
             self.hn_s = e(M, h); self.dh_s = e(M, h)                       # compacted scored rows (head GEMMs)
             self.tT = e(max(h, self.nh * self.hd) * M)                     # transposed narrow operand of the wgrad GEMMs
+            # the four weight-gradient GEMMs of a layer as ONE grouped launch (no split-K, no reduce launches) when their
+            # 256x256 tiles fill whole rounds of the 256 CUs: each keeps its own transposed narrow operand until the launch
+            self.tTg, self._pend = None, []
+            if self.train_base and M % 64 == 0 and os.environ.get("MOLLY_GROUPED_WGRAD", "1") != "0":
+                dims = [(self.nqkv, h), (h, self.nh * self.hd), (2 * ff, h), (h, ff)]        # (out, in) of qkv, o, gate|up, down
+                if all(min(n, k) % 64 == 0 for n, k in dims):
+                    tiles = sum(-(-n // 256) * -(-k // 256) for n, k in dims)
+                    if tiles / (-(-tiles // 256) * 256) >= 0.85:
+                        self.tTg = [e(min(n, k) * M) for n, k in dims]
             if not self.train_base:
                 self.junk = torch.zeros(max(h, 2 * self.hd), dtype=BF16, device=dev)   # gain gradients nobody reads
             # split-K scratch for the wgrad GEMMs: 8 slabs of the largest per-layer weight
@@ -243,6 +255,28 @@ class Qwen3Engine:
             ops.gemm(dt, lo.A[i][mod], out=dx, accumulate=True, b_kmajor=True)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
+    def _wgrad_layer(self, slot: int, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
+        """One of the four per-layer weight gradients (slot: 0 qkv, 1 o, 2 gate|up, 3 down).  With the grouped path the
+        narrow operand is transposed NOW (while it is hot) into the slot's own buffer and the GEMM is deferred to
+        `_wgrad_flush`; dy / x must stay unchanged until then (they do: see the call sites)."""
+        if self.tTg is None:
+            return self._wgrad(dy, x, dw, accumulate)
+        M, N = dy.shape
+        K = x.shape[1]
+        if K <= N:                                             # dw^T[K,N] = (x^T)[K,M] dy[M,N], stored transposed into dw
+            xt = self.tTg[slot][:K * M].view(K, M)
+            ops.transpose(x, xt)
+            self._pend.append((xt, dy, dw, True))
+        else:                                                  # dw[N,K] = (dy^T)[N,M] x[M,K]
+            dyt = self.tTg[slot][:N * M].view(N, M)
+            ops.transpose(dy, dyt)
+            self._pend.append((dyt, x, dw, False))
+
+    def _wgrad_flush(self, accumulate: bool):
+        if self._pend:
+            ops.gemm_grouped(self._pend, accumulate=accumulate)
+            self._pend = []
+
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
         """dw[N,K] (+)= dy[M,N]^T x[M,K], contraction over the M token rows.
         Fast form (tokens % 64 == 0): transpose the NARROWER operand once (an HBM-bound pass over the smaller matrix) and
@@ -332,7 +366,7 @@ class Qwen3Engine:
             if lora is not None:
                 self._lora_bwd(i, a, "down_proj", a["act"], dx, self.d_act, accumulate)
             if tb:
-                self._wgrad(dx, a["act"], g["down"], accumulate)
+                self._wgrad_layer(3, dx, a["act"], g["down"], accumulate)
             ops.swiglu_bwd(a["gu"], self.d_act, self.d_gu)
             dxn2 = spare[0]
             self._dgrad(self.d_gu, w["gu"], dxn2)
@@ -340,7 +374,7 @@ class Qwen3Engine:
                 self._lora_bwd(i, a, "gate_proj", a["xn2"], self.d_gu[:, :self.ff], dxn2, accumulate)
                 self._lora_bwd(i, a, "up_proj", a["xn2"], self.d_gu[:, self.ff:], dxn2, accumulate)
             if tb:
-                self._wgrad(self.d_gu, a["xn2"], g["gu"], accumulate)
+                self._wgrad_layer(2, self.d_gu, a["xn2"], g["gu"], accumulate)
             dx2 = spare[1]
             ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, gw(g, "ln2"), cfg.rms_norm_eps, dres=dx, dx=dx2,
                             dw_accumulate=acc_n, workspace=self.ws)
@@ -349,7 +383,7 @@ class Qwen3Engine:
             if lora is not None:
                 self._lora_bwd(i, a, "o_proj", a["attn"], dx2, self.d_attn, accumulate)
             if tb:
-                self._wgrad(dx2, a["attn"], g["o"], accumulate)
+                self._wgrad_layer(1, dx2, a["attn"], g["o"], accumulate)
             ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
                          self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta)
@@ -363,7 +397,9 @@ class Qwen3Engine:
                 self._lora_bwd(i, a, "k_proj", a["xn"], self.d_qkv[:, nq:nq + nk_], dxn, accumulate)
                 self._lora_bwd(i, a, "v_proj", a["xn"], self.d_qkv[:, nq + nk_:], dxn, accumulate)
             if tb:
-                self._wgrad(self.d_qkv, a["xn"], g["qkv"], accumulate)
+                self._wgrad_layer(0, self.d_qkv, a["xn"], g["qkv"], accumulate)
+                # dx, d_gu, dx2 and d_qkv are all still intact here (the norm backward below overwrites dx)
+                self._wgrad_flush(accumulate)
             ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, gw(g, "ln1"), cfg.rms_norm_eps, dres=dx2, dx=dx,
                             dw_accumulate=acc_n, workspace=self.ws)
             if tb and final_micro and self.grads_final_hook is not None:

@@ -569,3 +569,27 @@ def test_gelu_epilogue_erf_accuracy_over_the_whole_range():
     zr = z.float().requires_grad_(True)
     torch.nn.functional.gelu(zr).sum().backward()
     assert (dz - zr.grad).abs().max().item() <= 8e-3
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_grouped_equals_separate_launches(accumulate):
+    """Grouped launch (the four weight-gradient GEMMs of a layer in one persistent launch, mixed transposed / plain outputs,
+    ragged sizes): bit-identical to the unsplit single-problem kernel on every problem, whatever was in the outputs before."""
+    K = 1024 + 64
+    shapes = [(512, 768, True), (256, 264, False), (1000, 512, True), (260, 1032, False)]       # (M, N, trans_out)
+    probs, refs = [], []
+    for i, (M, N, to) in enumerate(shapes):
+        a = _rand(M, K, seed=70 + i).to(BF)
+        b = _rand(K, N, seed=80 + i).to(BF)
+        init = _rand(*((N, M) if to else (M, N)), seed=90 + i).to(BF)
+        out = init.clone()
+        ref = init.clone()
+        lib().call("molly_gemm_force_tile", 512)                       # the unsplit 256x256 kernel
+        ops.gemm(a, b, out=ref, accumulate=accumulate, b_kmajor=True, trans_out=to)
+        lib().call("molly_gemm_force_tile", 0)
+        probs.append((a, b, out, to))
+        refs.append(ref)
+    ops.gemm_grouped(probs, accumulate=accumulate)
+    torch.cuda.synchronize()
+    for (a, b, out, to), ref in zip(probs, refs):
+        assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
