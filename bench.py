@@ -225,7 +225,9 @@ def main():
                  (True, True): "TN gemm256_kernel<true,true>"}
         for t, f, kcfg, lay in timed:
             key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64>"
-            if kcfg // 1000 > 1:
+            if kcfg >= 100000:                    # grouped launch: cfg = 512 + 1000 + 100000 * problems
+                key += f" grouped x{kcfg // 100000} (a layer's weight gradients in one launch)"
+            elif kcfg // 1000 > 1:
                 key += " + splitk_reduce"
             d = by_kernel.setdefault(key, [0, 0.0, 0.0])
             d[0] += 1; d[1] += t; d[2] += f
