@@ -136,8 +136,13 @@ class Qwen3Engine:
             if self.train_base and M % 64 == 0 and os.environ.get("MOLLY_GROUPED_WGRAD", "1") != "0":
                 dims = [(self.nqkv, h), (h, self.nh * self.hd), (2 * ff, h), (h, ff)]        # (out, in) of qkv, o, gate|up, down
                 if all(min(n, k) % 64 == 0 for n, k in dims):
-                    tiles = sum(-(-n // 256) * -(-k // 256) for n, k in dims)
-                    if tiles / (-(-tiles // 256) * 256) >= 0.85:
+                    per = [-(-n // 256) * -(-k // 256) for n, k in dims]
+                    eff = lambda t: t / (-(-t // 256) * 256)
+                    # worth it when the single launches would go through split-K (their own grids do not fill the chip:
+                    # Qwen3-0.6B/1.7B widths) and the combined grid does; where every weight gradient fills the chip by
+                    # itself (4B: two of four, 8B: all) deferring the GEMMs only costs cache locality (measured -2...-4 %)
+                    split = sum(1 for t in per if not (t >= 200 and eff(t) >= 0.8))
+                    if split >= 3 and eff(sum(per)) >= 0.85:
                         self.tTg = [e(min(n, k) * M) for n, k in dims]
             if not self.train_base:
                 self.junk = torch.zeros(max(h, 2 * self.hd), dtype=BF16, device=dev)   # gain gradients nobody reads
