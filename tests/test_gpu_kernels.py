@@ -571,8 +571,9 @@ def test_gelu_epilogue_erf_accuracy_over_the_whole_range():
     assert (dz - zr.grad).abs().max().item() <= 8e-3
 
 
+@pytest.mark.parametrize("persist", [256, 0, 8])
 @pytest.mark.parametrize("accumulate", [False, True])
-def test_gemm_grouped_equals_separate_launches(accumulate):
+def test_gemm_grouped_equals_separate_launches(accumulate, persist):
     """Grouped launch (the four weight-gradient GEMMs of a layer in one persistent launch, mixed transposed / plain outputs,
     ragged sizes): bit-identical to the unsplit single-problem kernel on every problem, whatever was in the outputs before."""
     K = 1024 + 64
@@ -589,7 +590,11 @@ def test_gemm_grouped_equals_separate_launches(accumulate):
         lib().call("molly_gemm_force_tile", 0)
         probs.append((a, b, out, to))
         refs.append(ref)
-    ops.gemm_grouped(probs, accumulate=accumulate)
+    lib().call("molly_gemm_set_persistent_blocks", persist)          # one block per CU / per tile (multi-rank setting) / few
+    try:
+        ops.gemm_grouped(probs, accumulate=accumulate)
+    finally:
+        lib().call("molly_gemm_set_persistent_blocks", 256)
     torch.cuda.synchronize()
     for (a, b, out, to), ref in zip(probs, refs):
         assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
