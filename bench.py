@@ -235,9 +235,9 @@ def main():
                          "achieved_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in by_kernel.items()}
         step_ms = [a.elapsed_time(b) for a, b in step_ev]
         # HBM-side traffic of the dominant kernel cannot be counted live (PMC needs rocprofv3): quote the committed PMC
-        # passes of this same workload (profiles/r01_pmc_hbm_traffic.csv; corrected as MI355X_MICROARCH.md §HBM prescribes)
+        # passes of this same workload (profiles/r01b_pmc_hbm_traffic.csv, tools/pmc_hbm_traffic.py; corrected as MI355X_MICROARCH.md §HBM prescribes)
         traffic, traffic_src = None, None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_hbm_traffic.json")
         if args.train_mode == "full" and (B, T, K, args.model) == (8, 2048, 512, "1.7b") and os.path.exists(tj):
             with open(tj) as f:
                 tr = json.load(f)
