@@ -52,11 +52,12 @@ int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const v
 
 /* fp32 scratch the GEMM may use for split-K partial slabs (wgrad shapes whose 256x256 grid would not fill the chip);
  * caller-owned device memory, stays valid until replaced; NULL / 0 disables split-K. */
-/* Grouped launch of up to 4 GEMMs that share K, the operand layouts (A k-contiguous [M][K], B k-major [K][N]: the dgrad /
+/* Grouped launch of up to 16 GEMMs that share K, the operand layouts (A k-contiguous [M][K], B k-major [K][N]: the dgrad /
  * weight-gradient form) and the epilogue flags (MOLLY_GEMM_ACCUMULATE, MOLLY_GEMM_OUT_F32); each problem has its own
  * pointers, sizes and transposed-output choice (trans_out != 0: C is [N][M], ldc >= M).  One persistent launch walks the
  * concatenated tile list: the four weight-gradient GEMMs of a decoder layer (64 + 128 + 192 + 384 tiles of 256 x 256 =
- * three full rounds of the 256 CUs) need no split-K slabs and no reduce launches.  `problems` is a HOST array. */
+ * three full rounds of the 256 CUs) need no split-K slabs and no reduce launches; the fourteen rank-r adapter gradients of a
+ * layer (dA, dB of seven targets) are one launch instead of fourteen split-K pairs.  `problems` is a HOST array. */
 typedef struct {
     const void* A; const void* B; void* C;
     int M, N, lda, ldb, ldc, trans_out;

@@ -36,12 +36,12 @@ struct GemmArgs {
     int splits;               // split-K factor of the 256x256 kernel (1 = none)
     int group_m;              // M-tiles per group in the tile walk of the 256x256 kernel
     float* ws;                // fp32 partial slabs [splits][M][N] when splits > 1
-    // grouped launch (gemm256_kernel<..., GRP>): up to 4 problems sharing K, layouts and epilogue flags; one work list
+    // grouped launch (gemm256_kernel<..., GRP>): up to 16 problems sharing K, layouts and epilogue flags; one work list
     int ngroup;
     struct Group {
         const bf16_t* A; const bf16_t* B; void* C;
         int M, N, lda, ldb, ldc, tiles_m, tiles_n, trans_out, work0;
-    } grp[4];
+    } grp[16];
 };
 
 // ---- k-contiguous operand: tile [ROWS][64] bf16 (128-B LDS rows); one wave-instruction = 8 rows (1 KiB).
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 // Arithmetic intensity 128 flop/B of L2->LDS traffic (2x the 128² tile): the per-CU vector-memory path (64 B/clk) and
 // the matrix pipe are no longer at a 1:1 ridge.
 // ================================================================================================
-// GRP: grouped launch — the work list concatenates the tiles of up to 4 problems (p.grp) that share K, the operand layouts
+// GRP: grouped launch — the work list concatenates the tiles of up to 16 problems (p.grp) that share K, the operand layouts
 // and the epilogue flags; each keeps its own pointers, sizes and transposed-output choice (TO is ignored).  The weight-
 // gradient GEMMs of one decoder layer are 64 + 128 + 192 + 384 = 768 tiles = three full rounds of 256 CUs: one launch, no
 // split-K slabs, no reduce launches.
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         if constexpr (GRP) {
             int gi = 0;
 #pragma unroll
-            for (int t = 1; t < 4; ++t)
+            for (int t = 1; t < 16; ++t)
                 if (t < p.ngroup && work >= p.grp[t].work0) gi = t;
             const GemmArgs::Group& G = p.grp[gi];
             cA = G.A; cB = G.B; cC = G.C; cM = G.M; cN = G.N; clda = G.lda; cldb = G.ldb; cldc = G.ldc;
@@ -860,7 +860,7 @@ extern "C" int molly_gemm_set_group_m(int g) {
 }
 
 extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {
-    MOLLY_CHECK(problems && count >= 1 && count <= 4, "gemm_grouped: 1..4 problems (count=%d)", count);
+    MOLLY_CHECK(problems && count >= 1 && count <= 16, "gemm_grouped: 1..16 problems (count=%d)", count);
     MOLLY_CHECK(K > 0 && !(flags & ~(MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_OUT_F32)),
                 "gemm_grouped: K=%d, flags 0x%x (accumulate / fp32 output only)", K, flags);
     GemmArgs p{};

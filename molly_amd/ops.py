@@ -86,9 +86,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
 
 
 def gemm_grouped(problems, accumulate: bool = False):
-    """Up to 4 GEMMs out_i (+)= a_i @ b_i in ONE persistent launch (molly_gemm_grouped_bf16): a_i [M_i, K] k-contiguous, b_i [K, N_i]
+    """Up to 16 GEMMs out_i (+)= a_i @ b_i in ONE persistent launch (molly_gemm_grouped_bf16): a_i [M_i, K] k-contiguous, b_i [K, N_i]
     k-major, all sharing K; `problems` = [(a, b, out, trans_out)], trans_out: out_i is [N_i, M_i].  No split-K, no reduce."""
-    assert 1 <= len(problems) <= 4
+    assert 1 <= len(problems) <= 16
     K = problems[0][0].shape[1]
     desc = torch.empty(len(problems), 6, dtype=torch.int64)
     flags = GEMM_ACCUMULATE if accumulate else 0

@@ -116,6 +116,13 @@ class Qwen3Engine:
                     self.A[-1]["lxd"] = {m: e(M, d) for m, d in dims.items()}
         if self.lora is not None:
             self.lora_dt = e(M, self.lora.rp)
+            # adapter gradients (dB, dA of the seven targets) of one layer as ONE grouped launch: each keeps its transposed
+            # rank-r operand (t^T, dt^T: rp x M) until the layer's last dgrad; dropout(x) then has to survive the dA GEMM, so
+            # the masked dx term goes through a buffer of its own
+            self.lora_tT = None
+            if M % 64 == 0 and self.lora.rp % 64 == 0 and os.environ.get("MOLLY_GROUPED_WGRAD", "1") != "0":
+                self.lora_tT = {m: (e(self.lora.rp * M), e(self.lora.rp * M)) for m in LORA_TARGETS}
+                self.lora_tmp = e(M * max(h, ff, self.nh * self.hd))
         self.x_out = e(M, h)
         self.hn = e(M, h)
         self.C = min(self.ce_chunk_rows, M)
@@ -245,15 +252,27 @@ class Qwen3Engine:
     def _lora_bwd(self, i: int, a: dict, mod: str, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool):
         """dB (+)= dy^T t ; dt = s * dy B ; dA (+)= dt^T dropout(x) ; dx += mask * (dt A)."""
         lo = self.lora
-        self._wgrad(dy, a["lt"][mod], lo.dB[i][mod], accumulate)
+        grouped = getattr(self, "lora_tT", None) is not None
+        M = dy.shape[0]
+        if grouped:
+            tt = self.lora_tT[mod][0].view(lo.rp, M)
+            ops.transpose(a["lt"][mod], tt)
+            self._pend.append((tt, dy, lo.dB[i][mod], True))           # dB^T[rp, out] = t^T dy, stored transposed
+        else:
+            self._wgrad(dy, a["lt"][mod], lo.dB[i][mod], accumulate)
         dt = self.lora_dt
         self._dgrad(dy, lo.B[i][mod], dt)
         if lo.scale != 1.0:
             ops.scale_(dt, lo.scale)
         xd = a["lxd"][mod] if lo.p > 0.0 else x                    # the forward's dropout(x), kept
-        self._wgrad(dt, xd, lo.dA[i][mod], accumulate)
+        if grouped:
+            dtt = self.lora_tT[mod][1].view(lo.rp, M)
+            ops.transpose(dt, dtt)
+            self._pend.append((dtt, xd, lo.dA[i][mod], False))         # dA[rp, in] = dt^T dropout(x)
+        else:
+            self._wgrad(dt, xd, lo.dA[i][mod], accumulate)
         if lo.p > 0.0:
-            tmp = xd                                               # dropout(x) is dead after the dA GEMM
+            tmp = self.lora_tmp[:M * x.shape[1]].view(M, x.shape[1]) if grouped else xd   # (ungrouped: dropout(x) is dead by now)
             ops.gemm(dt, lo.A[i][mod], out=tmp, b_kmajor=True)
             ops.dropout(tmp, lo.p, lo.mask_seed(i, mod), out=dx, accumulate=True)
         else:
@@ -401,6 +420,7 @@ class Qwen3Engine:
                 self._lora_bwd(i, a, "q_proj", a["xn"], self.d_qkv[:, :nq], dxn, accumulate)
                 self._lora_bwd(i, a, "k_proj", a["xn"], self.d_qkv[:, nq:nq + nk_], dxn, accumulate)
                 self._lora_bwd(i, a, "v_proj", a["xn"], self.d_qkv[:, nq + nk_:], dxn, accumulate)
+                self._wgrad_flush(accumulate)                  # the layer's fourteen adapter gradients, one launch
             if tb:
                 self._wgrad_layer(0, self.d_qkv, a["xn"], g["qkv"], accumulate)
                 # dx, d_gu, dx2 and d_qkv are all still intact here (the norm backward below overwrites dx)
