@@ -12,6 +12,8 @@ exactly like the reference does (src/train.py:127,143,152); `prepare()` re-homes
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional, Tuple
 
@@ -373,8 +375,12 @@ class OmicsOne(nn.Module):
             self.prepare()
         return self._rt
 
-    def _embed_and_inject(self, input_ids, omic_ids, omic_info_list, B, T, keep_for_backward):
-        """reference: src/model/omics_one.py:164-172 — token embeddings, then encoder -> projector -> overwrite."""
+    def _embed_and_inject(self, input_ids, omic_ids, omic_info_list, B, T, keep_for_backward, wait_embed=None,
+                          wait_proj=None):
+        """reference: src/model/omics_one.py:164-172 — token embeddings, then encoder -> projector -> overwrite.
+        Launch order: the FROZEN encoders run first — they read no trainable parameter, so their ≈8 ms cover the head of the
+        previous step's side-stream AdamW / all-gather (embedding, gains, projectors), which `wait_embed` / `wait_proj` then
+        find finished; the values written are those of the reference's order (lookup, then overwrite)."""
         rt = self._rt
         h = self.text_config.hidden_size
         M = B * T
@@ -383,9 +389,14 @@ class OmicsOne(nn.Module):
         rt.llm.reserve(M, B, T, training=keep_for_backward)
         hs = rt.llm.A[0]["x"] if keep_for_backward else rt.llm.x_out
         ids_dev = input_ids.reshape(-1).to(rt.dev, non_blocking=True)
-        ops.copy_rows(rt.llm.embed, hs, M, src_idx64=ids_dev)
         overwritten = np.zeros(M, dtype=bool)
         saved = {}
+        encoded = []
+        if rt.train_bio or os.environ.get("MOLLY_ENC_FIRST", "1") == "0":   # trained encoders read parameters the optimizer is publishing
+            for w in (wait_embed, wait_proj):
+                if w is not None:
+                    w()
+            wait_embed = wait_proj = None
         if omic_ids is not None:
             for i in range(len(omic_ids)):
                 assert len(omic_ids[i]) == len(omic_info_list[i]), \
@@ -403,12 +414,19 @@ class OmicsOne(nn.Module):
                     enc_out = eng.forward(ids.to(rt.dev, non_blocking=True), training=keep_for_backward and rt.train_bio)
                 except Exception as e:  # reference re-wraps encoder failures (omics_one.py:89-90)
                     raise RuntimeError(f"Error processing omic sequences: {e}")
-                emb = ops.gemm_nt(enc_out, rt.W[proj + ".weight"], bias=rt.W[proj + ".bias"])
-                dst_dev = dst.to(rt.dev, non_blocking=True)
-                ops.copy_rows(emb, hs, emb.shape[0], dst_idx32=dst_dev)
-                valid = dst.numpy() >= 0
-                overwritten[dst.numpy()[valid]] = True
-                saved[name] = (enc_out, dst_dev, proj, eng)
+                encoded.append((name, eng, proj, enc_out, dst))
+        if wait_embed is not None:
+            wait_embed()
+        ops.copy_rows(rt.llm.embed, hs, M, src_idx64=ids_dev)
+        if wait_proj is not None:
+            wait_proj()
+        for name, eng, proj, enc_out, dst in encoded:
+            emb = ops.gemm_nt(enc_out, rt.W[proj + ".weight"], bias=rt.W[proj + ".bias"])
+            dst_dev = dst.to(rt.dev, non_blocking=True)
+            ops.copy_rows(emb, hs, emb.shape[0], dst_idx32=dst_dev)
+            valid = dst.numpy() >= 0
+            overwritten[dst.numpy()[valid]] = True
+            saved[name] = (enc_out, dst_dev, proj, eng)
         return hs, overwritten, saved
 
     @staticmethod
@@ -451,13 +469,15 @@ class OmicsOne(nn.Module):
             raise RuntimeError("forward_backward: nothing is trainable (prepare(train_llm/train_mlp/lora))")
         if opt is not None and not rt.full:
             opt.wait_all_params()                 # small adapter/projector group: no per-layer overlap
-        elif opt is not None:
-            # parameters read before the decoder layers: gains/biases (tail region), projectors, embedding (= tied head)
-            opt.wait_params(self.n_decay, rt.P.numel)
-            opt.wait_params(0, rt.llm.layer_lo[0])
-            opt.wait_params(rt.llm.layers_hi, self.n_decay)
+        wait_embed = wait_proj = None
+        if opt is not None and rt.full:
+            # parameters read before the decoder layers: embedding (= tied head), then gains/biases (tail region) and the
+            # projectors — waited for inside _embed_and_inject, behind the frozen encoders' forward
+            wait_embed = lambda: opt.wait_params(0, rt.llm.layer_lo[0])
+            wait_proj = lambda: (opt.wait_params(self.n_decay, rt.P.numel), opt.wait_params(rt.llm.layers_hi, self.n_decay))
         lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
-        hs, overwritten, saved = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, True)
+        hs, overwritten, saved = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, True, wait_embed,
+                                                        wait_proj)
         shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
         scored = torch.nonzero(shifted != -100).reshape(-1).to(torch.int32)       # host-side: no device sync
         shifted = shifted.to(rt.dev, non_blocking=True)
