@@ -478,6 +478,14 @@ class OmicsOne(nn.Module):
         lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
         hs, overwritten, saved = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, True, wait_embed,
                                                         wait_proj)
+        # the embedding-gradient index (host-side sort) is built and uploaded NOW, while the stream is short: a pageable
+        # host-to-device copy makes the host wait for everything queued before it, which at backward time is the whole step
+        emb_idx = None
+        if rt.train_llm:
+            order, seg, uid = embed_backward_index(input_ids.reshape(-1).cpu().numpy(), overwritten)
+            if len(uid):
+                emb_idx = (torch.from_numpy(order).to(rt.dev), torch.from_numpy(seg).to(rt.dev),
+                           torch.from_numpy(uid).to(rt.dev), len(uid))
         shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
         scored = torch.nonzero(shifted != -100).reshape(-1).to(torch.int32)       # host-side: no device sync
         shifted = shifted.to(rt.dev, non_blocking=True)
@@ -487,11 +495,8 @@ class OmicsOne(nn.Module):
             opt.wait_all_params()
         d_hs = rt.llm.loss_and_backward(accumulate=accumulate, final_micro=final_micro)
         # ---- gradient of the input embeddings: text rows -> embed_tokens, omic rows -> projector
-        if rt.train_llm:
-            order, seg, uid = embed_backward_index(input_ids.reshape(-1).cpu().numpy(), overwritten)
-            if len(uid):
-                ops.embed_bwd(d_hs, torch.from_numpy(order).to(rt.dev), torch.from_numpy(seg).to(rt.dev),
-                              torch.from_numpy(uid).to(rt.dev), len(uid), rt.llm.d_embed)
+        if emb_idx is not None:
+            ops.embed_bwd(d_hs, emb_idx[0], emb_idx[1], emb_idx[2], emb_idx[3], rt.llm.d_embed)
         for name, (enc_out, dst_dev, proj, eng) in saved.items():
             if not (rt.train_mlp or rt.train_bio):
                 break
