@@ -865,14 +865,6 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
                 "gemm_grouped: K=%d, flags 0x%x (accumulate / fp32 output only)", K, flags);
     GemmArgs p{};
     p.K = K; p.flags = flags; p.splits = 1; p.ws = nullptr; p.group_m = g_group_m; p.ngroup = count;
-    {
-        void* zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) {
-            molly_set_error("gemm_grouped: cannot resolve the zero page");
-            return 3;
-        }
-        p.zeros = (const bf16_t*)zp;
-    }
     int work = 0;
     for (int i = 0; i < count; ++i) {
         const molly_gemm_problem& q = problems[i];
@@ -887,6 +879,14 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
         G.M = q.M; G.N = q.N; G.lda = q.lda; G.ldb = q.ldb; G.ldc = q.ldc;
         G.tiles_m = cdiv(q.M, 256); G.tiles_n = cdiv(q.N, 256); G.trans_out = q.trans_out; G.work0 = work;
         work += G.tiles_m * G.tiles_n;
+    }
+    {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) {
+            molly_set_error("gemm_grouped: cannot resolve the zero page");
+            return 3;
+        }
+        p.zeros = (const bf16_t*)zp;
     }
     // the single-problem fields describe problem 0 (never read by the grouped kernel beyond its initial values)
     p.A = p.grp[0].A; p.B = p.grp[0].B; p.C = p.grp[0].C; p.M = p.grp[0].M; p.N = p.grp[0].N;

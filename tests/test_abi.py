@@ -30,6 +30,14 @@ def test_error_channel_and_abi_version():
     # argument validation happens before any launch: callable without a GPU
     rc = m.fn["molly_gemm_nt_bf16"](None, None, None, None, None, None, 128, 128, 48, 48, 48, 128, 0, 0)
     assert rc != 0 and "multiple of 64" in m.last_error()
+    # grouped launch: the problem table is validated on the host before anything touches the GPU
+    rc = m.fn["molly_gemm_grouped_bf16"](None, None, 0, 1024, 0)
+    assert rc != 0 and "1..16 problems" in m.last_error()
+    prob = (ctypes.c_int64 * 6)(16, 32, 48, 256 | (250 << 32), 1024 | (256 << 32), 256)       # N = 250: not a multiple of 8
+    rc = m.fn["molly_gemm_grouped_bf16"](None, ctypes.cast(prob, ctypes.c_void_p), 1, 1024, 0)
+    assert rc != 0 and "multiple of 8" in m.last_error()
+    rc = m.fn["molly_cls_loss_fwd_bwd"](None, None, None, None, None, None, 4, 8, 4, 0, -100, 1)  # ld < V
+    assert rc != 0 and "cls_loss" in m.last_error()
 
 
 def test_product_package_never_imports_the_oracle():
