@@ -123,3 +123,30 @@ def test_ragged_batch_at_real_widths_vs_oracle(tag):
         assert abs(got.double().norm().item() - ref.double().norm().item()) <= 2e-2 * ref.norm().item() + 1e-7, n
         checked += 1
     assert checked >= 50
+
+
+def test_lora_rank64_at_real_widths_vs_oracle():
+    """`--use-lora` at Molly-1.7B's widths: rank-64 adapters on all seven targets of the layer (the production rank: no
+    padding), base frozen, projectors trainable; the fourteen adapter gradients go through ONE grouped launch.  Loss and every
+    adapter / projector gradient against the oracle's autograd on a ragged 3 x 448-token batch (a multiple of 64, not of 256)."""
+    from molly_amd.lora import LoraConfig
+    from molly_amd.synth import synth_batch
+    from oracle import molly_ref as R
+    from test_gpu_lora import _check_grads, _oracle_sd_with_lora, _randomize_B
+    meta, _ = wide_fixture("wide")
+    c = meta["config"]
+    m = _build(meta, train_llm=False, lora=LoraConfig(r=64, lora_alpha=64, lora_dropout=0.0))
+    _randomize_B(m, std=0.02)
+    sp = {k: tuple(v) for k, v in c["special_ids"].items()}
+    b = synth_batch(3, 448, [("protein", 64), ("rna", 64)], seed=13, text_vocab=1000, special_ids=sp, pad_id=1000, ragged=True)
+    loss = m.forward_backward(*[b[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")])
+    torch.cuda.synchronize()
+    assert m._rt.llm.lora_tT is not None                                 # the grouped adapter-gradient path is the one that ran
+    sd, leaves = _oracle_sd_with_lora(meta, m)
+    llm, dna, prot = R.cfgs_from_meta(c)
+    ref_loss, _ = R.omics_forward(sd, llm, dna, prot, b, {"dna_rna": 64, "protein": 64})
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 5e-3, (loss.item(), ref_loss.item())
+    worst = _check_grads(m, leaves)
+    print("worst relative adapter-grad error at real widths", worst)
+    assert len(leaves) == 14 + 4
