@@ -80,6 +80,15 @@ def test_all_gradients_at_real_widths_vs_reference(tag):
         assert err <= bound, (n, err, bound)
         assert abs(got.double().norm().item() - ref_norm) <= 2e-2 * ref_norm + 1e-7, (n, got.norm().item(), ref_norm)
     print(f"{len(names)} tensors, worst error / bound {worst:.3f}")
+    # gradient accumulation through the same launches (grouped weight gradients at the 1.7B widths): a second micro-step on
+    # the same batch with accumulate=True doubles every gradient (bf16 read-modify-write of the first pass's values)
+    g1 = {n: G[n].float().clone() for n in names}
+    m.forward_backward(batch["input_ids"], batch["attention_mask"], batch["omic_ids"], batch["omic_info_list"],
+                       batch["labels"], accumulate=True)
+    torch.cuda.synchronize()
+    for n in names:
+        ref2 = 2 * g1[n]
+        assert (G[n].float() - ref2).abs().max().item() <= 2 ** -7 * ref2.abs().max().item() + 1e-12, n
 
 
 @pytest.mark.parametrize("tag", ["wide", "wide4b"])
