@@ -876,7 +876,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// ESM embeddings (HF:models/esm/modeling_esm.py:224-271,1050-1063).  One block per sequence:
+// ESM embeddings (HF:models/esm/modeling_esm.py:224-271,1050-1063).  gridDim.y blocks per sequence, each rebuilding the
+// sequence's statistics (K ids: nothing) and writing its share of the K x H output rows:
 // mask = ids != pad ; token-dropout rescale (1-0.12)/(1-n_mask/n_valid) ; masked-token rows zeroed ;
 // absolute position ids = cumsum(mask)*mask + pad ; output multiplied by mask.
 // ------------------------------------------------------------------------------------------------
@@ -909,11 +910,12 @@ __global__ __launch_bounds__(256) void esm_embed_kernel(const long* __restrict__
             spos[t] = mk ? run + pad_id : pad_id;
             if (mk) last_valid = t + 1;
         }
-        if (klen_out) klen_out[seq] = last_valid;
+        if (klen_out && blockIdx.y == 0) klen_out[seq] = last_valid;
     }
     __syncthreads();
     const int nch = H >> 3;
-    for (int t = threadIdx.x; t < K * nch; t += 256) {
+    const int per = (K + gridDim.y - 1) / gridDim.y, t_lo = blockIdx.y * per, t_hi = min(K, t_lo + per);
+    for (int t = t_lo * nch + threadIdx.x; t < t_hi * nch; t += 256) {
         const int tok = t / nch, c = t % nch;
         const long id = sid[tok];
         u32x4 o = u32x4{0, 0, 0, 0};
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(256) void esm_embed_kernel(const long* __restrict__
         }
         *reinterpret_cast<u32x4*>(out + ((size_t)seq * K + tok) * H + c * 8) = o;
     }
-    if (pos_out)
+    if (pos_out && blockIdx.y == 0)
         for (int t = threadIdx.x; t < K; t += 256) pos_out[(size_t)seq * K + t] = spos[t];
 }
 
@@ -1259,7 +1261,9 @@ extern "C" int molly_esm_embed(void* stream, const int64_t* ids, const void* wor
                                int* pos_ids_out, int* kv_len_out, int n_seq, int K, int H, int pad_id, int mask_id,
                                int token_dropout) {
     MOLLY_CHECK(n_seq > 0 && K > 0 && K <= 8192 && H % 8 == 0, "esm_embed: bad shape n_seq=%d K=%d H=%d", n_seq, K, H);
-    hipLaunchKernelGGL(esm_embed_kernel, dim3(n_seq), dim3(256), K * sizeof(int), ST, (const long*)ids,
+    // enough blocks to fill the chip whatever the number of sequences (one block per sequence left 8 CUs busy)
+    const int parts = max(1, min(K / 8, cdiv(1024, n_seq)));
+    hipLaunchKernelGGL(esm_embed_kernel, dim3(n_seq, parts), dim3(256), K * sizeof(int), ST, (const long*)ids,
                        (const bf16_t*)word_emb, (const bf16_t*)pos_emb, (bf16_t*)out, pos_ids_out, kv_len_out, K, H, pad_id,
                        mask_id, token_dropout);
     MOLLY_LAUNCH_CHECK();
