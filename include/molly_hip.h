@@ -71,6 +71,8 @@ int molly_gemm_set_group_m(int g);
 /* tuning hook: resident blocks of the persistent 256x256 kernel (default 256 = one per CU; multiple of 8);
  * 0 = launch one block per tile. */
 int molly_gemm_set_persistent_blocks(int n);
+/* split-K: shortest K-slice, in 64-wide K-tiles, the heuristic accepts for a grid that is not skinny (default 16). */
+int molly_gemm_set_min_ktiles(int n);
 /* tuning hook: barrier schedule of the 256x256 kernel: 0 = four phases (16 MFMAs each) per K-tile, 1 = two phases (32 MFMAs),
  * -1 (default) = two phases for the forms with a k-major B operand, four for the rest (what measured faster). */
 int molly_gemm_set_schedule(int mode);

@@ -692,6 +692,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int g_group_m = 4;
 int g_schedule = -1;              // 256x256 kernel: -1 = per form, 0 = four phases per K-tile, 1 = two phases per K-tile
 int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile
+int g_min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
 int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 float* g_ws = nullptr;
 size_t g_ws_bytes = 0;
@@ -726,7 +727,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             const long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, BN);
             // (decode GEMMs, M = batch rows: a pure weight stream — slices down to 4 K-tiles)
             const bool skinny = (p.M < 256 || p.N < 256) && t128 < 256;
-            const int min_kt = skinny ? ((p.M < 64 || p.N < 64) ? 4 : 8) : 16;
+            const int min_kt = skinny ? ((p.M < 64 || p.N < 64) ? 4 : 8) : g_min_ktiles;
             int best = 0;
             double best_score = 0.0;
             for (int sp : {2, 3, 4, 6, 8, 12, 16, 24, 32}) {
@@ -907,6 +908,12 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
 extern "C" int molly_gemm_set_schedule(int mode) {
     MOLLY_CHECK(mode >= -1 && mode <= 1, "gemm_set_schedule: %d not in {-1,0,1}", mode);
     g_schedule = mode;
+    return 0;
+}
+
+extern "C" int molly_gemm_set_min_ktiles(int n) {
+    MOLLY_CHECK(n >= 2 && n <= 64, "gemm_set_min_ktiles: %d not in 2..64", n);
+    g_min_ktiles = n;
     return 0;
 }
 

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--a", type=int, required=True)
     ap.add_argument("--b", type=int, required=True)
     ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=8)
     args = ap.parse_args()
     import molly_amd
     from molly_amd import config as C
@@ -32,7 +33,7 @@ def main():
     m.prepare("cuda", random_init_seed=1234)
     opt = Zero2Optimizer(m._rt.P.flat, m._rt.G.flat, m.n_decay, lr=3e-5)
     m.attach_optimizer(opt)
-    b = synth_batch(8, 2048, [("protein", 512)], seed=42)
+    b = synth_batch(args.batch, 2048, [("protein", 512)], seed=42)
     a = [b[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")]
 
     def step():
