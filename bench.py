@@ -127,6 +127,8 @@ def main():
                     help="full = headline (--train-llm --train-mlp); lora = --use-lora r=64; mlp = projectors only (side figures)")
     ap.add_argument("--zero-stage", type=int, default=2, choices=(0, 2),
                     help="2 = ZeRO-2 (reduce-scatter / sharded AdamW / all-gather); 0 = the reference's ds_z0 fallback (all-reduce)")
+    ap.add_argument("--event-stride", type=int, default=7,
+                    help="HIP events around every n-th GEMM launch of the timed region (1 = all: 2-3 %% slower steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", nargs=3, type=int, metavar=("LLM_LAYERS", "ENC_LAYERS", "THREADS"))
     args = ap.parse_args()
@@ -192,6 +194,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     ops.GEMM_PROFILE = []
+    ops.GEMM_PROFILE_STRIDE = args.event_stride
     step_ev = []
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -215,24 +218,31 @@ def main():
         tokens = world * B * T * args.steps
         # dominant kernel = gemm256_kernel (the 256x256 ping-pong MFMA GEMM); its three operand-layout instantiations
         # are separate rows in rocprofv3 --stats.  Launches that went to the 128x128 kernel (small grids) are listed apart.
-        timed = [(a.elapsed_time(b), f, kcfg, lay) for a, b, f, kcfg, lay in prof]
-        gemm_ms = sum(t for t, *_ in timed)
-        gemm_fl = sum(f for _, f, *_ in timed)
-        n_launch = len(timed)
-        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        # every GEMM launch of the timed region is listed; HIP events bracket every `stride`-th one (7: coprime with the 4- and
+        # 9-GEMM patterns of the decoder / encoder layers, so every shape is sampled).  Per class, the launches that were not
+        # timed are priced at the class's sampled rate.
+        n_launch = len(prof)
+        timed = [(a.elapsed_time(b), f, kcfg, lay) for a, b, f, kcfg, lay in prof if a is not None]
+        achieved = sum(f for _, f, *_ in timed) / (sum(t for t, *_ in timed) * 1e-3) / 1e12
         by_kernel = {}
         names = {(False, False): "NT gemm256_kernel<false,false>", (False, True): "NN gemm256_kernel<false,true>",
                  (True, True): "TN gemm256_kernel<true,true>"}
-        for t, f, kcfg, lay in timed:
+        def klass(kcfg, lay):
             key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64>"
             if kcfg >= 100000:                    # grouped launch: cfg = 512 + 1000 + 100000 * problems
                 key += f" grouped x{kcfg // 100000} (a layer's weight gradients in one launch)"
             elif kcfg // 1000 > 1:
                 key += " + splitk_reduce"
-            d = by_kernel.setdefault(key, [0, 0.0, 0.0])
-            d[0] += 1; d[1] += t; d[2] += f
-        by_kernel = {k: {"launches": v[0], "avg_launch_us": round(v[1] * 1e3 / v[0], 2),
-                         "achieved_tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in by_kernel.items()}
+            return key
+        for a, b, f, kcfg, lay in prof:
+            d = by_kernel.setdefault(klass(kcfg, lay), [0, 0, 0.0, 0.0, 0.0])     # launches, timed, ms timed, flops timed, flops all
+            d[0] += 1; d[4] += f
+            if a is not None:
+                d[1] += 1; d[2] += a.elapsed_time(b); d[3] += f
+        gemm_ms = sum(v[2] * v[4] / v[3] for v in by_kernel.values() if v[3] > 0)  # all launches, at each class's sampled rate
+        by_kernel = {k: {"launches": v[0], "timed": v[1], "avg_launch_us": round(v[2] * 1e3 / max(v[1], 1), 2),
+                         "achieved_tflops": round(v[3] / (v[2] * 1e-3) / 1e12, 1) if v[2] > 0 else None}
+                     for k, v in by_kernel.items()}
         step_ms = [a.elapsed_time(b) for a, b in step_ev]
         # HBM-side traffic of the dominant kernel cannot be counted live (PMC needs rocprofv3): quote the committed PMC
         # passes of this same workload (profiles/r01b_pmc_hbm_traffic.csv, tools/pmc_hbm_traffic.py; corrected as MI355X_MICROARCH.md §HBM prescribes)

@@ -12,8 +12,31 @@ BF16 = torch.bfloat16
 GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32, GEMM_TRANS_OUT = 1, 2, 4, 8, 16, 32
 
 
-# optional per-launch timing of the dominant kernel (bench.py roofline): list of (start_event, end_event, flops)
+# optional timing of the dominant kernel (bench.py roofline): list of (start_event | None, end_event | None, flops, cfg, layout).
+# Every launch is listed; HIP events bracket every GEMM_PROFILE_STRIDE-th one only (an event pair costs a few microseconds of
+# dispatch per launch: around all ~390 GEMM launches of a step that is 2-3 % of the step being measured).
 GEMM_PROFILE = None
+GEMM_PROFILE_STRIDE = 1
+_prof_n = 0
+
+
+def _prof_begin():
+    """-> start event when this launch is a sampled one, else None (and counts the launch)."""
+    global _prof_n
+    _prof_n += 1
+    if _prof_n % GEMM_PROFILE_STRIDE:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _prof_end(prof, e0, flops, layout):
+    e1 = None
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+    prof.append((e0, e1, flops, lib().query("molly_gemm_last_config"), layout))
 
 
 def _stream() -> int:
@@ -73,15 +96,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     elif out.dtype != BF16:
         raise TypeError("gemm_nt: out must be bf16 or fp32")
     prof = GEMM_PROFILE
-    if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _prof_begin() if prof is not None else None
     lib().call("molly_gemm_bf16", _stream(), a, b, out, bias, res, M, N, K, a.stride(0), b.stride(0), out.stride(0),
                res.stride(0) if res is not None else 0, flags, int(a_kmajor), int(b_kmajor))
     if prof is not None:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, lib().query("molly_gemm_last_config"), (a_kmajor, b_kmajor)))
+        _prof_end(prof, e0, 2.0 * M * N * K, (a_kmajor, b_kmajor))
     return out
 
 
@@ -105,15 +124,10 @@ def gemm_grouped(problems, accumulate: bool = False):
     if f32:
         flags |= GEMM_OUT_F32
     prof = GEMM_PROFILE
-    if prof is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _prof_begin() if prof is not None else None
     lib().call("molly_gemm_grouped_bf16", _stream(), desc.data_ptr(), len(problems), K, flags)
     if prof is not None:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        prof.append((e0, e1, sum(2.0 * a.shape[0] * b.shape[1] * K for a, b, _, _ in problems),
-                     lib().query("molly_gemm_last_config"), (False, True)))
+        _prof_end(prof, e0, sum(2.0 * a.shape[0] * b.shape[1] * K for a, b, _, _ in problems), (False, True))
 
 
 def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
