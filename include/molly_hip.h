@@ -132,6 +132,9 @@ int molly_ce_fwd_bwd(void* stream, void* logits, const int64_t* labels, float* r
  * d(logits) * (*scale) when write_grad (padding columns V..ld-1 get 0). */
 int molly_cls_loss_fwd_bwd(void* stream, void* logits, const int64_t* labels, const float* targets, float* row_loss,
                            const float* scale, int rows, int V, int ld, int mode, int ignore_index, int write_grad);
+/* greedy token selection of generate(do_sample=False) — HF:generation/utils.py `next_tokens = torch.argmax(scores, -1)`
+ * (reference src/model/omics_one.py:220-232 passes do_sample through): first maximal index per row of fp32 logits [rows][ld]. */
+int molly_argmax_f32(void* stream, const float* x, int64_t* out, int rows, int V, int ld);
 int molly_sum_f32(void* stream, const float* x, long n, const float* scale_or_null, float* out, int accumulate);
 
 /* LayerNorm forward (affine, eps 1e-5) — ESM pre-LN blocks and emb_layer_norm_after: HF:models/esm/

@@ -1203,6 +1203,43 @@ extern "C" int molly_cls_loss_fwd_bwd(void* stream, void* logits, const int64_t*
     return 0;
 }
 
+// greedy token selection of HF generate (do_sample=False: torch.argmax over the vocabulary; the FIRST maximal index wins
+// ties, a NaN counts as the maximum): one block per row of fp32 logits.
+__global__ __launch_bounds__(256) void argmax_f32_kernel(const float* __restrict__ x, long* __restrict__ out, int V, int ld) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const float* r = x + (size_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    bool nan = false;
+    for (int c = threadIdx.x; c < V; c += 256) {
+        const float v = r[c];
+        if (v != v) { if (!nan) { nan = true; bi = c; } }
+        else if (!nan && (v > best || (bi == 0x7fffffff))) { best = v; bi = c; }
+    }
+    sv[threadIdx.x] = nan ? INFINITY : best;
+    si[threadIdx.x] = nan ? bi - 0x40000000 : bi;          // NaN lanes sort in front of every number, by index among themselves
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float a = sv[threadIdx.x], b = sv[threadIdx.x + o];
+            const int ia = si[threadIdx.x], ib = si[threadIdx.x + o];
+            const bool na = ia < 0, nb = ib < 0;
+            const bool take_b = (nb && !na) || (nb == na && (b > a || (b == a && ib < ia)));
+            if (take_b) { sv[threadIdx.x] = b; si[threadIdx.x] = ib; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = si[0] < 0 ? si[0] + 0x40000000 : si[0];
+}
+
+extern "C" int molly_argmax_f32(void* stream, const float* x, int64_t* out, int rows, int V, int ld) {
+    MOLLY_CHECK(rows > 0 && V > 0 && V < 0x40000000 && ld >= V, "argmax: rows=%d V=%d ld=%d", rows, V, ld);
+    hipLaunchKernelGGL(argmax_f32_kernel, dim3(rows), dim3(256), 0, ST, x, (long*)out, V, ld);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int molly_sum_f32(void* stream, const float* x, long n, const float* scale, float* out, int accumulate) {
     hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, ST, x, n, scale, out, accumulate);
     MOLLY_LAUNCH_CHECK();

@@ -213,7 +213,7 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
         if do_sample:
             nxt = torch.multinomial(lg.softmax(-1), 1, generator=generator).squeeze(1)
         else:
-            nxt = lg.argmax(-1)
+            nxt = ops.argmax(lg) if lg.dtype == torch.float32 else lg.argmax(-1)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
         out = torch.cat([out, nxt[:, None]], 1)
         if eos is not None:

@@ -283,6 +283,16 @@ def cls_loss_fwd_bwd(logits, V, row_loss, scale, labels=None, targets=None, igno
                0 if labels is not None else 1, ignore_index, int(write_grad))
 
 
+def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row-wise argmax of fp32 logits [rows, V] (first maximal index, like torch.argmax) -> int64 [rows]."""
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    rows, V = logits.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    lib().call("molly_argmax_f32", _stream(), logits, out, rows, V, logits.stride(0))
+    return out
+
+
 def count_valid(labels, scale_out, count_out, ignore_index=-100):
     lib().call("molly_count_valid", _stream(), labels, labels.numel(), ignore_index, scale_out, count_out)
 

@@ -598,3 +598,22 @@ def test_gemm_grouped_equals_separate_launches(accumulate, persist):
     torch.cuda.synchronize()
     for (a, b, out, to), ref in zip(probs, refs):
         assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+
+
+def test_argmax_matches_torch_first_maximum():
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for rows, V in ((32, 151936), (3, 1000), (5, 97)):
+        x = torch.randn(rows, V, generator=g).to(DEV)
+        x[0, 17] = x[0].max() + 1.0
+        x[0, 900 % V] = x[0, 17]                      # tie: the FIRST maximal index wins
+        x[1] = 0.25                                   # a constant row -> index 0
+        if rows > 2:
+            x[2, V - 1] = float("inf")
+        got = ops.argmax(x)
+        assert torch.equal(got, x.argmax(-1)), (got.tolist()[:5], x.argmax(-1).tolist()[:5])
+    y = torch.randn(4, 2048, generator=g).to(DEV)
+    y[3, 77] = float("nan")
+    assert ops.argmax(y)[3].item() == 77              # NaN counts as the maximum (torch semantics)
+    wide = torch.randn(6, 4096, generator=g).to(DEV)
+    view = wide[:, :1000]                              # row pitch != V
+    assert torch.equal(ops.argmax(view), view.argmax(-1))
