@@ -7,7 +7,9 @@ shard, all-gather).  Nothing is skipped or cached inside the timed region.  Work
 (SURVEY.md §8d C2): seq_len 2048 text + one 512-residue protein span per sample, B samples per GPU, GA=1, LLM +
 projectors trainable, encoders frozen.  Weak scaling: per-GPU work is fixed as N grows.
 
-    python bench.py [--gpus N --steps K --warmup W]        # N>1: launched by torch.distributed.run, one rank per GPU
+    python bench.py [--gpus N --steps K --warmup W]        # N>1: one rank per GPU — under torch.distributed.run when the
+                                                           # caller launched it so (WORLD_SIZE set), else bench.py starts
+                                                           # the N ranks itself (fresh children, before any GPU call)
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (the bf16 MFMA
 GEMM) measured with HIP events inside the timed region, and `cpu_baseline` = the CPU oracle timed on the host cores.
 """
@@ -40,16 +42,45 @@ def enc_flops_per_token(cfg, K):
     return 2 * Le * (4 * he * he + 2 * he * ffe) + 4 * Le * he * K
 
 
-def _cpu_step_worker(llm_layers: int, enc_layers: int, threads: int, T: int = 256, K: int = 64):
-    """One fwd + bwd + clipped AdamW step of the CPU oracle (oracle/molly_ref.py) at Molly-1.7B widths; prints JSON."""
+def _host_cpu():
+    """(physical cores, CPU model string) from lscpu; falls back to os.cpu_count()."""
+    import subprocess
+    cores, model = None, "unknown"
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        model = kv.get("Model name", model)
+        cores = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+    except Exception:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores or avail, avail)                      # never more threads than this process may run on
+    return max(1, cores), model
+
+
+# the two CPU-baseline configurations of SURVEY.md §8d / BASELINE.md §3
+CPU_CONFIGS = {
+    # C1 exactly: BASELINE configs[0] — Qwen3-0.6B + ESM2-t6-8M, fp32, B=2, T=256, one 64-residue protein span
+    "c1": dict(llm="0.6b", enc="esm2_8m", B=2, T=256, K=64),
+    # C2 down-scaled: the headline model (Qwen3-1.7B + ESM2-650M, full depth, full vocabulary), B=1, T=512, K=128
+    "c2s": dict(llm="1.7b", enc="esm2_650m", B=1, T=512, K=128),
+}
+
+
+def _cpu_step_worker(which: str, threads: int, budget_s: float, warmups: int = 2, timed: int = 5):
+    """fwd + bwd + clipped AdamW steps of the CPU oracle (oracle/molly_ref.py, fp32) on one of CPU_CONFIGS; prints JSON.
+    Protocol: `warmups` un-timed steps, then up to `timed` timed ones, median reported; the loop stops
+    early when `budget_s` of wall time is used up (the steps done so far are reported, at least one timed step)."""
     from oracle import molly_ref as R
     from molly_amd import config as C
     from molly_amd.params import enc_param_specs, llm_norm_specs, llm_param_specs
     from molly_amd.synth import synth_batch
+    t_start = time.time()
     torch.manual_seed(0)
     torch.set_num_threads(threads)
-    llm_c, prot_c = C.qwen3("1.7b"), C.esm2_650m()
-    llm_c.num_hidden_layers, prot_c.num_hidden_layers = llm_layers, enc_layers
+    cc = CPU_CONFIGS[which]
+    llm_c = C.qwen3(cc["llm"])
+    prot_c = C.esm2_650m() if cc["enc"] == "esm2_650m" else C.esm2_t6_8m()
     llm = R.LlmCfg(**{k: getattr(llm_c, k) for k in R.LlmCfg.__dataclass_fields__})
     prot = R.EncCfg(**{k: getattr(prot_c, k) for k in R.EncCfg.__dataclass_fields__})
     sd = {}
@@ -64,11 +95,15 @@ def _cpu_step_worker(llm_layers: int, enc_layers: int, threads: int, T: int = 25
         sd[n] = t
     sd["protein_projector.weight"] = torch.empty(llm_c.hidden_size, prot_c.hidden_size).normal_(0, 0.02).requires_grad_(True)
     sd["protein_projector.bias"] = torch.zeros(llm_c.hidden_size, requires_grad=True)
-    batch = synth_batch(1, T, [("protein", K)], seed=42)
+    B, T, K = cc["B"], cc["T"], cc["K"]
+    batch = synth_batch(B, T, [("protein", K)], seed=42)         # same generator and seed as the GPU run's rank 0
     params = {n: p for n, p in sd.items() if p.requires_grad}
     state = {n: (torch.zeros_like(p), torch.zeros_like(p)) for n, p in params.items()}
-    secs = []
-    for step in (1, 2):                      # step 1 faults the memory in; step 2 is the timed one
+    secs, step = [], 0
+    while len(secs) < warmups + timed:
+        if len(secs) > warmups and time.time() - t_start > budget_s:
+            break
+        step += 1
         t0 = time.time()
         loss, _ = R.omics_forward(sd, llm, None, prot, batch, {"dna_rna": K, "protein": K})
         loss.backward()
@@ -79,42 +114,87 @@ def _cpu_step_worker(llm_layers: int, enc_layers: int, threads: int, T: int = 25
                 R.adamw_step(p, p.grad * coef, state[n][0], state[n][1], step, 3e-5, 0.0 if R.is_no_decay(n) else 1e-2)
                 p.grad = None
         secs.append(time.time() - t0)
-    flops = T * algorithmic_flops_per_token(llm_c, T) + K * (enc_flops_per_token(prot_c, K) + 6 * prot_c.hidden_size * llm_c.hidden_size)
-    print(json.dumps({"seconds": secs[-1], "first_step_seconds": secs[0], "tokens": T, "llm_layers": llm_layers,
-                      "enc_layers": enc_layers, "threads": threads, "K": K, "flops": flops}), flush=True)
+        if len(secs) <= warmups and time.time() - t_start > budget_s and len(secs) >= 1:
+            warmups = len(secs)                                  # out of time inside the warm-ups: one timed step still follows
+    timed_s = secs[warmups:] or secs[-1:]
+    print(json.dumps({"config": which, "B": B, "T": T, "K": K, "threads": threads, "warmups": min(warmups, len(secs) - 1) if secs[warmups:] else len(secs) - 1,
+                      "step_seconds": [round(x, 3) for x in timed_s], "median_seconds": statistics.median(timed_s),
+                      "tokens_per_step": B * T, "loss": float(loss)}), flush=True)
 
 
-def cpu_baseline():
-    """The CPU oracle (`kind: port`, oracle/molly_ref.py) timed on the host cores on a BOUNDED sample of the same workload,
-    in a child process with a hard timeout so the default bench always finishes in minutes.  A whole fp32 Molly-1.7B step
-    (28 Qwen3 + 33 ESM-2 layers, 30 GB of state) needs minutes on a big host just to fault its memory in, so the sample
-    is a reduced-DEPTH model at the full widths and vocabulary (4 of 28 Qwen3 layers, 4 of 33 ESM-2 layers; embedding,
-    lm_head+CE and optimizer complete), B=1, T=256, one 64-residue protein span, second of two fwd+bwd+clipped-AdamW steps.
-    `value` is scaled to the metric's unit through the algorithmic FLOP count: the CPU's sustained FLOP/s on the sample
-    divided by the FLOPs per token of the full BASELINE workload (SURVEY.md §8d formula, the same one the GPU line uses)."""
+def _run_cpu_config(which: str, threads: int, budget_s: float):
     import subprocess
-    from molly_amd import config as C
-    threads = max(1, min(os.cpu_count() or 1, 32))            # >32 intra-op threads only add barrier cost at these sizes
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "4", "4", str(threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", which, str(threads), str(budget_s)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 3 + 120,
+                           env={**os.environ, "HIP_VISIBLE_DEVICES": "", "WORLD_SIZE": "1"})
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "tokens/s", "cores": threads, "kind": "port", "sample": "CPU oracle exceeded its 240 s box"}
+        return None, f"CPU oracle ({which}) exceeded its box"
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not line:
-        return {"value": None, "unit": "tokens/s", "cores": threads, "kind": "port", "sample": f"CPU oracle failed: {r.stderr[-200:]}"}
-    d = json.loads(line[-1])
-    cpu_flops = d["flops"] / d["seconds"]
-    T, K = 2048, 512
-    full_per_token = (T * algorithmic_flops_per_token(C.qwen3("1.7b"), T) +
-                      K * (enc_flops_per_token(C.esm2_650m(), K) + 6 * 1280 * 2048)) / T
-    return {"value": round(cpu_flops / full_per_token, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": (f"Molly-1.7B widths fp32, reduced depth (4/28 Qwen3 + 4/33 ESM-2 layers, full vocab head), B=1 T={d['tokens']} "
-                       f"protein K={d['K']}: 2nd fwd+bwd+clipped-AdamW step {d['seconds']:.1f} s = {cpu_flops / 1e9:.0f} GFLOP/s "
-                       f"algorithmic; value = that rate / {full_per_token / 1e9:.2f} GFLOP per token of the full T=2048 workload")}
+        return None, f"CPU oracle ({which}) failed: {r.stderr[-200:]}"
+    return json.loads(line[-1]), None
 
 
-def main():
+def cpu_baseline(budget_s: float = 45.0):
+    """The CPU oracle (`kind: port`, oracle/molly_ref.py, parity-pinned to the reference through tests/golden) timed on the
+    host's physical cores, protocol of SURVEY.md §8d / BASELINE.md §3: the down-scaled C2 — the headline MODEL at full depth
+    and vocabulary (Qwen3-1.7B + ESM2-650M, fp32), B=1, T=512, one 128-residue protein span — and C1 exactly (Qwen3-0.6B +
+    ESM2-t6-8M, fp32, B=2, T=256, K=64); fwd + bwd + clipped AdamW; 2 warm-up steps then the median of up to 5 timed steps,
+    each configuration inside a wall-time box so that the default bench finishes in minutes.  `value` = measured tokens/s
+    of the down-scaled C2 (tokens of the step / median step time — no FLOP extrapolation); C1 rides along in `c1`.
+    Each runs in a child process that never touches the GPU."""
+    cores, model = _host_cpu()
+    out = {"value": None, "unit": "tokens/s", "cores": cores, "cpu_model": model, "kind": "port"}
+    d2, err2 = _run_cpu_config("c2s", cores, budget_s)
+    d1, err1 = _run_cpu_config("c1", cores, budget_s / 2)
+    if d2 is not None:
+        out["value"] = round(d2["tokens_per_step"] / d2["median_seconds"], 2)
+        out["sample"] = (f"C2 down-scaled (SURVEY 8d): Molly-1.7B full depth fp32 (Qwen3-1.7B + ESM2-650M), B={d2['B']} T={d2['T']} "
+                         f"protein K={d2['K']}, fwd+bwd+clipped AdamW, {d2['warmups']} warm-up + {len(d2['step_seconds'])} timed "
+                         f"steps {d2['step_seconds']} s, median {d2['median_seconds']:.2f} s, {cores} threads = physical cores of {model}")
+    else:
+        out["sample"] = err2
+    if d1 is not None:
+        out["c1"] = {"value": round(d1["tokens_per_step"] / d1["median_seconds"], 2), "unit": "tokens/s",
+                     "sample": (f"C1 exactly: Qwen3-0.6B + ESM2-t6-8M fp32, B={d1['B']} T={d1['T']} K={d1['K']}, {d1['warmups']} warm-up + "
+                                f"{len(d1['step_seconds'])} timed steps {d1['step_seconds']} s, median {d1['median_seconds']:.2f} s")}
+    else:
+        out["c1"] = {"value": None, "sample": err1}
+    return out
+
+
+def _self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU, reference:
+    scripts/train/examples/run_train_1B_z2_b1.sh:60-64 `deepspeed --include localhost:0..7`).  Runs BEFORE anything touches
+    the GPU in this process; the ranks are fresh children (never an exec of a GPU-initialised process); returns their rc."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           *[a for a in argv if a != "--dry-run-launch"]]
+    if args.dry_run_launch:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    return subprocess.run(cmd, env=env).returncode
+
+
+def attention_flops_per_step(cfg, enc_cfg, B, T, K, train_bio=False):
+    """Executed attention matmul FLOPs counted the way SURVEY §8d counts them (causal half for the decoder, fwd + 2x bwd,
+    no recompute credit; full K x K forward only for the frozen encoder)."""
+    llm = 3 * 4 * cfg.num_hidden_layers * cfg.num_attention_heads * cfg.head_dim * (T / 2) * T * B
+    enc = (3 if train_bio else 1) * 4 * enc_cfg.num_hidden_layers * enc_cfg.hidden_size * K * K * B
+    return llm + enc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -127,39 +207,63 @@ def main():
                     help="full = headline (--train-llm --train-mlp); lora = --use-lora r=64; mlp = projectors only (side figures)")
     ap.add_argument("--zero-stage", type=int, default=2, choices=(0, 2),
                     help="2 = ZeRO-2 (reduce-scatter / sharded AdamW / all-gather); 0 = the reference's ds_z0 fallback (all-reduce)")
+    ap.add_argument("--bucket-mib", type=float, default=0.0,
+                    help="ZeRO bucket size in MiB of bf16 (one reduce-scatter / all-gather each; every xGMI link carries bucket/world "
+                         "of it); 0 = the default of 32 MiB per link (256 MiB at 8 GPUs).  SURVEY §5 sweep: 64 ... 1024")
+    ap.add_argument("--exposed-comm-steps", type=int, default=4,
+                    help="N>1: extra steps after the timed region with the exchange NOT overlapped, to report the exposed "
+                         "communication time (0 = skip)")
     ap.add_argument("--event-stride", type=int, default=7,
                     help="HIP events around every n-th GEMM launch of the timed region (1 = all: 2-3 %% slower steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-worker", nargs=3, type=int, metavar=("LLM_LAYERS", "ENC_LAYERS", "THREADS"))
-    args = ap.parse_args()
+    ap.add_argument("--cpu-budget", type=float, default=45.0, help="wall-time box (s) of the down-scaled-C2 CPU run; C1 gets half")
+    ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("CONFIG", "THREADS", "BUDGET_S"))
+    ap.add_argument("--dry-run-launch", action="store_true", help="print the rank launch command instead of running it")
+    args = ap.parse_args(argv)
     if args.cpu_baseline_worker:
-        _cpu_step_worker(*args.cpu_baseline_worker)
-        return
+        w = args.cpu_baseline_worker
+        _cpu_step_worker(w[0], int(w[1]), float(w[2]))
+        return 0
+
+    # ---- N > 1 without a launcher: start the ranks ourselves (before any GPU call in this process) -----------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch N ranks, or none and let bench.py do it)")
     # test hooks (a one-GPU box can still run the multi-process path end to end): MOLLY_BENCH_DEVICE pins every rank to
     # one device, MOLLY_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
     if "MOLLY_BENCH_DEVICE" in os.environ:
         local = int(os.environ["MOLLY_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    import datetime
     import torch.distributed as dist
+    backend = None
     if world > 1:
         backend = os.environ.get("MOLLY_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        # reference: src/train.py:606-610 (nccl, device_id, 30 min timeout)
+        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=30),
+                                **({"device_id": dev} if backend == "nccl" else {}))
+
+    def barrier():
+        if world > 1:
+            dist.barrier(**({"device_ids": [local]} if backend == "nccl" else {}))
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
-        dist.barrier()
+    barrier()
     import molly_amd
     from molly_amd import config as C, ops
     from molly_amd.synth import synth_batch
     from molly_amd.trainer import Zero2Optimizer
+    from molly_amd.trainer.zero2 import preflight_collectives
+
+    comm_check = preflight_collectives(dev) if world > 1 else None   # tiny in-place RS/AG/AR with known answers: fail fast
 
     cfg = C.molly(args.model, k_tokens=args.k_protein)
     m = molly_amd.OmicsOne(cfg)
@@ -174,8 +278,11 @@ def main():
         m.prepare(dev, random_init_seed=1234, train_llm=False, train_mlp=True,
                   lora=LoraConfig(r=64, lora_alpha=64, lora_dropout=0.05, seed=42) if args.train_mode == "lora" else None)
     rt = m._rt
+    opt_kw = {}
+    if args.bucket_mib > 0:
+        opt_kw["chunk_elems"] = max(8, int(args.bucket_mib * (1 << 20) / 2 / world) // 8 * 8)
     opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0,
-                         stage=args.zero_stage)
+                         stage=args.zero_stage, **opt_kw)
     m.attach_optimizer(opt)
 
     B, T, K = args.batch, args.seq, args.k_protein
@@ -187,32 +294,57 @@ def main():
         opt.step(lr=3e-5)
         return loss
 
+    def timed_steps(n, first):
+        """n steps bracketed by barrier + synchronize on both sides -> (wall seconds, [per-step ms], last loss)."""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        evs = []
+        t0 = time.perf_counter()
+        for i in range(n):
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            loss = step(first + i)
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, [a.elapsed_time(b) for a, b in evs], loss
+
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     ops.GEMM_PROFILE = []
     ops.GEMM_PROFILE_STRIDE = args.event_stride
-    step_ev = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        e0 = torch.cuda.Event(enable_timing=True); e0.record()
-        loss = step(args.warmup + i)
-        e1 = torch.cuda.Event(enable_timing=True); e1.record()
-        step_ev.append((e0, e1))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, step_ms, loss = timed_steps(args.steps, args.warmup)
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss_v = float(loss.item())
+
+    # ---- N > 1: how much of the exchange is exposed?  same steps with the collectives on the compute stream ---------
+    comm = None
+    if world > 1:
+        comm = {"backend": backend, "world_size": dist.get_world_size(), "preflight": comm_check,
+                "comm_bytes_per_step_per_gpu": opt.comm_bytes_per_step(), "bucket_mib": round(opt.bucket * 2 / (1 << 20), 1),
+                "per_link_mib_per_bucket": round(opt.chunk * 2 / (1 << 20), 1), "buckets": len(opt.buckets),
+                "overlap": bool(opt.overlap), "persistent_gemm": os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "0") == "1"}
+        if backend == "nccl":
+            try:
+                comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        if args.exposed_comm_steps > 0 and opt.overlap:
+            opt.set_overlap(False)
+            step(0)
+            dt2, ms2, _ = timed_steps(args.exposed_comm_steps, 1)
+            opt.set_overlap(True)
+            t2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            comm["step_ms_p50_no_overlap"] = round(statistics.median(ms2), 2)
+            comm["exposed_comm_ms_removed_by_overlap"] = round(statistics.median(ms2) - statistics.median(step_ms), 2)
 
     if rank == 0:
         tokens = world * B * T * args.steps
@@ -240,24 +372,31 @@ def main():
             if a is not None:
                 d[1] += 1; d[2] += a.elapsed_time(b); d[3] += f
         gemm_ms = sum(v[2] * v[4] / v[3] for v in by_kernel.values() if v[3] > 0)  # all launches, at each class's sampled rate
+        gemm_flops_step = sum(v[4] for v in by_kernel.values()) / args.steps       # EXECUTED GEMM flops per step (exact 2MNK)
         by_kernel = {k: {"launches": v[0], "timed": v[1], "avg_launch_us": round(v[2] * 1e3 / max(v[1], 1), 2),
                          "achieved_tflops": round(v[3] / (v[2] * 1e-3) / 1e12, 1) if v[2] > 0 else None}
                      for k, v in by_kernel.items()}
-        step_ms = [a.elapsed_time(b) for a, b in step_ev]
         # HBM-side traffic of the dominant kernel cannot be counted live (PMC needs rocprofv3): quote the committed PMC
-        # passes of this same workload (profiles/r01b_pmc_hbm_traffic.csv, tools/pmc_hbm_traffic.py; corrected as MI355X_MICROARCH.md §HBM prescribes)
+        # passes of this same workload (tools/pmc_hbm_traffic.py; corrected as MI355X_MICROARCH.md §HBM prescribes)
         traffic, traffic_src = None, None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01b_hbm_traffic.json")
-        if args.train_mode == "full" and (B, T, K, args.model) == (8, 2048, 512, "1.7b") and os.path.exists(tj):
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        tj = next((os.path.join(prof_dir, f) for f in ("r02_hbm_traffic.json", "r01b_hbm_traffic.json")
+                   if os.path.exists(os.path.join(prof_dir, f))), None)
+        if args.train_mode == "full" and (B, T, K, args.model) == (8, 2048, 512, "1.7b") and tj:
             with open(tj) as f:
                 tr = json.load(f)
             traffic, traffic_src = tr["gemm_hbm_bytes_per_launch"], tr["source"]
         flops_step = B * (T * algorithmic_flops_per_token(cfg.text_config, T) +
                           K * (enc_flops_per_token(cfg.protein_config, K) + 3 * 2 * cfg.protein_config.hidden_size *
                                cfg.text_config.hidden_size))
+        # executed = what the kernels really ran: every GEMM launch's 2MNK (lm_head on the scored rows only) + the attention
+        # matmuls (causal half, no recompute credit)
+        exec_step = gemm_flops_step + attention_flops_per_step(cfg.text_config, cfg.protein_config, B, T, K,
+                                                                args.train_mode == "bio")
+        sps = dt / args.steps
         out = {
             "metric": f"training tokens/sec Molly-{args.model.upper()} bf16", "value": round(tokens / dt, 1), "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Molly-{args.model.upper()} (Qwen3-{args.model.upper()} + NT-500M + ESM2-650M) train step, "
                                    f"seq_len {T} text + {K}-residue protein span per sample, {B} samples/GPU, GA=1, "
@@ -267,10 +406,13 @@ def main():
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}",
                        "scored_token_fraction": 0.25,
                        "note": "prompt = 75% of each sample with labels -100 (SURVEY 8d); lm_head+CE run on the scored rows only "
-                               "(identical loss/gradients); model_tflops_per_gpu uses the full algorithmic FLOP count"},
+                               "(identical loss/gradients).  executed_* count the FLOPs the kernels ran; model_* credit the full "
+                               "algorithmic count of SURVEY 8d (lm_head on every row)"},
             "step_ms_p50": round(statistics.median(step_ms), 2),
-            "model_tflops_per_gpu": round(flops_step / (dt / args.steps) / 1e12, 1),
-            "mfma_roofline_frac_step": round(flops_step / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "executed_tflops_per_gpu": round(exec_step / sps / 1e12, 1),
+            "mfma_roofline_frac_step_executed": round(exec_step / sps / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "model_tflops_per_gpu": round(flops_step / sps / 1e12, 1),
+            "mfma_roofline_frac_step": round(flops_step / sps / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "loss": round(loss_v, 4),
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM (gemm256_kernel / gemm_kernel, all launches of the timed region)",
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -279,13 +421,16 @@ def main():
                          "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                          "gemm_share_of_step": round(gemm_ms / sum(step_ms), 3), "by_kernel": by_kernel},
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if comm is not None:
+            out["comm"] = comm
+        if not args.no_cpu_baseline and world == 1:                  # rank 0 at N=1 only (contract)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

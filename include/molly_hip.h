@@ -163,10 +163,14 @@ int molly_esm_embed(void* stream, const int64_t* ids, const void* word_emb, cons
  * src/trainer/domain_loss.py:676-708; DeepSpeed gradient_clipping, src/configs/ds_z2_config.json:5). */
 int molly_sqnorm_blocks(void);
 int molly_sqnorm_bf16(void* stream, const void* g, long n, float* workspace, float* out, int accumulate);
-int molly_clip_coef(void* stream, const float* norm_sq, float max_norm, float pre_scale, float* norm_out, float* coef_out);
+/* Overflow guard (DeepSpeed's ZeRO step skips the update when a gradient is inf/NaN): a non-finite norm makes the
+ * coefficient NaN and adds 1 to *skipped_count; molly_adamw_step given a NaN *grad_scale leaves master / moments /
+ * parameters untouched, and takes its bias corrections at (step - *skipped_count): skipped steps do not age Adam. */
+int molly_clip_coef(void* stream, const float* norm_sq, float max_norm, float pre_scale, float* norm_out, float* coef_out,
+                    float* skipped_count_or_null);
 int molly_adamw_step(void* stream, float* master, float* exp_avg, float* exp_avg_sq, const void* grad, void* param_out,
                      long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                     const float* grad_scale_or_null);
+                     const float* grad_scale_or_null, const float* skipped_count_or_null);
 /* out[j] (+)= sum_r x[r, j] — bias gradient of the projector nn.Linear (reference src/model/omics_one.py:23-29).
  * workspace: molly_colsum_parts(rows) * H floats. */
 int molly_colsum_parts(int rows);

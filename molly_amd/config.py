@@ -146,6 +146,13 @@ def esm2_650m() -> EncConfig:
                      token_dropout=True, pad_token_id=1, mask_token_id=32)
 
 
+def esm2_t6_8m() -> EncConfig:
+    """ESM2-t6-8M: the protein encoder of BASELINE configs[0] (the reference's CPU-runnable mini run); head_dim 16."""
+    return EncConfig(vocab_size=33, hidden_size=320, intermediate_size=1280, num_hidden_layers=6,
+                     num_attention_heads=20, max_position_embeddings=1026, position_embedding_type="rotary",
+                     token_dropout=True, pad_token_id=1, mask_token_id=32)
+
+
 def nt_500m_human_ref() -> EncConfig:
     return EncConfig(vocab_size=4105, hidden_size=1280, intermediate_size=5120, num_hidden_layers=24,
                      num_attention_heads=20, max_position_embeddings=1002, position_embedding_type="absolute",

@@ -14,4 +14,4 @@ void molly_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* molly_last_error(void) { return g_err; }
-extern "C" int molly_abi_version(void) { return 1; }
+extern "C" int molly_abi_version(void) { return 2; }

@@ -964,9 +964,18 @@ __global__ __launch_bounds__(256) void sqnorm_part_kernel(const bf16_t* __restri
 
 // norm_sq (device scalar, possibly all-reduced across ranks) -> total norm, clip coefficient
 // coef = min(1, max_norm / (norm + 1e-6)) * pre_scale       (torch.nn.utils.clip_grad_norm_)
-__global__ void clip_coef_kernel(const float* norm_sq, float max_norm, float pre_scale, float* norm_out, float* coef_out) {
+// A non-finite norm (an inf/NaN gradient somewhere) makes the coefficient NaN = "skip this step": adamw_kernel leaves the
+// master, the moments and the parameters untouched for it, and *skipped (optional) counts such steps — what DeepSpeed's
+// ZeRO step does on overflow (the reference survives a bad batch; DeepSpeed 0.16.9 stage_1_and_2.py step(), un-vendored).
+__global__ void clip_coef_kernel(const float* norm_sq, float max_norm, float pre_scale, float* norm_out, float* coef_out,
+                                 float* skipped) {
     const float n = sqrtf(*norm_sq) * pre_scale;
     *norm_out = n;
+    if (!isfinite(n)) {
+        *coef_out = __builtin_nanf("");
+        if (skipped) *skipped += 1.f;
+        return;
+    }
     float c = max_norm > 0.f ? fminf(1.f, max_norm / (n + 1e-6f)) : 1.f;
     *coef_out = c * pre_scale;
 }
@@ -974,9 +983,14 @@ __global__ void clip_coef_kernel(const float* norm_sq, float max_norm, float pre
 // torch.optim.AdamW single-tensor math on an fp32 master shard; grad bf16 scaled by *gscale; emits bf16 param
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const bf16_t* __restrict__ grad, bf16_t* __restrict__ param_out, long n,
-                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt, const float* __restrict__ gscale) {
+                                                    float lr, float b1, float b2, float eps, float wd, int step,
+                                                    const float* __restrict__ gscale, const float* __restrict__ skipped) {
     const float gs = gscale ? *gscale : 1.f;
+    if (gs != gs) return;                                   // skipped step (clip_coef_kernel): nothing changes
+    // bias corrections of the steps actually TAKEN (skipped ones do not advance Adam's step count)
+    const float t = (float)step - (skipped ? *skipped : 0.f);
+    const float bc1 = 1.f - powf(b1, t);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
     const long nch = n >> 2;
     for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
         f32x4 p = *reinterpret_cast<f32x4*>(master + c * 4);
@@ -1321,22 +1335,21 @@ extern "C" int molly_sqnorm_bf16(void* stream, const void* g, long n, float* wor
 }
 
 extern "C" int molly_clip_coef(void* stream, const float* norm_sq, float max_norm, float pre_scale, float* norm_out,
-                               float* coef_out) {
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST, norm_sq, max_norm, pre_scale, norm_out, coef_out);
+                               float* coef_out, float* skipped_count_or_null) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST, norm_sq, max_norm, pre_scale, norm_out, coef_out,
+                       skipped_count_or_null);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int molly_adamw_step(void* stream, float* master, float* exp_avg, float* exp_avg_sq, const void* grad,
                                 void* param_out, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                int step, const float* grad_scale) {
+                                int step, const float* grad_scale, const float* skipped_count_or_null) {
     MOLLY_CHECK(n % 4 == 0 && step >= 1, "adamw: n=%ld must be a multiple of 4 and step >= 1", n);
     if (n == 0) return 0;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, master, exp_avg, exp_avg_sq,
-                       (const bf16_t*)grad, (bf16_t*)param_out, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
-                       grad_scale);
+                       (const bf16_t*)grad, (bf16_t*)param_out, n, lr, beta1, beta2, eps, weight_decay, step,
+                       grad_scale, skipped_count_or_null);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -60,10 +60,9 @@ class MultiModalInfer:
         if args.device != "cuda" or not torch.cuda.is_available():
             raise Exception("cuda not available, please check env.")          # reference :119-120 (GPU only there too)
         self.device = torch.device("cuda", 0)
-        from .data import ToyOmicTokenizer, ToyTextTokenizer
-        self.text_tokenizer = ToyTextTokenizer()
-        self.dna_rna_tokenizer = ToyOmicTokenizer("dna")
-        self.protein_tokenizer = ToyOmicTokenizer("protein")
+        from .loaders import setup_tokenizers
+        self.text_tokenizer, self.dna_rna_tokenizer, self.protein_tokenizer, self.real_tokenizers = setup_tokenizers(
+            args.text_model_path, args.dna_rna_model_path, args.protein_model_path)
         self._load_model()
 
     def _load_model(self):
@@ -80,18 +79,18 @@ class MultiModalInfer:
         m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
         m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
         if not a.no_load_pretrained:
-            for sub, path in ((m.model, a.text_model_path), (m.dna_rna_model, a.dna_rna_model_path),
-                              (m.protein_model, a.protein_model_path)):
-                f = os.path.join(path, "pytorch_model.bin")
-                if not os.path.exists(f):
-                    raise FileNotFoundError(f"{f}: no weights; pass --no-load-pretrained for random init")
-                sub.load_state_dict(torch.load(f, map_location="cpu"), strict=False, assign=True)
+            from .loaders import load_pretrained
+            if not self.real_tokenizers:
+                raise RuntimeError("pretrained weights need their tokenizers: the model directories hold no tokenizer files")
+            for sub, path, what in ((m.model, a.text_model_path, "LLM"), (m.dna_rna_model, a.dna_rna_model_path, "dna/rna encoder"),
+                                    (m.protein_model, a.protein_model_path, "protein encoder")):
+                load_pretrained(sub, path, what)
         full = os.path.join(a.trained_model_path, "pytorch_model.bin")
         if not a.use_lora and os.path.exists(full):
-            # reference :236-246: the whole OmicsOne state dict
+            # reference :236-246: the whole OmicsOne state dict, strict like the reference's plain load_state_dict
             sd = torch.load(full, map_location="cpu")
-            missing, unexpected = m.load_state_dict(sd, strict=False, assign=True)
-            print(f"Multimodal loaded ({len(sd)} tensors, {len(missing)} missing, {len(unexpected)} ignored).")
+            m.load_state_dict(sd)
+            print(f"Multimodal loaded ({len(sd)} tensors).")
         lora_cfg = None
         if a.use_lora and a.lora_live:
             from .lora import LoraConfig

@@ -15,6 +15,7 @@ from __future__ import annotations
 import os
 
 import math
+import re
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -51,7 +52,71 @@ def _lin(i, o, bias):
     return m
 
 
-class _Shell(nn.Module):
+class _MetaSafe(nn.Module):
+    """nn.Module whose still-unloaded (meta) tensors survive the calls the reference makes on its sub-models
+    (reference: src/inference_lora.py:243-250 — plain `load_state_dict(sd)` then `.to(torch.bfloat16).to(device).eval()`):
+      * `load_state_dict` ASSIGNS the checkpoint tensors to parameters that have no storage yet (nn.Module's default would
+        "copy" into meta tensors, a silent no-op), and copies as usual into parameters that do;
+      * `.to()/.cuda()/.float()/...` move what has storage and leave meta tensors alone (they never had a value to move);
+        `prepare()` later refuses any tensor that is still meta unless a random init was explicitly asked for."""
+
+    # checkpoint keys of the HF modules that Molly's forward never reads (SURVEY.md App. C: the encoders' MaskedLM /
+    # contact heads, rotary inv_freq / position_ids buffers).  The reference's `pytorch_model.bin` carries them and its
+    # loader is strict (src/inference_lora.py:243), so they are accepted on load, kept on the host, and written back by
+    # state_dict() — a checkpoint round-trips through this class with the reference's exact key set.
+    _DEAD_KEY = re.compile(r"(^|\.)(esm\.contact_head\.|lm_head\.(bias$|dense\.|layer_norm\.|decoder\.)|"
+                           r"(esm\.|self\.)?rotary_embeddings\.inv_freq$|esm\.embeddings\.position_ids$)")
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        for k, v in getattr(self, "_passthrough", {}).items():
+            sd[prefix + k] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        own_keys = set(super().state_dict().keys())
+        dead = {k: v for k, v in state_dict.items() if k not in own_keys and self._DEAD_KEY.search(k)}
+        if dead:
+            if not hasattr(self, "_passthrough"):
+                object.__setattr__(self, "_passthrough", {})
+            self._passthrough.update({k: v.detach().cpu() for k, v in dead.items()})
+            state_dict = {k: v for k, v in state_dict.items() if k not in dead}
+        if not assign and any(t.is_meta for t in list(self.parameters()) + list(self.buffers())):
+            # per tensor: assign where the destination is meta, copy elsewhere
+            own = {**dict(self.named_parameters(remove_duplicate=False)), **dict(self.named_buffers(remove_duplicate=False))}
+            to_copy = {k: v for k, v in state_dict.items() if k in own and not own[k].is_meta}
+            res = super().load_state_dict(state_dict, strict=strict, assign=True)
+            with torch.no_grad():
+                for k, v in to_copy.items():
+                    own[k].copy_(v)
+                    _set_tensor(self, k, own[k])
+        else:
+            res = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        for mod in self.modules():                       # assignment unties shared tensors: tie them again (HF tie_weights)
+            if hasattr(mod, "_retie_weights"):
+                mod._retie_weights()
+        return res
+
+    def _apply(self, fn, recurse=True):
+        return super()._apply(lambda t: t if t.is_meta else fn(t), recurse)
+
+
+def _set_tensor(root: nn.Module, name: str, value: torch.Tensor):
+    """Put `value` at dotted `name` under `root`, as a Parameter or a buffer — whichever the slot currently is
+    (the reference's `freeze_subtree`, src/utils/tools.py:277-311, turns frozen parameters into buffers)."""
+    mod = root
+    *path, leaf = name.split(".")
+    for k in path:
+        mod = mod[int(k)] if k.isdigit() else getattr(mod, k)
+    if leaf in mod._buffers:
+        mod._buffers[leaf] = value.detach()
+    else:
+        old = mod._parameters.get(leaf)
+        rg = value.requires_grad if isinstance(value, nn.Parameter) else (old.requires_grad if old is not None else True)
+        setattr(mod, leaf, value if isinstance(value, nn.Parameter) else nn.Parameter(value, requires_grad=rg))
+
+
+class _Shell(_MetaSafe):
     def materialize(self, std=0.02, seed=0):
         g = torch.Generator().manual_seed(seed)
         for n, p in list(self.named_parameters()):
@@ -104,6 +169,11 @@ class Qwen3ForCausalLM(_Shell):
         self.model.norm = _Norm(h)
         self.lm_head = _lin(h, c.vocab_size, False)
         if c.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+
+    def _retie_weights(self):
+        if self.config.tie_word_embeddings and "weight" in self.lm_head._parameters and \
+                "weight" in self.model.embed_tokens._parameters:
             self.lm_head.weight = self.model.embed_tokens.weight
 
     def materialize(self, std=0.02, seed=0):
@@ -227,7 +297,7 @@ def embed_backward_index(input_ids_flat: np.ndarray, overwritten: np.ndarray):
 
 
 # ---- the model ---------------------------------------------------------------------------------------------------
-class OmicsOne(nn.Module):
+class OmicsOne(_MetaSafe):
     def __init__(self, config: OmicsModalConfig):
         super().__init__()
         self.text_config = config.text_config
@@ -263,9 +333,18 @@ class OmicsOne(nn.Module):
                                             otherwise the encoders are frozen buffers, never communicated."""
         assert self.model is not None and self.dna_rna_model is not None and self.protein_model is not None, \
             "attach .model / .dna_rna_model / .protein_model first (reference: src/train.py:127,143,152)"
+        if random_init_seed is None:
+            # a tensor that never received a value (checkpoint not loaded, or a key it lacked) must not silently become
+            # random numbers: only an explicit random_init_seed (== the reference's --no-load-pretrained) initialises
+            hollow = [n for n, t in super().state_dict().items() if t.is_meta]
+            if hollow:
+                raise RuntimeError(f"{len(hollow)} tensors have no value (first: {hollow[:3]}): load a checkpoint "
+                                   "(load_state_dict) or pass random_init_seed for a --no-load-pretrained run")
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("molly_amd.OmicsOne runs on the GPU only; the CPU oracle lives in /oracle (tests only)")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         if train_llm and lora is not None:
             raise ValueError("lora and train_llm are exclusive: the reference freezes the base under --use-lora")
         if train_llm and not train_mlp:
@@ -326,22 +405,26 @@ class OmicsOne(nn.Module):
                         v.normal_(0.0, 0.02, generator=gen)
                 else:
                     v.copy_(src.to(dev))
-        # re-point module parameters at the flat views (so state_dict()/save keep working and see updates)
+        # re-point module parameters (and the buffers the reference's freeze_subtree made of frozen ones) at the flat views,
+        # so state_dict()/save keep working and see updates, and the staging copies are released
         trainable_bufs = [base] if full else ([Q] if Q is not None else [])
         with torch.no_grad():
             named = dict(self.named_parameters(remove_duplicate=False))
+            buffers = dict(self.named_buffers(remove_duplicate=False))
             for buf in bufs:
                 for n, v in buf.views.items():
-                    if n not in named:
-                        continue
-                    mod = self
-                    *path, leaf = n.split(".")
-                    for k in path:
-                        mod = mod[int(k)] if k.isdigit() else getattr(mod, k)
-                    setattr(mod, leaf, nn.Parameter(v, requires_grad=named[n].requires_grad and
-                                                    any(buf is tb for tb in trainable_bufs)))
+                    if n in named:
+                        _set_tensor(self, n, nn.Parameter(v, requires_grad=named[n].requires_grad and
+                                                          any(buf is tb for tb in trainable_bufs)))
+                    elif n in buffers:
+                        _set_tensor(self, n, v)
             if self.text_config.tie_word_embeddings:
-                self.model.lm_head.weight = self.model.model.embed_tokens.weight
+                emb = self.model.model.embed_tokens
+                if "weight" in emb._buffers:
+                    self.model.lm_head._buffers["weight"] = emb._buffers["weight"]
+                    self.model.lm_head._parameters.pop("weight", None)
+                else:
+                    self.model.lm_head.weight = emb.weight
         rt = type("Runtime", (), {})()
         rt.dev, rt.base, rt.enc = dev, base, enc
         rt.full, rt.train_llm, rt.train_mlp = full, bool(train_llm), bool(train_mlp or lora is not None)
@@ -370,9 +453,30 @@ class OmicsOne(nn.Module):
         self._rt = rt
         return self
 
+    def infer_trainable(self):
+        """(train_llm, train_mlp, train_bio) as the module tree says it — what the reference's `set_up_trainable_param`
+        (src/utils/tools.py:313-338) leaves behind: a frozen sub-tree has had its Parameters re-registered as buffers
+        (`freeze_subtree`, :277-311) or carries requires_grad=False; a trainable one still has Parameters that require grad."""
+        def live(*mods):
+            return any(p.requires_grad for m in mods if m is not None for p in m.parameters())
+        return (live(self.model), live(self.dna_rna_projector, self.protein_projector),
+                live(self.dna_rna_model, self.protein_model))
+
+    def prepare_from_module_state(self, device=None, **kw):
+        """`prepare()` with the trainable set read off the module tree — the call to make after the reference's own
+        `set_up_trainable_param(model, args)`, or after `inference_lora.py`'s `load_state_dict(...)` +
+        `.to(torch.bfloat16).to(device).eval()` (nothing requires grad in eval use: pass through `torch.no_grad`)."""
+        if device is None:
+            devs = {t.device for t in list(self.parameters()) + list(self.buffers()) if t.is_cuda}
+            device = devs.pop() if len(devs) == 1 else "cuda"
+        llm, mlp, bio = self.infer_trainable() if self.training else (False, False, False)    # .eval(): inference only
+        if llm and not mlp:
+            raise NotImplementedError("--train-llm without --train-mlp (frozen projectors inside the LLM's flat group)")
+        return self.prepare(device, train_llm=llm, train_mlp=mlp, train_bio=bio, **kw)
+
     def _runtime(self):
         if self._rt is None:
-            self.prepare()
+            self.prepare_from_module_state()
         return self._rt
 
     def _embed_and_inject(self, input_ids, omic_ids, omic_info_list, B, T, keep_for_backward, wait_embed=None,

@@ -318,13 +318,13 @@ def sqnorm(g, out, workspace, accumulate=False):
     lib().call("molly_sqnorm_bf16", _stream(), g, g.numel(), workspace, out, int(accumulate))
 
 
-def clip_coef(norm_sq, max_norm, pre_scale, norm_out, coef_out):
-    lib().call("molly_clip_coef", _stream(), norm_sq, float(max_norm), float(pre_scale), norm_out, coef_out)
+def clip_coef(norm_sq, max_norm, pre_scale, norm_out, coef_out, skipped=None):
+    lib().call("molly_clip_coef", _stream(), norm_sq, float(max_norm), float(pre_scale), norm_out, coef_out, skipped)
 
 
-def adamw_step(master, m, v, grad, param_out, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+def adamw_step(master, m, v, grad, param_out, lr, beta1, beta2, eps, wd, step, grad_scale=None, skipped=None):
     lib().call("molly_adamw_step", _stream(), master, m, v, grad, param_out, master.numel(), float(lr), float(beta1),
-               float(beta2), float(eps), float(wd), int(step), grad_scale)
+               float(beta2), float(eps), float(wd), int(step), grad_scale, skipped)
 
 
 def cast_f32_to_bf16(x, out):

@@ -2,8 +2,8 @@
 """Launcher with the reference's flag names (reference: src/train.py:237-594, the subset its example scripts pass:
 scripts/train/examples/run_train_1B_z2_b1.sh).  One process per GPU:
     python -m torch.distributed.run --nproc-per-node N -m molly_amd.train <flags>
-Model paths may be HF model directories (their config.json is read; weights from pytorch_model.bin / model.safetensors when
-present) or the built-in shape presets `qwen3-{0.6b,1.7b,4b,8b}`, `esm2-650m`, `nt-500m`, `tiny` with --no-load-pretrained.
+Model paths may be HF model directories (config.json; weights from model.safetensors / pytorch_model.bin, single file or
+sharded with an index; tokenizers through transformers.AutoTokenizer when the directory holds tokenizer files) or the built-in shape presets `qwen3-{0.6b,1.7b,4b,8b}`, `esm2-650m`, `nt-500m`, `tiny` with --no-load-pretrained.
 Cosmetic flags of the reference (swanlab, report_to, enable-list, attn_impl, use_liger, ...) are accepted and ignored.
 """
 import argparse
@@ -88,12 +88,15 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        import datetime
+        dist.init_process_group(os.environ.get("MOLLY_DIST_BACKEND", "nccl"), timeout=datetime.timedelta(minutes=30),
+                                **({"device_id": torch.device("cuda", local)}
+                                   if os.environ.get("MOLLY_DIST_BACKEND", "nccl") == "nccl" else {}))   # reference :606-610
     torch.manual_seed(a.seed)
 
     import molly_amd
     from .config import OmicsModalConfig
-    from .data import DatasetConfig, OmicsDataset, ToyOmicTokenizer, ToyTextTokenizer, qwen_omics_collate_fn
+    from .data import DatasetConfig, OmicsDataset, qwen_omics_collate_fn
     from .trainer import TrainArgs, Trainer, save_model
     cfg = OmicsModalConfig(text_config=_preset(a.text_model_path, "text"), dna_rna_config=_preset(a.dna_rna_model_path, "dna"),
                            protein_config=_preset(a.protein_model_path, "protein"))
@@ -102,20 +105,23 @@ def main(argv=None):
     m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)
     m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
     m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
+    from .loaders import load_pretrained, setup_tokenizers
+    text_tok, dna_tok, prot_tok, real_tok = setup_tokenizers(a.text_model_path, a.dna_rna_model_path, a.protein_model_path)
     if not a.no_load_pretrained:
-        for sub, path in ((m.model, a.text_model_path), (m.dna_rna_model, a.dna_rna_model_path),
-                          (m.protein_model, a.protein_model_path)):
-            f = os.path.join(path, "pytorch_model.bin")
-            if not os.path.exists(f):
-                raise FileNotFoundError(f"{f}: no weights; pass --no-load-pretrained for random init")
-            sub.load_state_dict(torch.load(f, map_location="cpu"), strict=False, assign=True)
+        if not real_tok:
+            raise RuntimeError("pretrained weights need their tokenizers: the model directories hold no tokenizer files "
+                               "(stand-in tokenizers are for --no-load-pretrained smoke runs only)")
+        for sub, path, what in ((m.model, a.text_model_path, "LLM"), (m.dna_rna_model, a.dna_rna_model_path, "dna/rna encoder"),
+                                (m.protein_model, a.protein_model_path, "protein encoder")):
+            load_pretrained(sub, path, what)
+    m.set_special_tokens(text_tok)
+    # random init ONLY for an explicit --no-load-pretrained run: a checkpoint that lacks a tensor must fail, not be made up
     m.prepare(torch.device("cuda", local), train_llm=a.train_llm and lora is None, train_mlp=a.train_mlp or lora is not None,
-              random_init_seed=1234, lora=lora, train_bio=a.train_bio)
-    # tokenizers: the real ones need vocab files (none offline) -> the deterministic stand-ins of molly_amd.data
+              random_init_seed=1234 if a.no_load_pretrained else None, lora=lora, train_bio=a.train_bio)
     dcfg = DatasetConfig(max_len=a.max_len, max_src_len=a.max_src_len, mode=a.mode, cal_metric_pos=None,
                          dna_rna_k_tokens=a.dna_rna_k_tokens, protein_k_tokens=a.protein_k_tokens)
-    ds = OmicsDataset(a.train_dataset_path, ToyTextTokenizer(), dcfg, dna_rna_tokenizer=ToyOmicTokenizer("dna"),
-                      protein_tokenizer=ToyOmicTokenizer("protein"), read_nums=a.read_nums or None, shuffle=True, seed=a.seed)
+    ds = OmicsDataset(a.train_dataset_path, text_tok, dcfg, dna_rna_tokenizer=dna_tok, protein_tokenizer=prot_tok,
+                      read_nums=a.read_nums or None, shuffle=True, seed=a.seed)
     targs = TrainArgs(output_dir=a.output_dir, per_device_train_batch_size=a.per_device_train_batch_size,
                       gradient_accumulation_steps=a.gradient_accumulation_steps, num_train_epochs=a.num_train_epochs,
                       max_steps=a.train_iters, learning_rate=a.learning_rate, weight_decay=a.weight_decay,
@@ -130,8 +136,8 @@ def main(argv=None):
             raise NotImplementedError("only eval_loss (lower is better) is tracked — the reference's default")
         ecfg = DatasetConfig(max_len=a.eval_max_len, max_src_len=a.eval_max_src_len, mode=a.mode, cal_metric_pos=None,
                              dna_rna_k_tokens=a.dna_rna_k_tokens, protein_k_tokens=a.protein_k_tokens)
-        eval_ds = OmicsDataset(a.eval_dataset_path, ToyTextTokenizer(), ecfg, dna_rna_tokenizer=ToyOmicTokenizer("dna"),
-                               protein_tokenizer=ToyOmicTokenizer("protein"), read_nums=a.eval_read_nums or None)
+        eval_ds = OmicsDataset(a.eval_dataset_path, text_tok, ecfg, dna_rna_tokenizer=dna_tok, protein_tokenizer=prot_tok,
+                               read_nums=a.eval_read_nums or None)
     tr = Trainer(m, ds, qwen_omics_collate_fn, targs, eval_dataset=eval_ds)
     tr.train()
     if (not dist.is_initialized()) or dist.get_rank() == 0:

@@ -80,16 +80,16 @@ def save_model(model, output_dir: str):
 
 class Trainer:
     def __init__(self, model, train_dataset, collate_fn: Callable, args: TrainArgs, log_fn: Callable = print,
-                 eval_dataset=None):
+                 eval_dataset=None, optimizer=None):
         self.model, self.ds, self.collate, self.args, self.log = model, train_dataset, collate_fn, args, log_fn
         self.eval_ds = eval_dataset
         self.best_metric, self.best_step, self._bad_evals = None, None, 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         rt = model._runtime()
-        self.opt = Zero2Optimizer(rt.P.flat, rt.G.flat, model.n_decay, lr=args.learning_rate,
-                                  betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon,
-                                  weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, stage=args.zero_stage)
+        self.opt = optimizer if optimizer is not None else Zero2Optimizer(
+            rt.P.flat, rt.G.flat, model.n_decay, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
+            eps=args.adam_epsilon, weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, stage=args.zero_stage)
         model.attach_optimizer(self.opt)
         self.history: List[dict] = []
 
@@ -146,42 +146,56 @@ class Trainer:
             self._bad_evals += 1
         return bool(a.early_stopping_patience) and a.load_best_model_at_end and self._bad_evals >= a.early_stopping_patience
 
+    def _micro_per_epoch(self) -> int:
+        n_micro = math.ceil(len(self.ds) / self.args.per_device_train_batch_size)
+        if self.world > 1:
+            n_micro -= n_micro % self.world
+        return n_micro // self.world
+
     def train(self):
+        """Window bookkeeping of the pasted HF loop (reference src/trainer/domain_loss.py:584-608): an epoch of
+        `steps_in_epoch` micro-batches makes ceil(steps_in_epoch / GA) optimizer steps — the LAST window of an epoch may be
+        shorter and still steps (`do_sync_step = (step+1) % GA == 0 or (step+1) == steps_in_epoch`, :608)."""
         a, m = self.args, self.model
         B, GA = a.per_device_train_batch_size, a.gradient_accumulation_steps
-        micro_per_epoch = math.ceil(len(self.ds) / B) // self.world
-        steps_per_epoch = max(micro_per_epoch // GA, 1)
+        micro_per_epoch = self._micro_per_epoch()
+        if micro_per_epoch == 0:
+            raise ValueError(f"{len(self.ds)} samples make fewer micro-batches of {B} than there are ranks ({self.world}): "
+                             "no rank would ever step")
+        steps_per_epoch = max(math.ceil(micro_per_epoch / GA), 1)      # HF: num_update_steps_per_epoch
         total = a.max_steps if a.max_steps > 0 else math.ceil(a.num_train_epochs * steps_per_epoch)
         warmup = math.ceil(total * a.warmup_ratio)
         step, epoch = 0, 0
         window_loss = torch.zeros((), dtype=torch.float32, device=m._rt.dev)
-        log_acc, last_logged, t0 = 0.0, 0, time.time()
+        last_logged, t0 = 0, time.time()
         while step < total:
-            micro = 0
-            for batch in self._micro_batches(epoch):
+            in_window = 0
+            for mi, batch in enumerate(self._micro_batches(epoch)):
+                do_sync = (mi + 1) % GA == 0 or (mi + 1) == micro_per_epoch
                 loss = m.forward_backward(batch["input_ids"], batch["attention_mask"], batch["omic_ids"],
-                                          batch["omic_info_list"], batch["labels"], accumulate=micro > 0,
-                                          final_micro=micro == GA - 1)
-                window_loss += loss
-                micro += 1
-                if micro < GA:
+                                          batch["omic_info_list"], batch["labels"], accumulate=in_window > 0,
+                                          final_micro=do_sync)
+                # reference :655-661 — a non-finite micro loss adds the running average of the current logging span instead
+                window_loss += torch.where(torch.isfinite(loss), loss, window_loss / (1 + step - last_logged))
+                in_window += 1
+                if not do_sync:
                     continue
                 lr = linear_warmup_lr(step, a.learning_rate, warmup, total)
                 gnorm = self.opt.step(lr=lr)
                 step += 1
-                micro = 0
+                in_window = 0
                 if step % a.logging_steps == 0 or step == total:
                     wl = window_loss.clone()
                     if self.world > 1:
                         dist.all_reduce(wl)
                         wl /= self.world
-                    v = float(wl.item())
-                    if not math.isfinite(v):                        # reference: NaN/Inf filter for the LOG only
-                        v = log_acc / max(last_logged, 1)
-                    rec = {"step": step, "loss": round(v / (step - last_logged), 4), "grad_norm": float(gnorm.item()),
-                           "learning_rate": lr, "epoch": round(epoch + micro / max(micro_per_epoch, 1), 4),
-                           "elapsed_s": round(time.time() - t0, 2)}
-                    log_acc += v
+                    # learning_rate = the rate this step used (the pasted loop reads it before the scheduler steps, :717)
+                    rec = {"step": step, "loss": round(float(wl.item()) / (step - last_logged), 4),
+                           "grad_norm": float(gnorm.item()), "learning_rate": lr,
+                           "epoch": round(epoch + (mi + 1) / micro_per_epoch, 4), "elapsed_s": round(time.time() - t0, 2)}
+                    skipped = getattr(self.opt, "skipped_steps", None)
+                    if skipped is not None and int(skipped()) > 0:
+                        rec["skipped_steps"] = int(skipped())
                     last_logged = step
                     window_loss.zero_()
                     self.history.append(rec)
@@ -194,7 +208,30 @@ class Trainer:
                 if step >= total:
                     break
             epoch += 1
+        if a.load_best_model_at_end and self.best_step is not None:
+            self._load_best()
         return self.history
+
+    def _load_best(self):
+        """HF `load_best_model_at_end`: training ends on the weights of the best evaluation, not the last step's.  `best/` was
+        written by rank 0 (`_maybe_evaluate`); every rank reads it back into its flat buffers and refreshes the fp32 masters."""
+        a, m = self.args, self.model
+        if dist.is_initialized():
+            dist.barrier()
+        d = os.path.join(a.output_dir, "best")
+        rt = m._runtime()
+        self.opt.wait_all_params()
+        torch.cuda.synchronize()
+        if rt.llm.lora is not None:
+            from ..lora import load_live_adapter
+            load_live_adapter(m, d)
+        else:
+            sd = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu")
+            with torch.no_grad():
+                for n, v in rt.P.views.items():
+                    if n in sd:
+                        v.copy_(sd[n].to(v.dtype))
+        self.opt.refresh_master()
 
     def _save_checkpoint(self, step: int):
         a = self.args

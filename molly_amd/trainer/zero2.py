@@ -28,6 +28,7 @@ Overlap (default on for world > 1): collectives run on a dedicated communication
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -42,15 +43,35 @@ def linear_warmup_lr(step: int, base_lr: float, warmup: int, total: int) -> floa
 
 
 class _DistComm:
-    """torch.distributed collectives (RCCL on ROCm); in-place on contiguous bucket regions."""
+    """torch.distributed collectives (RCCL on ROCm); in-place on contiguous bucket regions (NCCL/RCCL define both in-place
+    forms: reduce-scatter with recvbuff == sendbuff + rank*recvcount, all-gather with sendbuff == recvbuff + rank*sendcount).
+    `staged=True` goes through a scratch chunk instead (one extra copy per bucket) — selected by `preflight_collectives`
+    if the in-place forms ever returned a wrong answer on the installed backend."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, staged: bool = False):
         self.group = group
+        self.staged = staged
+        self._scratch = None
+
+    def _tmp(self, like):
+        if self._scratch is None or self._scratch.numel() < like.numel() or self._scratch.dtype != like.dtype:
+            self._scratch = torch.empty(like.numel(), dtype=like.dtype, device=like.device)
+        return self._scratch[:like.numel()]
 
     def reduce_scatter(self, out_chunk, region):
+        if self.staged:
+            tmp = self._tmp(out_chunk)
+            dist.reduce_scatter_tensor(tmp, region, group=self.group)
+            out_chunk.copy_(tmp)
+            return
         dist.reduce_scatter_tensor(out_chunk, region, group=self.group)
 
     def all_gather(self, region, chunk):
+        if self.staged:
+            tmp = self._tmp(chunk)
+            tmp.copy_(chunk)
+            dist.all_gather_into_tensor(region, tmp, group=self.group)
+            return
         dist.all_gather_into_tensor(region, chunk, group=self.group)
 
     def all_reduce(self, t):
@@ -58,6 +79,53 @@ class _DistComm:
 
     def all_reduce_region(self, region):
         dist.all_reduce(region, group=self.group)
+
+
+_STAGED_DEFAULT = False        # set by preflight_collectives when the in-place forms misbehave on this backend
+
+
+def preflight_collectives(device, group=None, n_per_rank: int = 4096) -> dict:
+    """First contact with the communication backend, before anything expensive is built: the three collectives of the step
+    (in-place reduce-scatter, in-place all-gather, all-reduce) on small integer-valued bf16 buffers with known answers.
+    A wrong in-place result switches every later `_DistComm` to its staged form (and says so); a wrong staged result raises.
+    Returns a small report for the bench line."""
+    global _STAGED_DEFAULT
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rep = {"world": world, "inplace_reduce_scatter": None, "inplace_all_gather": None, "all_reduce": None}
+
+    def fresh():
+        # element j of rank r's buffer = (j % 8) + r: sums over ranks are small integers, exact in bf16
+        base = (torch.arange(n_per_rank * world, device=device) % 8).to(torch.bfloat16)
+        return base + rank
+    want_sum = (torch.arange(n_per_rank * world, device=device) % 8).float() * world + world * (world - 1) / 2
+    for staged in (False, True):
+        comm = _DistComm(group, staged=staged)
+        buf = fresh()
+        mine = buf[rank * n_per_rank:(rank + 1) * n_per_rank]
+        comm.reduce_scatter(mine, buf)
+        ok_rs = bool(torch.equal(mine.float(), want_sum[rank * n_per_rank:(rank + 1) * n_per_rank]))
+        buf2 = torch.zeros(n_per_rank * world, dtype=torch.bfloat16, device=device)
+        buf2[rank * n_per_rank:(rank + 1) * n_per_rank] = rank + 1
+        comm.all_gather(buf2, buf2[rank * n_per_rank:(rank + 1) * n_per_rank])
+        want_ag = (torch.arange(n_per_rank * world, device=device) // n_per_rank + 1).float()
+        ok_ag = bool(torch.equal(buf2.float(), want_ag))
+        flags = torch.tensor([float(ok_rs), float(ok_ag)], device=device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)              # every rank takes the same decision
+        ok_rs, ok_ag = bool(flags[0] > 0), bool(flags[1] > 0)
+        if not staged:
+            rep["inplace_reduce_scatter"], rep["inplace_all_gather"] = ok_rs, ok_ag
+        if ok_rs and ok_ag:
+            _STAGED_DEFAULT = staged
+            break
+        if staged:
+            raise RuntimeError(f"collectives return wrong results on this backend (staged form too): rs={ok_rs} ag={ok_ag}")
+    t = fresh()
+    dist.all_reduce(t, group=group)
+    rep["all_reduce"] = bool(torch.equal(t.float(), want_sum))
+    if not rep["all_reduce"]:
+        raise RuntimeError("all_reduce returned a wrong sum on this backend")
+    rep["staged"] = _STAGED_DEFAULT
+    return rep
 
 
 class _HipKernels:
@@ -72,10 +140,12 @@ class _HipKernels:
         self.ops.sqnorm(g, out, self.ws, accumulate=accumulate)
 
     def clip_coef(self, norm_sq, max_norm, pre_scale, norm_out, coef_out):
-        self.ops.clip_coef(norm_sq, max_norm, pre_scale, norm_out, coef_out)
+        # coef_out is scal[2:3]; the slot behind it (scal[3]) counts skipped (non-finite-norm) steps
+        self.skipped = coef_out.as_strided((1,), (1,), coef_out.storage_offset() + 1)
+        self.ops.clip_coef(norm_sq, max_norm, pre_scale, norm_out, coef_out, self.skipped)
 
     def adamw(self, master, m, v, grad, param_out, lr, b1, b2, eps, wd, step, gscale):
-        self.ops.adamw_step(master, m, v, grad, param_out, lr, b1, b2, eps, wd, step, gscale)
+        self.ops.adamw_step(master, m, v, grad, param_out, lr, b1, b2, eps, wd, step, gscale, getattr(self, "skipped", None))
 
 
 class Zero2Optimizer:
@@ -117,11 +187,11 @@ class Zero2Optimizer:
             pos += per
         self.m = torch.zeros_like(self.master)
         self.v = torch.zeros_like(self.master)
-        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)       # [0]=norm^2 [1]=norm [2]=coef
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)       # [0]=norm^2 [1]=norm [2]=coef [3]=skipped steps
         self.k = kernels if kernels is not None else _HipKernels(dev)
         self.t = 0
         # ---- overlap machinery -------------------------------------------------------------------------------
-        self.comm = comm if comm is not None else _DistComm(group)
+        self.comm = comm if comm is not None else _DistComm(group, staged=_STAGED_DEFAULT)
         self.overlap = (self.world > 1) if overlap is None else overlap
         self.overlap = self.overlap and flat_params.is_cuda
         self.P_out = flat_params                # AdamW writes here; the all-gather publishes into P (same buffer in production)
@@ -133,16 +203,32 @@ class Zero2Optimizer:
         self._async_armed = False
         self.ustream = None
         if self.overlap:
-            if self.world > 1:
+            if self.world > 1 and flat_params.is_cuda and os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "0") != "1":
                 # RCCL's collective kernels hold CUs for milliseconds.  The persistent GEMM launches exactly one block per
                 # CU, each owning 1/256 of the tiles: with a few CUs taken, the blocks that cannot start wait for a whole
                 # share to finish and the launch takes twice as long.  One block per tile degrades by the CUs taken only.
+                # (A prediction, not yet a measurement: MOLLY_GEMM_PERSISTENT_MULTI=1 keeps the persistent launch for an A/B.)
                 from .. import ops
                 ops.lib().call("molly_gemm_set_persistent_blocks", 0)
             self.cstream = torch.cuda.Stream(device=dev, priority=-1)     # collectives first whenever CUs free up
             self._rs_done = [False] * len(self.buckets)
             self._ag_events = [None] * len(self.buckets)
             self._ag_waited = [True] * len(self.buckets)
+
+    def set_overlap(self, on: bool):
+        """Switch between the overlapped exchange (collectives on the communication stream) and the synchronous one (the
+        reference's overlap_comm:false) between two steps — bench.py measures the exposed communication time this way."""
+        if self.world == 1 or not self.P.is_cuda:
+            return
+        self.wait_all_params()
+        torch.cuda.current_stream().wait_stream(self.cstream) if hasattr(self, "cstream") else None
+        torch.cuda.synchronize()
+        if on and not hasattr(self, "cstream"):
+            self.cstream = torch.cuda.Stream(device=self.P.device, priority=-1)
+        self._rs_done = [False] * len(self.buckets)
+        self._ag_events = [None] * len(self.buckets)
+        self._ag_waited = [True] * len(self.buckets)
+        self.overlap = bool(on)
 
     # ---- hooks the engines call -------------------------------------------------------------------------------
     def on_grads_final(self, lo: int, hi: int):
@@ -290,6 +376,22 @@ class Zero2Optimizer:
                 self._ag_events[b] = done
                 self._ag_waited[b] = False
         self._async_armed = True
+
+    def skipped_steps(self) -> int:
+        """Optimizer steps skipped because the gradient norm was not finite (host sync: call when logging)."""
+        return int(self.scal[3].item())
+
+    @torch.no_grad()
+    def refresh_master(self):
+        """Re-read the fp32 masters from the bf16 parameters (after a checkpoint was loaded into them); moments are kept."""
+        if self.stage == 0:
+            self.master.copy_(self.P.float())
+            return
+        pos = 0
+        for start, per in self.buckets:
+            lo = start + self.rank * per
+            self.master[pos:pos + per].copy_(self.P[lo:lo + per].float())
+            pos += per
 
     def comm_bytes_per_step(self) -> int:
         """bytes each rank sends (= receives) per optimizer step: RS + AG of bf16, (world-1)/world of the buffer each."""

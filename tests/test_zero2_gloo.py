@@ -26,7 +26,7 @@ class TorchKernels:
         param_out.copy_(master.to(param_out.dtype))
 
 
-def _worker(rank, world, port, n, n_decay, chunk, ret, stage=2):
+def _worker(rank, world, port, n, n_decay, chunk, ret, stage=2, staged=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from molly_amd.trainer.zero2 import Zero2Optimizer
@@ -35,7 +35,9 @@ def _worker(rank, world, port, n, n_decay, chunk, ret, stage=2):
     P = p0.clone().bfloat16()
     grads = [torch.randn(n, generator=torch.Generator().manual_seed(10 + r)).bfloat16() for r in range(world)]
     G = grads[rank].clone()
-    opt = Zero2Optimizer(P, G, n_decay, lr=1e-2, max_grad_norm=1.0, chunk_elems=chunk, kernels=TorchKernels(), stage=stage)
+    from molly_amd.trainer.zero2 import _DistComm
+    opt = Zero2Optimizer(P, G, n_decay, lr=1e-2, max_grad_norm=1.0, chunk_elems=chunk, kernels=TorchKernels(), stage=stage,
+                         comm=_DistComm(staged=True) if staged else None)
     for _ in range(2):
         G.copy_(grads[rank])
         norm = opt.step()
@@ -104,3 +106,33 @@ def test_bucket_partition_covers_buffer_once():
     opt = Zero2Optimizer(P, P.clone(), 1000, chunk_elems=1000, kernels=TorchKernels())
     assert sum(per * opt.world for _, per in opt.buckets) == 4096
     assert all(per % 8 == 0 for _, per in opt.buckets)
+
+
+def _preflight_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from molly_amd.trainer.zero2 import preflight_collectives
+    ret[rank] = preflight_collectives(torch.device("cpu"), n_per_rank=64)
+    dist.destroy_process_group()
+
+
+def test_preflight_collectives_two_ranks():
+    """bench.py's first contact with the communication backend: the in-place reduce-scatter / all-gather / all-reduce forms
+    the ZeRO step uses return their known answers (gloo here; RCCL on the GPU box runs the same function)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_preflight_worker, args=(2, 29571, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        rep = ret[r]
+        assert rep["world"] == 2 and rep["all_reduce"] is True
+        assert rep["inplace_reduce_scatter"] and rep["inplace_all_gather"] and rep["staged"] is False
+
+
+def test_staged_collectives_equal_inplace():
+    """The fallback `preflight_collectives` would select (scratch chunk instead of aliasing) steps to the same parameters,
+    bit for bit, as the in-place collectives."""
+    mgr = mp.Manager()
+    a, b = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(2, 29573, 1024, 768, 64, a, 2, True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29575, 1024, 768, 64, b), nprocs=2, join=True)
+    assert torch.equal(a[0][0], a[1][0]) and torch.equal(a[0][0], b[0][0]) and a[0][1] == b[0][1]
