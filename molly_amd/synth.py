@@ -75,16 +75,18 @@ SPECIAL_IDS = {
 
 def synth_batch(B: int, T: int, spans: List[Tuple[str, int]], seed: int, text_vocab: int = 151643,
                 enc_vocab: Dict[str, int] | None = None, ragged: bool = False,
-                special_ids: Dict[str, Tuple[int, int, int]] | None = None, pad_id: int = 151643):
+                special_ids: Dict[str, Tuple[int, int, int]] | None = None, pad_id: int = 151643, mixed_k: bool = False):
     """One collated batch. `spans` = [(type, K), ...] per sample (all samples get the same span set,
     like the reference which pads every omic row to K = *_k_tokens, omics_dataset.py:430-444).
-    All spans must share one K (the collate stacks them: omics_dataset.py:483-486)."""
+    Spans normally share one K (the reference's dataset stacks a sample's rows: omics_dataset.py:411).  `mixed_k=True` lifts
+    that for BASELINE config 4 (protein K=1024 beside DNA K=1000): `omic_ids` is then a list (samples) of lists (rows) of
+    1-D tensors — what `OmicsOne.process_omic_sequences` itself iterates over (reference src/model/omics_one.py:104-118)."""
     g = torch.Generator().manual_seed(seed)
     sp = special_ids or SPECIAL_IDS
     enc_vocab = enc_vocab or {"dna": 4100, "rna": 4100, "protein": 24}
     Ks = {k for _, k in spans}
-    assert len(Ks) <= 1, "collate stacks omic rows: one K per batch"
-    K = Ks.pop() if Ks else 0
+    assert len(Ks) <= 1 or mixed_k, "collate stacks omic rows: one K per batch"
+    K = max(Ks) if Ks else 0
     n_max = max(len(spans), 1)
     input_ids = torch.randint(0, text_vocab, (B, T), generator=g, dtype=torch.int64)
     labels = torch.full((B, T), -100, dtype=torch.int64)
@@ -130,5 +132,7 @@ def synth_batch(B: int, T: int, spans: List[Tuple[str, int]], seed: int, text_vo
         if valid < T:
             input_ids[b, valid:] = pad_id
             attention_mask[b, valid:] = 0
+    if mixed_k:
+        omic_ids = [[omic_ids[b, j, :k].clone() for j, (_, k) in enumerate(spans)] for b in range(B)]
     return {"input_ids": input_ids, "labels": labels, "attention_mask": attention_mask,
             "omic_ids": omic_ids, "omic_info_list": info}

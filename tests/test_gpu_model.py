@@ -118,3 +118,75 @@ def test_error_behaviour_matches_reference(tiny_meta, tiny_gold):
     with pytest.raises(AssertionError, match="out-of-range token"):
         m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], omic_ids=ids,
           omic_info_list=batch["omic_info_list"])
+
+
+def _shells(meta):
+    import molly_amd
+    from molly_amd.config import EncConfig, LlmConfig, OmicsModalConfig
+    c = meta["config"]
+    cfg = OmicsModalConfig(text_config=LlmConfig.from_dict(c["text"]), dna_rna_config=EncConfig.from_dict(c["dna_rna"]),
+                           protein_config=EncConfig.from_dict(c["protein"]))
+    cfg.dna_rna_project_token_num = cfg.protein_project_token_num = c["K"]
+    m = molly_amd.OmicsOne(cfg)
+    m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)                 # un-materialised shells, as a caller builds them
+    m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
+    m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
+    return m
+
+
+def test_reference_inference_call_sequence_on_the_shells(tiny_meta, tiny_gold):
+    """src/inference_lora.py:243-250 verbatim: plain strict `load_state_dict(torch.load(...))` of a checkpoint with the
+    reference's key set (encoder MaskedLM / contact heads included), `.to(torch.bfloat16).to(device)`, `.eval()`, then a
+    forward — no prepare() call by the caller.  Must give the logits of the explicitly prepared model."""
+    batch = tiny_batch(tiny_gold, tiny_meta)
+    args = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], omic_ids=batch["omic_ids"],
+                omic_info_list=batch["omic_info_list"], labels=batch["labels"])
+    m = _shells(tiny_meta)
+    m.load_state_dict(tiny_state_dict(tiny_meta))
+    m = m.to(torch.bfloat16).to(torch.device("cuda", 0))
+    m.eval()
+    assert m.model.model.layers[0].mlp.down_proj.weight.is_cuda
+    with torch.no_grad():
+        out = m(**args)
+    assert m._rt.G is None                                               # .eval(): no trainable group was allocated
+    ref = build_tiny(tiny_meta)
+    with torch.no_grad():
+        want = ref(**args)
+    # the caller's .to(bf16) rounds the fp32 checkpoint exactly like prepare()'s copy into the bf16 flat buffer
+    assert torch.equal(out.logits, want.logits) and torch.equal(out.loss, want.loss)
+    # parameters now live in the flat buffers: a later load_state_dict copies INTO them (and is seen by the kernels)
+    sd2 = {k: v * 0.5 for k, v in tiny_state_dict(tiny_meta).items()}
+    m.load_state_dict(sd2)
+    with torch.no_grad():
+        out2 = m(**args)
+    assert not torch.equal(out2.logits, out.logits)
+    # a model that never received weights refuses to run
+    hollow = _shells(tiny_meta).to(torch.bfloat16).to("cuda").eval()
+    with pytest.raises(RuntimeError, match="no value"):
+        hollow(**args)
+
+
+def test_reference_freeze_then_train_call_sequence(tiny_meta, tiny_gold):
+    """src/train.py:655-660 -> set_up_trainable_param(model, args) with --train-mlp only: the LLM and encoder sub-trees are
+    re-registered as buffers (freeze_subtree).  `prepare_from_module_state` reads the trainable set off the module tree and
+    must step exactly like `prepare(train_llm=False, train_mlp=True)`."""
+    from test_shell_boundary import _apply_reference_flags
+    batch = tiny_batch(tiny_gold, tiny_meta)
+    a = [batch[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")]
+    m = _shells(tiny_meta)
+    m.load_state_dict(tiny_state_dict(tiny_meta))
+    _apply_reference_flags(m, train_llm=False, train_mlp=True, train_bio=False)
+    assert m.infer_trainable() == (False, True, False)
+    m.prepare_from_module_state("cuda")
+    loss = m.forward_backward(*a)
+    ref = _shells(tiny_meta)
+    ref.load_state_dict(tiny_state_dict(tiny_meta))
+    ref.prepare("cuda", train_llm=False, train_mlp=True)
+    loss_ref = ref.forward_backward(*a)
+    torch.cuda.synchronize()
+    assert torch.equal(loss, loss_ref) and torch.equal(m._rt.G.flat, ref._rt.G.flat)
+    assert sorted(m._rt.G.views) == ["dna_rna_projector.bias", "dna_rna_projector.weight", "protein_projector.bias",
+                                     "protein_projector.weight"]
+    # the frozen sub-trees are still in the checkpoint, as buffers, and now point into HBM
+    sd = m.state_dict()
+    assert sd["model.model.layers.0.mlp.down_proj.weight"].is_cuda and len(sd) == len(ref.state_dict())
