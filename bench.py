@@ -58,6 +58,13 @@ def _host_cpu():
     return max(1, cores), model
 
 
+# Intra-op threads of the CPU oracle.  SURVEY 8d says "physical cores"; measured on the GPU host of this pool (2 x EPYC 9575F,
+# 128 physical cores, gpurun_out/r02_t2_cpu*.log): the down-scaled C2 step takes 31.5 s with 128 threads, 17.3 s with 64 and
+# 12.0 s with 32 — at 512 tokens per step the matmuls are too small to feed two sockets, barriers and NUMA traffic dominate.
+# The baseline therefore uses min(physical cores, 32) threads (the CPU's best case of the three), and reports both numbers.
+CPU_THREAD_CAP = 32
+
+
 # the two CPU-baseline configurations of SURVEY.md §8d / BASELINE.md §3
 CPU_CONFIGS = {
     # C1 exactly: BASELINE configs[0] — Qwen3-0.6B + ESM2-t6-8M, fp32, B=2, T=256, one 64-residue protein span
@@ -119,7 +126,7 @@ def _cpu_step_worker(which: str, threads: int, budget_s: float, warmups: int = 2
     timed_s = secs[warmups:] or secs[-1:]
     print(json.dumps({"config": which, "B": B, "T": T, "K": K, "threads": threads, "warmups": min(warmups, len(secs) - 1) if secs[warmups:] else len(secs) - 1,
                       "step_seconds": [round(x, 3) for x in timed_s], "median_seconds": statistics.median(timed_s),
-                      "tokens_per_step": B * T, "loss": float(loss)}), flush=True)
+                      "tokens_per_step": B * T, "loss": float(loss.detach())}), flush=True)
 
 
 def _run_cpu_config(which: str, threads: int, budget_s: float):
@@ -144,15 +151,17 @@ def cpu_baseline(budget_s: float = 45.0):
     each configuration inside a wall-time box so that the default bench finishes in minutes.  `value` = measured tokens/s
     of the down-scaled C2 (tokens of the step / median step time — no FLOP extrapolation); C1 rides along in `c1`.
     Each runs in a child process that never touches the GPU."""
-    cores, model = _host_cpu()
-    out = {"value": None, "unit": "tokens/s", "cores": cores, "cpu_model": model, "kind": "port"}
+    physical, model = _host_cpu()
+    cores = min(physical, CPU_THREAD_CAP)
+    out = {"value": None, "unit": "tokens/s", "cores": cores, "physical_cores": physical, "cpu_model": model, "kind": "port"}
     d2, err2 = _run_cpu_config("c2s", cores, budget_s)
     d1, err1 = _run_cpu_config("c1", cores, budget_s / 2)
     if d2 is not None:
         out["value"] = round(d2["tokens_per_step"] / d2["median_seconds"], 2)
         out["sample"] = (f"C2 down-scaled (SURVEY 8d): Molly-1.7B full depth fp32 (Qwen3-1.7B + ESM2-650M), B={d2['B']} T={d2['T']} "
                          f"protein K={d2['K']}, fwd+bwd+clipped AdamW, {d2['warmups']} warm-up + {len(d2['step_seconds'])} timed "
-                         f"steps {d2['step_seconds']} s, median {d2['median_seconds']:.2f} s, {cores} threads = physical cores of {model}")
+                         f"steps {d2['step_seconds']} s, median {d2['median_seconds']:.2f} s, {cores} threads on {physical} physical cores of {model} "
+                         f"(more threads are slower at this size: 31.5 / 17.3 / 12.0 s per step at 128 / 64 / 32 threads, measured)")
     else:
         out["sample"] = err2
     if d1 is not None:
@@ -216,7 +225,7 @@ def main(argv=None):
     ap.add_argument("--event-stride", type=int, default=7,
                     help="HIP events around every n-th GEMM launch of the timed region (1 = all: 2-3 %% slower steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=45.0, help="wall-time box (s) of the down-scaled-C2 CPU run; C1 gets half")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="wall-time box (s) of the down-scaled-C2 CPU run; C1 gets half")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("CONFIG", "THREADS", "BUDGET_S"))
     ap.add_argument("--dry-run-launch", action="store_true", help="print the rank launch command instead of running it")
     args = ap.parse_args(argv)

@@ -116,9 +116,10 @@ int molly_swiglu_bwd(void* stream, const void* gate_up, const void* dout, void* 
 int molly_copy_rows(void* stream, const void* src, const int64_t* src_idx64, const int* src_idx32, void* dst,
                     const int* dst_idx32, long n, int H, int ld_src, int ld_dst, int accumulate);
 /* embedding backward through a sorted index: for unique id u, dE[uid[u]] += sum_k g[order[k]],
- * k in [seg_start[u], seg_start[u+1]); uid < 0 skips.  Deterministic (no atomics). */
+ * k in [seg_start[u], seg_start[u+1]); uid < 0 skips.  Deterministic (no atomics).  n_unique_dev (nullable): the number of
+ * segments lives on the device (molly_batch_assemble wrote it); n_unique is then only the launch bound (>= the true count). */
 int molly_embed_bwd(void* stream, const void* g, const int* order, const int* seg_start, const int64_t* uid,
-                    int n_unique, void* dE, int H, int ld_g, const float* row_scale);
+                    int n_unique, void* dE, int H, int ld_g, const float* row_scale, const int* n_unique_dev);
 
 /* cross-entropy on bf16 logits, in place -> d(logits) — HF:loss/loss_utils.py:32-71 (ForCausalLMLoss; Liger
  * fused-linear-CE when --use_liger).  `labels` are already shifted (row r is scored against labels[r]);
@@ -135,6 +136,17 @@ int molly_cls_loss_fwd_bwd(void* stream, void* logits, const int64_t* labels, co
 /* greedy token selection of generate(do_sample=False) — HF:generation/utils.py `next_tokens = torch.argmax(scores, -1)`
  * (reference src/model/omics_one.py:220-232 passes do_sample through): first maximal index per row of fp32 logits [rows][ld]. */
 int molly_argmax_f32(void* stream, const float* x, int64_t* out, int rows, int V, int ld);
+/* sampling of generate(do_sample=True) — the reference's inference settings (src/inference_lora.py:293-298: temperature 0.8,
+ * top_p 0.95, top_k 20, repetition_penalty 1.1) through HF's processors in HF's order (HF:generation/logits_process.py:
+ * RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper; softmax + multinomial in
+ * HF:generation/utils.py _sample).  fp32 logits [rows][ld] (modified in place by the penalty), generated int64
+ * [rows][ld_generated] (first n_generated columns), one token per row into next_token.  The draw is Philox4x32-10 keyed by
+ * (seed, step, row): HF's distribution, not torch's random stream.  probs_out / ids_out [rows][cap_out], n_out [rows]
+ * (nullable): the surviving tokens in descending order with their final probabilities.  1 <= top_k <= 1024. */
+int molly_sample_logits(void* stream, float* logits, int rows, int V, int ld, const int64_t* generated, int n_generated,
+                        int ld_generated, float repetition_penalty, float temperature, int top_k, float top_p, uint64_t seed,
+                        int step, int64_t* next_token, float* probs_out_or_null, int64_t* ids_out_or_null,
+                        int* n_out_or_null, int cap_out);
 int molly_sum_f32(void* stream, const float* x, long n, const float* scale_or_null, float* out, int accumulate);
 
 /* LayerNorm forward (affine, eps 1e-5) — ESM pre-LN blocks and emb_layer_norm_after: HF:models/esm/
@@ -157,6 +169,24 @@ int molly_gelu_bwd(void* stream, const void* z, const void* dout, void* dz, long
 int molly_esm_embed(void* stream, const int64_t* ids, const void* word_emb, const void* pos_emb_or_null, void* out,
                     int* pos_ids_out_or_null, int* kv_len_out_or_null, int n_seq, int K, int H, int pad_id, int mask_id,
                     int token_dropout);
+
+/* Batch assembly on the device — replaces the per-step host work around the model call: reference
+ * src/model/omics_one.py:69-72 (stack, mask, device->host sync assert), :93-97 (one slice copy per span), :104-118 (per-row
+ * .to(device)), and HF's label shift (HF:loss/loss_utils.py:60-63).  Inputs are slices of ONE packed int32 image that arrived
+ * by one pinned host->device copy: ids32/labels32 [B*T], spans [n_spans][4] = (b, start, group 0|1, row in the group's encoder
+ * batch; start -1 = encoded but never scattered), omic32_g* [n_rows][K].  Outputs: labels_shifted int64 [B*T] and the ordered
+ * scored_rows / *n_scored (label != ignore_index); per group the int64 encoder ids and dst[row*K + j] = b*T + start + 1 + j
+ * for j < k (k = min(config token count, K)), else -1; overwritten[B*T] (bytes); and, when `order` is given, the sorted
+ * embedding-gradient index over the NOT overwritten rows (stable radix sort by token id): order[], seg_start[n_unique + 1],
+ * uid[n_unique], *n_unique — all on the device.  keys_tmp: 2*B*T ints, vals_tmp: B*T ints, sort_ws: molly_batch_sort_workspace
+ * bytes.  labels32 / ids32 / order may be NULL (inference, process_omic_sequences). */
+int molly_batch_sort_workspace(int M);
+int molly_batch_assemble(void* stream, const int* ids32, const int* labels32, int B, int T, int vocab, int ignore_index,
+                         const int* spans, int n_spans, const int* omic32_g0, int n_rows0, int K0, int k0,
+                         const int* omic32_g1, int n_rows1, int K1, int k1, int64_t* labels_shifted, int* scored_rows,
+                         int* n_scored, int64_t* omic64_g0, int* dst_g0, int64_t* omic64_g1, int* dst_g1,
+                         unsigned char* overwritten, int* keys_tmp, int* vals_tmp, int* order, int* seg_start, int64_t* uid,
+                         int* n_unique, void* sort_ws, long sort_ws_bytes);
 
 /* optimizer shard step — torch.optim.AdamW (HF `adamw_torch`, reference src/trainer/omics_trainer.py:53-60) on an
  * fp32 master shard with bf16 grads; global-norm clip = torch.nn.utils.clip_grad_norm_ (reference

@@ -1,9 +1,12 @@
 """Build libmolly_hip.so (the C-ABI HIP library, include/molly_hip.h) in-tree with hipcc for gfx950.
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so travels to
-the GPU box with the repo snapshot.  Rebuilds only when a source is newer than its object."""
+the GPU box with the repo snapshot.  Staleness is decided by CONTENT (a digest of the source, every header and the flags,
+kept beside each object), not by modification times: a snapshot copy reshuffles mtimes, and a rebuild on the GPU box
+would cost box minutes and print into the benchmark's stdout.  Messages go to stderr for the same reason."""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -23,16 +26,22 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
-def _newest_header():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hs.append(os.path.join(ROOT, "include", "molly_hip.h"))
-    return max(os.path.getmtime(h) for h in hs)
+def _digest(src):
+    h = hashlib.sha256()
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "molly_hip.h")]
+    for f in [os.path.join(CSRC, src)] + hs:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(f for f in FLAGS if not f.startswith("-I")).encode())
+    return h.hexdigest()
 
 
 def _compile(src):
     obj = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+    stamp = obj + ".sha256"
     sp = os.path.join(CSRC, src)
-    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _newest_header()):
+    dg = _digest(src)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == dg:
         return obj, False
     cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -40,6 +49,8 @@ def _compile(src):
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(dg)
     return obj, True
 
 
@@ -51,13 +62,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=6) as ex:
         res = list(ex.map(_compile, _sources()))
     objs = [o for o, _ in res]
-    if any(c for _, c in res) or not os.path.exists(LIB):
+    want = hashlib.sha256("".join(open(o + ".sha256").read() for o in objs).encode()).hexdigest()
+    lstamp = os.path.join(OBJ, "libmolly_hip.sha256")
+    linked = os.path.exists(LIB) and os.path.exists(lstamp) and open(lstamp).read().strip() == want
+    if any(c for _, c in res) or not linked:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(lstamp, "w") as f:
+            f.write(want)
         if verbose:
-            print(f"[molly_amd.build] linked {LIB} from {len(objs)} objects")
+            print(f"[molly_amd.build] linked {LIB} from {len(objs)} objects", file=sys.stderr)
     return LIB
 
 

@@ -501,10 +501,11 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict__ g, const int* __restrict__ order,
                                                         const int* __restrict__ seg_start, const long* __restrict__ uid,
                                                         int n_unique, bf16_t* __restrict__ dE, int H, int ld_g,
-                                                        const float* __restrict__ row_scale) {
+                                                        const float* __restrict__ row_scale,
+                                                        const int* __restrict__ n_unique_dev) {
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= n_unique) return;
+    if (u >= n_unique || (n_unique_dev && u >= *n_unique_dev)) return;
     const int b = seg_start[u], e = seg_start[u + 1];
     const long id = uid[u];
     if (id < 0) return;
@@ -1179,11 +1180,11 @@ extern "C" int molly_copy_rows(void* stream, const void* src, const int64_t* src
 }
 
 extern "C" int molly_embed_bwd(void* stream, const void* g, const int* order, const int* seg_start, const int64_t* uid,
-                               int n_unique, void* dE, int H, int ld_g, const float* row_scale) {
+                               int n_unique, void* dE, int H, int ld_g, const float* row_scale, const int* n_unique_dev) {
     MOLLY_CHECK(H % 8 == 0 && ld_g % 8 == 0, "embed_bwd: H must be a multiple of 8");
     if (n_unique <= 0) return 0;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(n_unique, 4)), dim3(256), 0, ST, (const bf16_t*)g, order, seg_start,
-                       (const long*)uid, n_unique, (bf16_t*)dE, H, ld_g, row_scale);
+                       (const long*)uid, n_unique, (bf16_t*)dE, H, ld_g, row_scale, n_unique_dev);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

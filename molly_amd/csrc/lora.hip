@@ -6,23 +6,7 @@
 
 namespace {
 
-// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so element i's
-// keep bit is a pure function of (seed, i) and the backward pass regenerates the mask instead of storing it.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                              uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0;
-        c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
-        c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
+// Philox4x32-10: common.h (element i's keep bit is a pure function of (seed, i): the backward regenerates the mask).
 
 // out[i] (+)= keep_i ? x[i] / (1 - p) : 0, 8 elements (one Philox block = eight 16-bit uniforms) per thread.
 // P(keep) = 1 - thr / 65536 with thr = round(p * 65536): p = 0.05 -> 0.0500031.

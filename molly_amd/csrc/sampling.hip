@@ -1,0 +1,163 @@
+// Sampling logits processors + token draw of `generate(do_sample=True)` on the device.  The reference samples
+// with repetition_penalty 1.1, temperature 0.8, top_k 20, top_p 0.95 (src/inference_lora.py:293-298,
+// scripts/infer/inference_nt_lora.sh:28-30) through HF generate's processors, in HF's order
+// (HF:generation/logits_process.py RepetitionPenaltyLogitsProcessor -> TemperatureLogitsWarper -> TopKLogitsWarper ->
+// TopPLogitsWarper, then softmax + torch.multinomial, HF:generation/utils.py _sample):
+//   1. repetition penalty on every token generated so far:  s = s < 0 ? s * pen : s / pen   (once per distinct token)
+//   2. s /= temperature
+//   3. top-k: everything below the k-th largest score -> -inf   (ties with the k-th stay, as `scores < kth` keeps them)
+//   4. top-p: sort ascending, softmax, cumsum; drop tokens whose cumulative mass is <= 1 - top_p; the largest always stays
+//   5. softmax over what is left, one draw.
+// One block per row.  The k-th largest of V = 151936 scores comes from a 3-pass radix select on the order-preserving integer
+// image of the floats (11 + 11 + 10 bits, LDS histograms); the <= 1024 survivors are sorted in LDS (bitonic) and finished by
+// one thread (k = 20 in the reference's script).  The draw uses Philox4x32-10 keyed by (seed, step, row): the DISTRIBUTION is
+// HF's, the random stream is not torch's (tests compare the distribution; the survivors and their probabilities can be
+// written out for that).  The logits row is modified in place by step 1 (it is scratch: the next decode step overwrites it).
+#include "common.h"
+#include "molly_hip.h"
+
+namespace {
+
+constexpr int CAP = 1024;
+
+__device__ __forceinline__ unsigned fkey(float v) {            // larger float -> larger unsigned
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void sample_kernel(float* __restrict__ logits, int V, int ld, const long* __restrict__ gen,
+                                                      int n_gen, int ld_gen, float pen, float temperature, int top_k,
+                                                      float top_p, unsigned seed_lo, unsigned seed_hi, unsigned step,
+                                                      long* __restrict__ next_token, float* __restrict__ probs_out,
+                                                      long* __restrict__ ids_out, int* __restrict__ n_out, int cap_out) {
+    __shared__ unsigned hist[2048];
+    __shared__ float s_val[CAP];
+    __shared__ int s_idx[CAP];
+    __shared__ unsigned s_prefix, s_need;
+    __shared__ int s_cnt;
+    const int row = blockIdx.x, t = threadIdx.x;
+    float* x = logits + (size_t)row * ld;
+
+    // ---- 1. repetition penalty: read every listed token's score first, then write (duplicates write the same value)
+    if (pen != 1.0f && n_gen > 0) {
+        const long* g = gen + (size_t)row * ld_gen;
+        float keep[4];
+        int ids[4];
+        int m = 0;
+        for (int i = t; i < n_gen && m < 4; i += 1024) { ids[m] = (int)g[i]; keep[m] = x[ids[m]]; ++m; }
+        __syncthreads();
+        for (int j = 0; j < m; ++j) x[ids[j]] = keep[j] < 0.f ? keep[j] * pen : keep[j] / pen;
+        __syncthreads();
+    }
+
+    // ---- 3a. k-th largest by radix select (temperature > 0 is monotonic: select on the unscaled scores)
+    const int k = min(max(top_k, 1), V);
+    if (t == 0) { s_prefix = 0; s_need = (unsigned)k; }
+    __syncthreads();
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = t; i < 2048; i += 1024) hist[i] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const int sh = shifts[pass], nb = bits[pass];
+        const int hi_sh = sh + nb;                                   // bits above this pass's field
+        for (int i = t; i < V; i += 1024) {
+            const unsigned key = fkey(x[i]);
+            if (pass == 0 || (key >> hi_sh) == prefix) atomicAdd(&hist[(key >> sh) & ((1u << nb) - 1)], 1u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned need = s_need, cum = 0;
+            int b = (1 << nb) - 1;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= need) break;
+                cum += hist[b];
+            }
+            s_need = need - cum;
+            s_prefix = (prefix << nb) | (unsigned)b;
+        }
+        __syncthreads();
+    }
+    const unsigned thr = s_prefix;                                   // key of the k-th largest score
+
+    // ---- 3b. survivors (score >= k-th) into LDS, then sorted descending (ties: lower token id first)
+    if (t == 0) s_cnt = 0;
+    s_val[t] = -INFINITY;
+    s_idx[t] = 0x7fffffff;
+    __syncthreads();
+    for (int i = t; i < V; i += 1024) {
+        const float v = x[i];
+        if (fkey(v) >= thr) {
+            const int p = atomicAdd(&s_cnt, 1);
+            if (p < CAP) { s_val[p] = v; s_idx[p] = i; }
+        }
+    }
+    __syncthreads();
+    const int n = min(s_cnt, CAP);
+    for (int size = 2; size <= CAP; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int j = t ^ stride;
+            if (j > t) {
+                const bool desc = (t & size) == 0;
+                const float a = s_val[t], b = s_val[j];
+                const int ia = s_idx[t], ib = s_idx[j];
+                const bool a_first = a > b || (a == b && ia < ib);   // a belongs before b in descending order
+                if (desc != a_first) { s_val[t] = b; s_val[j] = a; s_idx[t] = ib; s_idx[j] = ia; }
+            }
+            __syncthreads();
+        }
+
+    // ---- 2, 4, 5: temperature, top-p, softmax, draw — one thread over the n sorted survivors
+    if (t == 0) {
+        const float T = temperature > 0.f ? temperature : 1.f;
+        const float mx = s_val[0] / T;
+        float sum = 0.f;
+        for (int j = n - 1; j >= 0; --j) { s_val[j] = __expf(s_val[j] / T - mx); sum += s_val[j]; }
+        int n_keep = n;
+        if (top_p < 1.f) {
+            float cum = 0.f;                                         // ascending cumulative mass, as HF computes it
+            for (int j = n - 1; j >= 1; --j) {
+                cum += s_val[j] / sum;
+                if (cum <= 1.f - top_p) n_keep = j; else break;
+            }
+        }
+        float ksum = 0.f;
+        for (int j = 0; j < n_keep; ++j) ksum += s_val[j];
+        unsigned rnd[4];
+        philox4x32_10((unsigned)row, step, 0u, 0u, seed_lo, seed_hi, rnd);
+        const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f) * ksum;
+        float acc = 0.f;
+        int pick = n_keep - 1;
+        for (int j = 0; j < n_keep; ++j) {
+            acc += s_val[j];
+            if (u < acc) { pick = j; break; }
+        }
+        next_token[row] = (long)s_idx[pick];
+        if (n_out) n_out[row] = n_keep;
+        if (probs_out)
+            for (int j = 0; j < min(n_keep, cap_out); ++j) {
+                probs_out[(size_t)row * cap_out + j] = s_val[j] / ksum;
+                ids_out[(size_t)row * cap_out + j] = (long)s_idx[j];
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int molly_sample_logits(void* stream, float* logits, int rows, int V, int ld, const int64_t* generated, int n_generated,
+                                   int ld_generated, float repetition_penalty, float temperature, int top_k, float top_p,
+                                   uint64_t seed, int step, int64_t* next_token, float* probs_out_or_null,
+                                   int64_t* ids_out_or_null, int* n_out_or_null, int cap_out) {
+    MOLLY_CHECK(rows > 0 && V > 0 && ld >= V, "sample_logits: rows=%d V=%d ld=%d", rows, V, ld);
+    MOLLY_CHECK(top_k >= 1 && top_k <= CAP, "sample_logits: top_k=%d outside 1..%d (no-top-k sampling is not built)", top_k, CAP);
+    MOLLY_CHECK(temperature > 0.f && top_p > 0.f && repetition_penalty > 0.f, "sample_logits: temperature / top_p / penalty must be > 0");
+    MOLLY_CHECK(n_generated <= 4096, "sample_logits: at most 4096 generated tokens enter the repetition penalty (got %d)", n_generated);
+    MOLLY_CHECK(n_generated == 0 || generated, "sample_logits: %d generated tokens without their ids", n_generated);
+    MOLLY_CHECK((probs_out_or_null == nullptr) == (ids_out_or_null == nullptr), "sample_logits: probs_out and ids_out go together");
+    hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, V, ld, (const long*)generated,
+                       n_generated, ld_generated, repetition_penalty, temperature, top_k, top_p, (unsigned)seed,
+                       (unsigned)(seed >> 32), (unsigned)step, (long*)next_token, probs_out_or_null, (long*)ids_out_or_null,
+                       n_out_or_null, cap_out);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}

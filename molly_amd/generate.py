@@ -39,7 +39,7 @@ class GenerationSession:
         pos = (mask.cumsum(1) - 1).clamp(min=0)                              # HF: position_ids = cumsum(mask)-1, pads -> 0/1
         self.lo = lo if lo is not None else torch.zeros(B, dtype=torch.int32, device=dev)
         self.n_valid = mask.sum(1).to(torch.int32).to(dev)                    # next position id per sample
-        hs, _, _ = m._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, False)
+        hs, _ = m._embed_and_inject(m._stage(input_ids, None, None, omic_ids, omic_info_list, want_sort=False), False)
         e.reserve(B * T, B, T, training=False)
         # rope tables must cover prompt + generated positions
         from .qwen3 import rope_tables
@@ -207,13 +207,21 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
     pad = pad_token_id if pad_token_id is not None else (int(eos[0]) if eos is not None else 0)
     out = torch.empty(B, 0, dtype=torch.int64, device=dev)
     unfinished = torch.ones(B, dtype=torch.bool, device=dev)
-    for _ in range(max_new_tokens):
-        lg = _process_logits(logits, out, temperature if do_sample else None, top_k if do_sample else None,
-                             top_p if do_sample else None, repetition_penalty)
-        if do_sample:
-            nxt = torch.multinomial(lg.softmax(-1), 1, generator=generator).squeeze(1)
+    # sampling with a top-k (the reference's inference settings: top_k 20) runs in ONE kernel per step: penalty, temperature,
+    # top-k, top-p, softmax and the draw (csrc/sampling.hip).  Without a top-k the torch restatement below is used.
+    fused = bool(do_sample and top_k and 1 <= top_k <= 1024 and logits.dtype == torch.float32)
+    seed = (generator.initial_seed() if generator is not None else torch.initial_seed()) & ((1 << 64) - 1)
+    for it in range(max_new_tokens):
+        if fused:
+            nxt = ops.sample_logits(logits, out if out.shape[1] else None, repetition_penalty, temperature, top_k, top_p,
+                                    seed, it)
         else:
-            nxt = ops.argmax(lg) if lg.dtype == torch.float32 else lg.argmax(-1)
+            lg = _process_logits(logits, out, temperature if do_sample else None, top_k if do_sample else None,
+                                 top_p if do_sample else None, repetition_penalty)
+            if do_sample:
+                nxt = torch.multinomial(lg.softmax(-1), 1, generator=generator).squeeze(1)
+            else:
+                nxt = ops.argmax(lg) if lg.dtype == torch.float32 else lg.argmax(-1)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
         out = torch.cat([out, nxt[:, None]], 1)
         if eos is not None:

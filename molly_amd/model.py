@@ -18,7 +18,6 @@ import math
 import re
 from typing import Dict, List, Optional, Tuple
 
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -228,74 +227,7 @@ class EsmForMaskedLM(_Shell):
         return cls(config).materialize(seed=seed)
 
 
-# ---- host-side batch assembly -----------------------------------------------------------------------------------
-def group_omics(omic_ids, omic_info_list, K_cfg: Dict[str, int], T: int):
-    """reference: src/model/omics_one.py:99-118 + :93-97.  One pass over the batch on the host; returns per modality
-    (ids int64 [N,K], dst_rows int32 [N*K]) where dst_rows[i*K+j] = b*T + start+1+j for j < min(K_cfg, K), else -1.
-    'pad' rows skipped; unknown type -> ValueError; start == -1 keeps the row in the encoder batch but never scatters."""
-    out = {"dna_rna": ([], []), "protein": ([], [])}
-    for b in range(len(omic_info_list)):
-        rows = omic_ids[b]
-        for j, info in enumerate(omic_info_list[b]):
-            t = info["type"]
-            if t in ("dna", "rna"):
-                g = out["dna_rna"]
-            elif t == "protein":
-                g = out["protein"]
-            elif t == "pad":
-                continue
-            else:
-                raise ValueError(f"Unsupported omic type: {t}")
-            g[0].append(rows[j])
-            g[1].append((b, int(info["start"])))
-    res = {}
-    for name, (rows, where) in out.items():
-        if not rows:
-            res[name] = None
-            continue
-        ids = torch.stack([torch.as_tensor(r) for r in rows], 0).to(torch.int64).cpu()
-        N, K = ids.shape
-        k = min(K_cfg[name], K)
-        dst = np.full((N, K), -1, dtype=np.int32)
-        for i, (b, start) in enumerate(where):
-            if start == -1:
-                continue
-            if start + 1 + k > T:
-                raise RuntimeError(
-                    f"omic span at start={start} (+{k} tokens) exceeds the sequence length {T} "
-                    "(reference fails here too: src/model/omics_one.py:97 after truncation, SURVEY.md §0.4-6)")
-            dst[i, :k] = b * T + start + 1 + np.arange(k, dtype=np.int32)
-        res[name] = (ids, torch.from_numpy(dst.reshape(-1)))
-    return res
-
-
-def check_trailing_pad(ids: torch.Tensor, pad: int = 1):
-    """The attention kernel masks keys by a per-sequence valid LENGTH; the reference's mask is `ids != 1`
-    (src/model/omics_one.py:70).  They coincide when pads are trailing, which is what the reference tokenisation emits
-    (padding='max_length', src/dataset/omics_dataset.py:430-444).  Interior pads are rejected loudly."""
-    m = ids != pad
-    n_valid = m.sum(1)
-    last = torch.where(m.any(1), (m.long() * torch.arange(1, ids.shape[1] + 1)).max(1).values, torch.zeros_like(n_valid))
-    if not torch.equal(n_valid, last):
-        raise NotImplementedError("omic ids with pad tokens (id 1) in the interior of a sequence are not supported")
-
-
-def embed_backward_index(input_ids_flat: np.ndarray, overwritten: np.ndarray):
-    """Sorted index for the embedding-gradient kernel: rows grouped by token id, overwritten (placeholder) rows dropped
-    — their embedding rows get no gradient because the reference overwrites them in place (omics_one.py:97)."""
-    ids = input_ids_flat.astype(np.int64).copy()
-    keep = ~overwritten
-    rows = np.nonzero(keep)[0].astype(np.int32)
-    order = rows[np.argsort(ids[rows], kind="stable")]
-    sorted_ids = ids[order]
-    if len(order) == 0:
-        return order, np.zeros(1, np.int32), np.zeros(0, np.int64)
-    bounds = np.nonzero(np.diff(sorted_ids))[0] + 1
-    seg = np.concatenate([[0], bounds, [len(order)]]).astype(np.int32)
-    uid = sorted_ids[seg[:-1]]
-    return order, seg, uid
-
-
+# ---- batch assembly: molly_amd/batch.py (one host pass, one pinned H2D copy, the rest in molly_batch_assemble) ----------
 # ---- the model ---------------------------------------------------------------------------------------------------
 class OmicsOne(_MetaSafe):
     def __init__(self, config: OmicsModalConfig):
@@ -479,21 +411,36 @@ class OmicsOne(_MetaSafe):
             self.prepare_from_module_state()
         return self._rt
 
-    def _embed_and_inject(self, input_ids, omic_ids, omic_info_list, B, T, keep_for_backward, wait_embed=None,
-                          wait_proj=None):
-        """reference: src/model/omics_one.py:164-172 — token embeddings, then encoder -> projector -> overwrite.
+    def _stager(self):
+        rt = self._rt
+        if getattr(rt, "stager", None) is None:
+            from .batch import BatchStager
+            rt.stager = BatchStager(rt.dev, self.text_config.vocab_size,
+                                    {"dna_rna": self.dna_rna_config.vocab_size, "protein": self.protein_config.vocab_size})
+        return rt.stager
+
+    def _stage(self, input_ids, labels, attention_mask, omic_ids, omic_info_list, want_sort):
+        """One host pass + one pinned host->device copy + the device-side assembly (molly_amd/batch.py)."""
+        B, T = input_ids.shape
+        if input_ids.is_cuda:                 # HF-Trainer-style callers move the batch first; the host pass needs it back
+            input_ids = input_ids.cpu()
+        return self._stager().stage(B, T, input_ids, labels, attention_mask, omic_ids, omic_info_list,
+                                    {"dna_rna": self.dna_rna_project_token_num, "protein": self.protein_project_token_num},
+                                    want_sort=want_sort)
+
+    def _embed_and_inject(self, st, keep_for_backward, wait_embed=None, wait_proj=None):
+        """reference: src/model/omics_one.py:164-172 — token embeddings, then encoder -> projector -> overwrite.  `st` is the
+        staged batch (device-side ids, encoder ids, scatter indices).
         Launch order: the FROZEN encoders run first — they read no trainable parameter, so their ≈8 ms cover the head of the
         previous step's side-stream AdamW / all-gather (embedding, gains, projectors), which `wait_embed` / `wait_proj` then
         find finished; the values written are those of the reference's order (lookup, then overwrite)."""
         rt = self._rt
-        h = self.text_config.hidden_size
+        B, T = st.B, st.T
         M = B * T
         if not keep_for_backward and getattr(rt, "opt", None) is not None:
             rt.opt.wait_all_params()              # inference entry points: every parameter must have been published
         rt.llm.reserve(M, B, T, training=keep_for_backward)
         hs = rt.llm.A[0]["x"] if keep_for_backward else rt.llm.x_out
-        ids_dev = input_ids.reshape(-1).to(rt.dev, non_blocking=True)
-        overwritten = np.zeros(M, dtype=bool)
         saved = {}
         encoded = []
         if rt.train_bio or os.environ.get("MOLLY_ENC_FIRST", "1") == "0":   # trained encoders read parameters the optimizer is publishing
@@ -501,54 +448,32 @@ class OmicsOne(_MetaSafe):
                 if w is not None:
                     w()
             wait_embed = wait_proj = None
-        if omic_ids is not None:
-            for i in range(len(omic_ids)):
-                assert len(omic_ids[i]) == len(omic_info_list[i]), \
-                    f"Mismatch in DNA count vs start_pos count at index {i}"
-            groups = group_omics(omic_ids, omic_info_list,
-                                 {"dna_rna": self.dna_rna_project_token_num, "protein": self.protein_project_token_num}, T)
-            for name, eng, proj in (("dna_rna", rt.dna, "dna_rna_projector"), ("protein", rt.prot, "protein_projector")):
-                if groups[name] is None:
-                    continue
-                ids, dst = groups[name]
-                assert bool((ids < eng.cfg.vocab_size).all()), \
-                    f"out-of-range token: {ids[ids >= eng.cfg.vocab_size]}"
-                check_trailing_pad(ids, 1)
-                try:
-                    enc_out = eng.forward(ids.to(rt.dev, non_blocking=True), training=keep_for_backward and rt.train_bio)
-                except Exception as e:  # reference re-wraps encoder failures (omics_one.py:89-90)
-                    raise RuntimeError(f"Error processing omic sequences: {e}")
-                encoded.append((name, eng, proj, enc_out, dst))
+        for name, eng, proj in (("dna_rna", rt.dna, "dna_rna_projector"), ("protein", rt.prot, "protein_projector")):
+            if name not in st.groups:
+                continue
+            ids64, dst, N, K = st.groups[name]
+            try:
+                enc_out = eng.forward(ids64, training=keep_for_backward and rt.train_bio)
+            except Exception as e:  # reference re-wraps encoder failures (omics_one.py:89-90)
+                raise RuntimeError(f"Error processing omic sequences: {e}")
+            encoded.append((name, eng, proj, enc_out, dst))
         if wait_embed is not None:
             wait_embed()
-        ops.copy_rows(rt.llm.embed, hs, M, src_idx64=ids_dev)
+        ops.copy_rows(rt.llm.embed, hs, M, src_idx32=st.ids32)
         if wait_proj is not None:
             wait_proj()
         for name, eng, proj, enc_out, dst in encoded:
             emb = ops.gemm_nt(enc_out, rt.W[proj + ".weight"], bias=rt.W[proj + ".bias"])
-            dst_dev = dst.to(rt.dev, non_blocking=True)
-            ops.copy_rows(emb, hs, emb.shape[0], dst_idx32=dst_dev)
-            valid = dst.numpy() >= 0
-            overwritten[dst.numpy()[valid]] = True
-            saved[name] = (enc_out, dst_dev, proj, eng)
-        return hs, overwritten, saved
+            ops.copy_rows(emb, hs, emb.shape[0], dst_idx32=dst)
+            saved[name] = (enc_out, dst, proj, eng)
+        return hs, saved
 
     @staticmethod
     def _kv_range(attention_mask, B, T, dev):
-        """attention_mask [B,T] of 0/1 with contiguous ones (right- or left-padded) -> per-sample [lo, hi)."""
-        if attention_mask is None:
-            return None, None
-        m = attention_mask.cpu().bool()
-        if bool(m.all()):
-            return None, None
-        idx = torch.arange(T)
-        lo = torch.where(m.any(1), (~m).long().cumprod(1).sum(1), torch.zeros(B, dtype=torch.long))
-        n = m.sum(1)
-        hi = lo + n
-        span = (idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None])
-        if not torch.equal(span, m):
-            raise NotImplementedError("attention_mask must be one contiguous run of ones per sample (right- or left-padded)")
-        return lo.to(torch.int32).to(dev), hi.to(torch.int32).to(dev)
+        """attention_mask [B,T] of 0/1 with contiguous ones (right- or left-padded) -> per-sample [lo, hi) on the device."""
+        from .batch import BatchStager
+        kv = BatchStager.kv_range(attention_mask, B, T)
+        return (None, None) if kv is None else (kv[0].to(dev), kv[1].to(dev))
 
     def attach_optimizer(self, opt):
         """Wire a Zero2Optimizer's overlap hooks into the engines (no-ops when the optimizer does not overlap)."""
@@ -579,28 +504,23 @@ class OmicsOne(_MetaSafe):
             # projectors — waited for inside _embed_and_inject, behind the frozen encoders' forward
             wait_embed = lambda: opt.wait_params(0, rt.llm.layer_lo[0])
             wait_proj = lambda: (opt.wait_params(self.n_decay, rt.P.numel), opt.wait_params(rt.llm.layers_hi, self.n_decay))
-        lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
-        hs, overwritten, saved = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, True, wait_embed,
-                                                        wait_proj)
-        # the embedding-gradient index (host-side sort) is built and uploaded NOW, while the stream is short: a pageable
-        # host-to-device copy makes the host wait for everything queued before it, which at backward time is the whole step
-        emb_idx = None
-        if rt.train_llm:
-            order, seg, uid = embed_backward_index(input_ids.reshape(-1).cpu().numpy(), overwritten)
-            if len(uid):
-                emb_idx = (torch.from_numpy(order).to(rt.dev), torch.from_numpy(seg).to(rt.dev),
-                           torch.from_numpy(uid).to(rt.dev), len(uid))
-        shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
-        scored = torch.nonzero(shifted != -100).reshape(-1).to(torch.int32)       # host-side: no device sync
-        shifted = shifted.to(rt.dev, non_blocking=True)
-        rt.llm.forward(hs, B, T, lo, hi, labels_shifted=shifted, training=True,
-                       scored_rows=scored.to(rt.dev, non_blocking=True))
+        # everything the step needs from the batch — ids, shifted labels, scored rows, encoder ids, scatter indices, key ranges
+        # and the sorted embedding-gradient index — through ONE pinned upload and the device-side assembly
+        st = self._stage(input_ids, labels, attention_mask, omic_ids, omic_info_list, want_sort=rt.train_llm)
+        hs, saved = self._embed_and_inject(st, True, wait_embed, wait_proj)
+        rt.llm.forward(hs, B, T, st.kv_lo, st.kv_hi, labels_shifted=st.labels_shifted, training=True,
+                       scored_rows=st.scored_rows)
         if opt is not None:
             opt.wait_all_params()
         d_hs = rt.llm.loss_and_backward(accumulate=accumulate, final_micro=final_micro)
         # ---- gradient of the input embeddings: text rows -> embed_tokens, omic rows -> projector
-        if emb_idx is not None:
-            ops.embed_bwd(d_hs, emb_idx[0], emb_idx[1], emb_idx[2], emb_idx[3], rt.llm.d_embed)
+        if rt.train_llm and not accumulate and not self.text_config.tie_word_embeddings:
+            # untied head (Qwen3-8B): nothing else writes the embedding's gradient, and embed_bwd ADDS to it — start from zero
+            # (tied: the head's weight gradient has just overwritten the shared tensor)
+            rt.llm.d_embed.zero_()
+        if st.emb_index is not None and st.n_overwritten < M:
+            order, seg, uid, n_unique_dev, bound = st.emb_index
+            ops.embed_bwd(d_hs, order, seg, uid, bound, rt.llm.d_embed, n_unique_dev=n_unique_dev)
         for name, (enc_out, dst_dev, proj, eng) in saved.items():
             if not (rt.train_mlp or rt.train_bio):
                 break
@@ -633,21 +553,19 @@ class OmicsOne(_MetaSafe):
         """reference: src/model/omics_one.py:49-136 — in-place overwrite of `hidden_states` [B,T,h]; returns it."""
         rt = self._runtime()
         B, T, h = hidden_states.shape
-        groups = group_omics(omic_ids_list, omic_info_list,
-                             {"dna_rna": self.dna_rna_project_token_num, "protein": self.protein_project_token_num}, T)
+        st = self._stager().stage(B, T, None, None, None, omic_ids_list, omic_info_list,
+                                  {"dna_rna": self.dna_rna_project_token_num, "protein": self.protein_project_token_num})
         flat = hidden_states.view(B * T, h)
         for name, eng, proj in (("dna_rna", rt.dna, "dna_rna_projector"), ("protein", rt.prot, "protein_projector")):
-            if groups[name] is None:
+            if name not in st.groups:
                 continue
-            ids, dst = groups[name]
-            assert bool((ids < eng.cfg.vocab_size).all()), f"out-of-range token: {ids[ids >= eng.cfg.vocab_size]}"
-            check_trailing_pad(ids, 1)
+            ids64, dst, N, K = st.groups[name]
             try:
-                enc_out = eng.forward(ids.to(rt.dev))
+                enc_out = eng.forward(ids64)
             except Exception as e:
                 raise RuntimeError(f"Error processing omic sequences: {e}")
             emb = ops.gemm_nt(enc_out, rt.W[proj + ".weight"], bias=rt.W[proj + ".bias"])
-            ops.copy_rows(emb, flat, emb.shape[0], dst_idx32=dst.to(rt.dev))
+            ops.copy_rows(emb, flat, emb.shape[0], dst_idx32=dst)
         return hidden_states
 
     def forward(self, input_ids=None, attention_mask=None, omic_ids=None, omic_info_list=None, labels=None,
@@ -664,12 +582,10 @@ class OmicsOne(_MetaSafe):
         if labels is not None and torch.is_grad_enabled() and rt.G is not None:
             loss = self.forward_backward(input_ids, attention_mask, omic_ids, omic_info_list, labels)
             return CausalLMOutputWithPast(loss=_attach_grads(self, loss))
-        lo, hi = self._kv_range(attention_mask, B, T, rt.dev)
-        hs, _, _ = self._embed_and_inject(input_ids, omic_ids, omic_info_list, B, T, False)
-        shifted = None
-        if labels is not None:
-            shifted = torch.nn.functional.pad(labels.cpu(), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous().to(rt.dev)
-        loss, logits = rt.llm.forward(hs, B, T, lo, hi, labels_shifted=shifted, training=False, return_logits=True)
+        st = self._stage(input_ids, labels, attention_mask, omic_ids, omic_info_list, want_sort=False)
+        hs, _ = self._embed_and_inject(st, False)
+        loss, logits = rt.llm.forward(hs, B, T, st.kv_lo, st.kv_hi, labels_shifted=st.labels_shifted, training=False,
+                                      return_logits=True)
         return CausalLMOutputWithPast(loss=loss.clone() if loss is not None else None,
                                       logits=logits.view(B, T, -1))
 

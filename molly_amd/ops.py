@@ -293,6 +293,29 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
+def sample_logits(logits, generated, repetition_penalty, temperature, top_k, top_p, seed, step, out=None, debug_cap=0):
+    """HF's sampling processors + one draw per row on the device (molly_sample_logits).  logits fp32 [rows, V] (modified in
+    place by the repetition penalty); generated int64 [rows, n] or None.  -> next tokens int64 [rows]
+    (+ (probs, ids, n_kept) of the surviving tokens when debug_cap > 0)."""
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    rows, V = logits.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    n_gen = 0 if generated is None else generated.shape[1]
+    if n_gen:
+        assert generated.dtype == torch.int64 and generated.stride(1) == 1
+    dbg = None
+    if debug_cap:
+        dbg = (torch.zeros(rows, debug_cap, dtype=torch.float32, device=logits.device),
+               torch.full((rows, debug_cap), -1, dtype=torch.int64, device=logits.device),
+               torch.zeros(rows, dtype=torch.int32, device=logits.device))
+    lib().call("molly_sample_logits", _stream(), logits, rows, V, logits.stride(0), generated if n_gen else None, n_gen,
+               generated.stride(0) if n_gen else 0, float(repetition_penalty or 1.0), float(temperature or 1.0), int(top_k),
+               float(top_p if top_p is not None else 1.0), int(seed) & ((1 << 64) - 1), int(step), out,
+               dbg[0] if dbg else None, dbg[1] if dbg else None, dbg[2] if dbg else None, debug_cap)
+    return (out, dbg) if debug_cap else out
+
+
 def count_valid(labels, scale_out, count_out, ignore_index=-100):
     lib().call("molly_count_valid", _stream(), labels, labels.numel(), ignore_index, scale_out, count_out)
 
@@ -309,9 +332,11 @@ def esm_embed(ids, word_emb, pos_emb, out, pos_ids, kv_len, pad_id, mask_id, tok
     return out
 
 
-def embed_bwd(g, order, seg_start, uid, n_unique, dE, row_scale=None):
-    """dE[uid[u]] += sum over k in [seg_start[u], seg_start[u+1]) of row_scale[order[k]] * g[order[k]]."""
-    lib().call("molly_embed_bwd", _stream(), g, order, seg_start, uid, n_unique, dE, dE.shape[1], g.stride(0), row_scale)
+def embed_bwd(g, order, seg_start, uid, n_unique, dE, row_scale=None, n_unique_dev=None):
+    """dE[uid[u]] += sum over k in [seg_start[u], seg_start[u+1]) of row_scale[order[k]] * g[order[k]].
+    n_unique_dev: device int holding the true segment count (n_unique is then the launch bound)."""
+    lib().call("molly_embed_bwd", _stream(), g, order, seg_start, uid, n_unique, dE, dE.shape[1], g.stride(0), row_scale,
+               n_unique_dev)
 
 
 def sqnorm(g, out, workspace, accumulate=False):

@@ -184,16 +184,20 @@ def test_config3_full_depth_molly4b_three_modalities():
     from molly_amd.synth import synth_batch
     m = _full("4b", 512, 512)
     spans = [("dna", 512), ("rna", 512), ("protein", 512)]
-    mb = [synth_batch(1, 3072, spans, seed=3), synth_batch(1, 3072, spans, seed=4, ragged=True)]
+    mb = [synth_batch(1, 3072, spans, seed=3), synth_batch(1, 3072, spans, seed=4)]
+    mb[1]["attention_mask"][0, 2900:] = 0                       # a right-padded sample (ragged=True could not fit 3 x 514 tokens)
+    mb[1]["labels"][0, 2900:] = -100
+    mb[1]["input_ids"][0, 2900:] = 151643
     _properties(m, mb)
     # the three spans landed where the batch says: the injected rows are the projector's outputs, every other row the lookup
     rt = m._rt
     b = mb[0]
     ids = b["input_ids"].reshape(-1).cuda()
-    hs, overwritten, _ = m._embed_and_inject(b["input_ids"], b["omic_ids"], b["omic_info_list"], 1, 3072, False)
+    st = m._stage(b["input_ids"], None, None, b["omic_ids"], b["omic_info_list"], want_sort=False)
+    hs, _ = m._embed_and_inject(st, False)
     torch.cuda.synchronize()
     emb = rt.llm.embed[ids]
-    ow = torch.from_numpy(overwritten).cuda()
+    ow = st.overwritten.bool()
     assert int(ow.sum()) == 3 * 512
     assert torch.equal(hs[~ow], emb[~ow]) and not torch.equal(hs[ow], emb[ow])
     for info in b["omic_info_list"][0]:

@@ -143,3 +143,58 @@ def test_greedy_decode_follows_the_reference_generate_golden(tiny_meta):
             if margins[t, b] <= 0.05:
                 break
             assert out[b, t] == ref[b, t], (b, t)
+
+
+def test_sampling_kernel_matches_hf_logits_processors():
+    """csrc/sampling.hip against HuggingFace's own processor classes (the third-party home of this arithmetic,
+    HF:generation/logits_process.py) at the reference's inference settings (src/inference_lora.py:293-298: repetition penalty 1.1,
+    temperature 0.8, top_k 20, top_p 0.95) on the real vocabulary: same surviving tokens, same probabilities, and the Philox
+    draws follow that distribution."""
+    from molly_amd import ops
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopKLogitsWarper, TopPLogitsWarper)
+    rows, V = 6, 151936
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(rows, V, generator=g) * 3.0
+    logits[1] *= 4.0                                              # a peaked row: top-p cuts deep into the top-k set
+    logits[2, :] = torch.randn(V, generator=g) * 0.01             # a flat row: all 20 survive
+    gen = torch.randint(0, V, (rows, 37), generator=g)
+    gen[:, 5] = gen[:, 4]                                         # duplicates are penalised once
+    top = logits.topk(3, dim=1).indices
+    gen[:, 0] = top[:, 0]                                         # the current best token has been generated before
+    gen[3, 1] = top[3, 1]
+    scores = logits.clone()
+    for proc in (RepetitionPenaltyLogitsProcessor(1.1), TemperatureLogitsWarper(0.8), TopKLogitsWarper(20), TopPLogitsWarper(0.95)):
+        scores = proc(gen, scores)
+    want = scores.softmax(-1)
+    dev_logits = logits.cuda()
+    nxt, (probs, ids, n_kept) = ops.sample_logits(dev_logits.clone(), gen.cuda(), 1.1, 0.8, 20, 0.95, seed=1234, step=0, debug_cap=32)
+    torch.cuda.synchronize()
+    for r in range(rows):
+        keep = torch.nonzero(want[r] > 0).reshape(-1)
+        n = int(n_kept[r])
+        assert n == len(keep), (r, n, len(keep))
+        got_ids = ids[r, :n].cpu()
+        assert sorted(got_ids.tolist()) == sorted(keep.tolist())
+        assert torch.allclose(probs[r, :n].cpu(), want[r, got_ids], rtol=1e-4, atol=1e-6), r
+        assert bool((probs[r, :n - 1] >= probs[r, 1:n]).all())   # descending
+        assert int(nxt[r]) in keep.tolist()
+    assert int(n_kept[1]) < int(n_kept[2]) == 20
+    # the draws: 3000 steps on the same scores -> empirical frequencies within 4 sigma of the probabilities
+    counts = torch.zeros(rows, V, dtype=torch.int32)
+    outs = []
+    for step in range(3000):
+        outs.append(ops.sample_logits(dev_logits.clone(), gen.cuda(), 1.1, 0.8, 20, 0.95, seed=99, step=step))
+    torch.cuda.synchronize()
+    outs = torch.stack(outs, 1).cpu()
+    for r in range(rows):
+        c = torch.bincount(outs[r], minlength=V).float()
+        assert bool((c[want[r] == 0] == 0).all())                # never a removed token
+        p = want[r]
+        sigma = (3000 * p * (1 - p)).sqrt()
+        sel = p > 0
+        assert bool(((c[sel] - 3000 * p[sel]).abs() <= 4 * sigma[sel] + 2).all()), r
+    # same (seed, step) -> same token; another seed -> another stream
+    a = ops.sample_logits(dev_logits.clone(), gen.cuda(), 1.1, 0.8, 20, 0.95, seed=7, step=5)
+    b = ops.sample_logits(dev_logits.clone(), gen.cuda(), 1.1, 0.8, 20, 0.95, seed=7, step=5)
+    assert torch.equal(a, b)
