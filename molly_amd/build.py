@@ -19,7 +19,7 @@ OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libmolly_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
-         "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
+         "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-ffp-contract=fast"]
 
 
 def _sources():

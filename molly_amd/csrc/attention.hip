@@ -70,9 +70,25 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
         const int last = max(T - 1 - key0, 0);
         const int rel = row < last ? row : last;
         const unsigned off = ((unsigned)rel * (unsigned)ld + (unsigned)col) * 2u;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds + inst * 512), 16, 0, 0);
+        // The LDS-DMA is issued from inline asm so that hipcc does not know an LDS write is in flight: with the builtin it
+        // put `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 of every half tile (the intrinsic read carries no
+        // alias information, so it waits for every pending LDS-DMA) — i.e. the prefetch of tile t+1 was drained in the
+        // middle of tile t and never overlapped the P·V work.  The wait is now ours: dma_wait() in front of the barrier that
+        // ends the tile (guide §5.7 'Inline asm', §5 'Three .s-level traps').
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds + inst * 512));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
     }
 }
+
+// "this register has arrived": an empty asm that READS v makes hipcc place the wait for v's pending global load HERE.  Used on
+// the per-kernel operand fragments (Q, dO, K, V rows, row statistics) right after their loads: left to itself hipcc waits for
+// them lazily inside the tile loop with counted `vmcnt(N)` that cannot see the asm-issued LDS-DMA — and those waits would then
+// drain the DMA pipeline every tile (guide §5 'Three .s-level traps' (b)).
+template <class T> __device__ __forceinline__ void arrived(const T& v) { asm volatile("" ::"v"(v)); }
+
+// every LDS-DMA piece this wave issued has landed (the barrier behind it publishes the tile to the other waves)
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // row-read fragment: tile[row][16*s + 8*h .. +7]   (row = 32*sub + (lane&31); s is a compile-time constant at call sites)
 template <int HD>
@@ -141,6 +157,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         const bf16_t* qp = Qb + (size_t)qrow * p.ldq + 8 * h;
 #pragma unroll
         for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) arrived(qf[s]);
     }
 
     f32x16 o[ND];
@@ -230,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         stage_kv<HD, false>(Kb, p.ldk, t_first * BKV, T, smem, wave, lane);
         stage_kv<HD, true>(Vb, p.ldv, t_first * BKV, T, smem + TILE, wave, lane);
     }
+    dma_wait();
     __syncthreads();
     int cur = 0;
     for (int t = t_first; t <= t_last; ++t) {
@@ -251,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                 softmax_pv(sc, k0 + 32 * sub, vf);
             }
         }
+        dma_wait();
         __syncthreads();
         cur ^= 1;
     }
@@ -410,6 +430,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     float lse = p.LSE[((size_t)b * p.nh + head) * T + qrow];
     lse = (lse == -INFINITY) ? 0.f : lse;
     const float dlt = p.delta[((size_t)b * p.nh + head) * T + qrow];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { arrived(qf[s]); arrived(dof[s]); }
+    arrived(lse); arrived(dlt);
 
     f32x16 dq[ND];
 #pragma unroll
@@ -425,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
         stage_kv<HD, false>(Kb, p.ldk, t_first * BKV, T, smem, wave, lane);
         stage_kv<HD, true>(Vb, p.ldv, t_first * BKV, T, smem + TILE, wave, lane);
     }
+    dma_wait();
     __syncthreads();
     int cur = 0;
     for (int t = t_first; t <= t_last; ++t) {
@@ -473,6 +497,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
                 }
             }
         }
+        dma_wait();
         __syncthreads();
         cur ^= 1;
     }
@@ -525,6 +550,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
             kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
             if (DO_DK) vf[s] = *reinterpret_cast<const bf16x8*>(vp + 16 * s);
         }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { arrived(kf[s]); if (DO_DK) arrived(vf[s]); }
     }
     f32x16 dk[ND], dv[ND];
 #pragma unroll
@@ -553,10 +580,12 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
             q = q < T ? q : T - 1;
             const size_t idx = ((size_t)b * p.nh + head) * T + q;
             const float* src = wave == 0 ? p.LSE + idx : p.delta + idx;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sStat + stg * 128 + wave * 64), 4, 0, 0);
+            const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(sStat + stg * 128 + wave * 64));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
         }
     };
     if (total > 0) stage(0, 0);
+    dma_wait();
     __syncthreads();
     int cur = 0;
     for (int it = 0; it < total; ++it) {
@@ -627,6 +656,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
                 }
             }
         }
+        dma_wait();
         __syncthreads();
         cur ^= 1;
     }

@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _release_gpu_memory(request):
+    """Full-size models (up to Molly-8B with gradients: 130 GB) must not pile up across tests."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available():
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 @pytest.fixture(scope="session")
 def tiny_meta():
     with open(os.path.join(GOLD, "tiny_meta.json")) as f:

@@ -123,7 +123,8 @@ def _full(size, k_dna, k_prot):
 
 
 def _properties(m, micro_batches, lnv_lo=10.0, lnv_hi=13.5):
-    """determinism; accumulation over the micro-batches == sum of their separate gradients; train loss == eval loss."""
+    """determinism; accumulation over the micro-batches == sum of their separate gradients; train loss == eval loss.
+    (Gradient copies stay bf16 and the comparison runs in slices: at 8.2 G parameters three fp32 copies would not fit.)"""
     rt = m._rt
     args = [[b[k] for k in KEYS] for b in micro_batches]
     singles, losses = [], []
@@ -132,21 +133,29 @@ def _properties(m, micro_batches, lnv_lo=10.0, lnv_hi=13.5):
         g1 = rt.G.flat.clone()
         l2 = m.forward_backward(*a).clone()
         assert torch.equal(l1, l2) and torch.equal(g1, rt.G.flat)               # no atomics, fixed reduction orders
-        assert torch.isfinite(g1.float()).all() and lnv_lo < l1.item() < lnv_hi, l1.item()   # ~ln(V) at random init
+        assert lnv_lo < l1.item() < lnv_hi, l1.item()                           # ~ln(V) at random init
         with torch.no_grad():
             ev = m(*a).loss
         assert abs(ev.item() - l1.item()) <= 2e-3, (ev.item(), l1.item())       # inference path == training path
-        singles.append(g1.float())
+        singles.append(g1)
         losses.append(l1.item())
     if len(args) > 1:
         m.forward_backward(*args[0], final_micro=False)
         for i, a in enumerate(args[1:]):
             m.forward_backward(*a, accumulate=True, final_micro=i == len(args) - 2)
         torch.cuda.synchronize()
-        want = sum(singles)
-        d = (rt.G.flat.float() - want).abs()
-        bound = 2 ** -6 * want.abs() + 2 ** -7 * sum(s.abs() for s in singles) + 2 ** -8 * want.abs().max()
-        assert (d <= bound).all(), (d / bound).max().item()
+        n, step = rt.G.flat.numel(), 1 << 28
+        gmax = max(float(s.abs().max()) for s in singles)
+        worst = 0.0
+        for o in range(0, n, step):
+            parts = [s[o:o + step].float() for s in singles]
+            assert all(bool(torch.isfinite(p_).all()) for p_ in parts)
+            want = sum(parts)
+            d = (rt.G.flat[o:o + step].float() - want).abs()
+            bound = 2 ** -6 * want.abs() + 2 ** -7 * sum(p_.abs() for p_ in parts) + 2 ** -8 * gmax
+            worst = max(worst, float((d / bound).max()))
+            del parts, want, d, bound
+        assert worst <= 1.0, worst
     return losses
 
 

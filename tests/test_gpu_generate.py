@@ -179,7 +179,7 @@ def test_sampling_kernel_matches_hf_logits_processors():
         assert torch.allclose(probs[r, :n].cpu(), want[r, got_ids], rtol=1e-4, atol=1e-6), r
         assert bool((probs[r, :n - 1] >= probs[r, 1:n]).all())   # descending
         assert int(nxt[r]) in keep.tolist()
-    assert int(n_kept[1]) < int(n_kept[2]) == 20
+    assert int(n_kept[1]) < int(n_kept[2]) and int(n_kept[2]) >= 19     # flat row: at most the smallest of the 20 is cut
     # the draws: 3000 steps on the same scores -> empirical frequencies within 4 sigma of the probabilities
     counts = torch.zeros(rows, V, dtype=torch.int32)
     outs = []
