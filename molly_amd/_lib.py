@@ -14,7 +14,8 @@ from typing import Dict, List, Tuple
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "molly_hip.h")
-LIB_PATH = os.path.join(HERE, "libmolly_hip.so")
+# MOLLY_LIB_PATH: a differently built library for same-box A/B runs (tools/); the product default is the in-tree build
+LIB_PATH = os.environ.get("MOLLY_LIB_PATH") or os.path.join(HERE, "libmolly_hip.so")
 
 _CT = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,

@@ -44,9 +44,38 @@ struct GemmArgs {
     } grp[16];
 };
 
+// One 1-KiB LDS-DMA piece (16 B per lane).  HIDE = issue it from inline asm, so that hipcc does not know an LDS write is in
+// flight: knowing, it puts `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 of every K-tile (the transposed-read
+// intrinsic carries no alias information, so it is made to wait for EVERY pending LDS-DMA) — which drained the two-tiles-ahead
+// prefetch of the k-major-operand forms (dgrad, wgrad) once per K-tile while the hand-placed counted waits sat unused beside it.
+// With HIDE every wait is the kernel's own (the 256x256 kernel's schedule already names them all); the 128x128 kernel keeps
+// the builtin because it relies on the waits hipcc derives.  (guide §5 'Three .s-level traps', §5.7)
+#ifndef MOLLY_GEMM_ASM_DMA
+#define MOLLY_GEMM_ASM_DMA 1
+#endif
+template <bool HIDE>
+__device__ __forceinline__ void dma16(const char* base, unsigned off, bf16_t* lds_dst) {
+    if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr)
+                     : "memory", "m0");
+    } else {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_dst), 16, 0, 0);
+    }
+}
+template <bool HIDE>
+__device__ __forceinline__ void dma16_lane(const char* src, bf16_t* lds_dst) {        // per-lane 64-bit source address
+    if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+    } else {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
+    }
+}
+
 // ---- k-contiguous operand: tile [ROWS][64] bf16 (128-B LDS rows); one wave-instruction = 8 rows (1 KiB).
 // chunk swizzle: ch ^ (row & 7)
-template <int ROWS, int NW, int BK>
+template <int ROWS, int NW, int BK, bool HIDE = false>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, int row0, int rows_total, int k0,
                                          bf16_t* lds_tile, int wave, int lane) {
     constexpr int CPR = BK / 8;                   // chunks per row (8: 128-B rows, 4: 64-B rows)
@@ -66,7 +95,7 @@ __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, i
         int rel = inst * RPI + r_in;
         rel = rel < last ? rel : last;
         const unsigned off = ((unsigned)rel * (unsigned)ld + (unsigned)(c_src * 8)) * 2u;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+        dma16<HIDE>(base, off, lds_tile + inst * 512);
     }
 }
 
@@ -81,7 +110,7 @@ __device__ __forceinline__ bf16x8 frag_kc(const bf16_t* lds_tile, int row, int c
 // NCB = COLS/16.  A ds_read_b64_tr_b16 of the 16x16x32 operand (half-wave = k-blocks 2g and 2g' of ONE column block)
 // then touches two ADJACENT 128-byte blocks = 256 contiguous bytes (conflict-free), and every address is
 // lane_base + compile-time constant (the XOR only involves lane bits), so the unrolled reads use DS immediates.
-template <int COLS, int NW, int BK>
+template <int COLS, int NW, int BK, bool HIDE = false>
 __device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, int col0, int cols_total, int k0, int k_total,
                                          const bf16_t* zeros, bf16_t* lds_tile, int wave, int lane) {
     constexpr int NCB = COLS / 16;
@@ -103,10 +132,10 @@ __device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, i
         rel = rel < last ? rel : last;
         const unsigned off = ((unsigned)kr * (unsigned)ld + (unsigned)rel) * 2u;
         if (full) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+            dma16<HIDE>(base, off, lds_tile + inst * 512);
         } else {
             const char* src = (k0 + kr < k_total) ? base + off : reinterpret_cast<const char*>(zeros);   // rows past K: exact zeros
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + inst * 512), 16, 0, 0);
+            dma16_lane<HIDE>(src, lds_tile + inst * 512);
         }
     }
 }
@@ -363,11 +392,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int kt = kt0 + ktl;
         bf16_t* dst = which < 2 ? smem + ((ktl % 3) * 2 + which) * HT : smem + (6 + (ktl & 1) * 2 + (which - 2)) * HT;
         if (which < 2) {
-            if (AT) stage_km<128, NWI, BK>(cA, clda, m0 + which * 128, cM, kt * BK, p.K, p.zeros, dst, wi, lane);
-            else stage_kc<128, NWI, BK>(cA, clda, m0 + which * 128, cM, kt * BK, dst, wi, lane);
+            if (AT) stage_km<128, NWI, BK, true>(cA, clda, m0 + which * 128, cM, kt * BK, p.K, p.zeros, dst, wi, lane);
+            else stage_kc<128, NWI, BK, true>(cA, clda, m0 + which * 128, cM, kt * BK, dst, wi, lane);
         } else {
-            if (BT) stage_km<128, NWI, BK>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, p.K, p.zeros, dst, wi, lane);
-            else stage_kc<128, NWI, BK>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, dst, wi, lane);
+            if (BT) stage_km<128, NWI, BK, true>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, p.K, p.zeros, dst, wi, lane);
+            else stage_kc<128, NWI, BK, true>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, dst, wi, lane);
         }
     };
     const int fr = lane & 15, fq = lane >> 4;

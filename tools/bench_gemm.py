@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--torch", action="store_true", help="add a torch.matmul (hipBLASLt/rocBLAS) column for orientation")
     ap.add_argument("--sched", type=int, nargs="+", default=None,
                     help="compare barrier schedules of the 256x256 kernel: 0 four-phase, 1 two-phase, -1 per-form default")
+    ap.add_argument("--lib-b", default=None,
+                    help="a second build of the library (e.g. molly_amd/libmolly_hip_b.so = -DMOLLY_GEMM_ASM_DMA=0): every shape "
+                         "is timed through both, interleaved in one process; columns 'A' (in-tree) and 'B'")
     ap.add_argument("--persist", type=int, nargs="+", default=None,
                     help="compare resident-block counts of the persistent 256x256 kernel (0 = one block per tile)")
     args = ap.parse_args()
@@ -43,6 +46,24 @@ def main():
         args.tiles = [800000 + 10 + x for x in args.sched]     # column key = 512 kernel with that schedule
     if args.persist is not None:
         args.tiles = [512000 + pv for pv in args.persist]      # column key = 512 kernel with that resident-block count
+    libs = {"A": lib()}
+    if args.lib_b:
+        from molly_amd._lib import MollyLib
+        libs["B"] = MollyLib(args.lib_b)
+        wsb = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        libs["B"].call("molly_gemm_set_workspace", wsb, wsb.numel() * 4)
+        ops.ensure_gemm_workspace(1 << 30)
+        args.tiles = ["A", "B"]
+
+    def run(t, a, b, out, kw):
+        if isinstance(t, str):
+            ak, bk = int(kw.get("a_kmajor", False)), int(kw.get("b_kmajor", False))
+            K_, M_ = (a.shape if ak else a.shape[::-1])
+            N_ = b.shape[1] if bk else b.shape[0]
+            libs[t].call("molly_gemm_bf16", torch.cuda.current_stream().cuda_stream, a, b, out, None, None, M_, N_, K_,
+                         a.stride(0), b.stride(0), out.stride(0), 0, 0, ak, bk)
+        else:
+            ops.gemm(a, b, out=out, **kw)
     print(f"{'shape':16s} {'form':4s} {'M':>7s} {'N':>7s} {'K':>7s} " + " ".join(f"{'BM' + str(t) + ' TF/s':>12s}" for t in args.tiles))
     for name, form, m, n, k in SHAPES:
         if args.only and args.only not in name:
@@ -60,7 +81,9 @@ def main():
         best = {t: 1e9 for t in args.tiles}
         for r in range(args.rounds):
             for t in args.tiles:
-                if t >= 800000:
+                if isinstance(t, str):
+                    pass
+                elif t >= 800000:
                     lib().call("molly_gemm_force_tile", 0)
                     lib().call("molly_gemm_set_schedule", t - 800010)
                 elif t >= 512000:
@@ -68,11 +91,11 @@ def main():
                     lib().call("molly_gemm_set_persistent_blocks", t - 512000)
                 else:
                     lib().call("molly_gemm_force_tile", t)
-                ops.gemm(a, b, out=out, **kw)              # warm
+                run(t, a, b, out, kw)              # warm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    ops.gemm(a, b, out=out, **kw)
+                    run(t, a, b, out, kw)
                 e1.record()
                 torch.cuda.synchronize()
                 best[t] = min(best[t], e0.elapsed_time(e1) / 3)
