@@ -219,6 +219,9 @@ def main(argv=None):
     ap.add_argument("--bucket-mib", type=float, default=0.0,
                     help="ZeRO bucket size in MiB of bf16 (one reduce-scatter / all-gather each; every xGMI link carries bucket/world "
                          "of it); 0 = the default of 32 MiB per link (256 MiB at 8 GPUs).  SURVEY §5 sweep: 64 ... 1024")
+    ap.add_argument("--rs-algo", choices=("rccl", "a2a"), default=None,
+                    help="gradient reduce-scatter: the library's collective (default) or all_to_all_single + a local fp32 reduction "
+                         "in rank order (SURVEY 5 option 2: every xGMI link carries one chunk at once, whatever RCCL would pick)")
     ap.add_argument("--exposed-comm-steps", type=int, default=4,
                     help="N>1: extra steps after the timed region with the exchange NOT overlapped, to report the exposed "
                          "communication time (0 = skip)")
@@ -291,7 +294,7 @@ def main(argv=None):
     if args.bucket_mib > 0:
         opt_kw["chunk_elems"] = max(8, int(args.bucket_mib * (1 << 20) / 2 / world) // 8 * 8)
     opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0,
-                         stage=args.zero_stage, **opt_kw)
+                         stage=args.zero_stage, rs_algo=args.rs_algo, **opt_kw)
     m.attach_optimizer(opt)
 
     B, T, K = args.batch, args.seq, args.k_protein
@@ -339,7 +342,7 @@ def main(argv=None):
         comm = {"backend": backend, "world_size": dist.get_world_size(), "preflight": comm_check,
                 "comm_bytes_per_step_per_gpu": opt.comm_bytes_per_step(), "bucket_mib": round(opt.bucket * 2 / (1 << 20), 1),
                 "per_link_mib_per_bucket": round(opt.chunk * 2 / (1 << 20), 1), "buckets": len(opt.buckets),
-                "overlap": bool(opt.overlap), "persistent_gemm": os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "0") == "1"}
+                "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo, "persistent_gemm": os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "0") == "1"}
         if backend == "nccl":
             try:
                 comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())

@@ -191,6 +191,9 @@ int molly_batch_assemble(void* stream, const int* ids32, const int* labels32, in
 /* optimizer shard step — torch.optim.AdamW (HF `adamw_torch`, reference src/trainer/omics_trainer.py:53-60) on an
  * fp32 master shard with bf16 grads; global-norm clip = torch.nn.utils.clip_grad_norm_ (reference
  * src/trainer/domain_loss.py:676-708; DeepSpeed gradient_clipping, src/configs/ds_z2_config.json:5). */
+/* local half of the all-to-all gradient reduce-scatter (SURVEY.md §5 option 2; replaces the reduction inside DeepSpeed's / NCCL's
+ * reduce-scatter, src/configs/ds_z2_config.json:23): out[i] = bf16(sum over r of in[r][i]) in fp32, r ascending. */
+int molly_reduce_rows_bf16(void* stream, const void* in, int rows, long n, void* out);
 int molly_sqnorm_blocks(void);
 int molly_sqnorm_bf16(void* stream, const void* g, long n, float* workspace, float* out, int accumulate);
 /* Overflow guard (DeepSpeed's ZeRO step skips the update when a gradient is inf/NaN): a non-finite norm makes the

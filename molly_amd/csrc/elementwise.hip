@@ -963,6 +963,25 @@ __global__ __launch_bounds__(256) void sqnorm_part_kernel(const bf16_t* __restri
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// out[i] = bf16( sum_r float(in[r][i]) ), r = 0 .. rows-1 in that fixed order: the local half of the all-to-all
+// reduce-scatter (Zero2Optimizer rs_algo="a2a"): every rank receives its chunk from every peer over that peer's own xGMI link
+// and sums the `world` copies in fp32 — one rounding, an order that does not depend on any collective algorithm.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const bf16_t* __restrict__ in, int rows, long n, bf16_t* __restrict__ out) {
+    const long nch = n >> 3;
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < rows; ++r) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(in + (size_t)r * n + c * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[2 * j] += bflo(v[j]); acc[2 * j + 1] += bfhi(v[j]); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack_bf2(acc[2 * j], acc[2 * j + 1]);
+        *reinterpret_cast<u32x4*>(out + c * 8) = o;
+    }
+}
+
 // norm_sq (device scalar, possibly all-reduced across ranks) -> total norm, clip coefficient
 // coef = min(1, max_norm / (norm + 1e-6)) * pre_scale       (torch.nn.utils.clip_grad_norm_)
 // A non-finite norm (an inf/NaN gradient somewhere) makes the coefficient NaN = "skip this step": adamw_kernel leaves the
@@ -1331,6 +1350,15 @@ extern "C" int molly_sqnorm_bf16(void* stream, const void* g, long n, float* wor
     MOLLY_LAUNCH_CHECK();
     hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, ST, workspace, (long)nb, (const float*)nullptr, out,
                        accumulate);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_reduce_rows_bf16(void* stream, const void* in, int rows, long n, void* out) {
+    MOLLY_CHECK(rows >= 1 && n >= 0 && n % 8 == 0, "reduce_rows: rows=%d, n=%ld must be a multiple of 8", rows, n);
+    MOLLY_CHECK(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "reduce_rows: buffers must be 16-byte aligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid_for(n / 8)), dim3(256), 0, ST, (const bf16_t*)in, rows, n, (bf16_t*)out);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

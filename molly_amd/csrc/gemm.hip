@@ -57,7 +57,7 @@ template <bool HIDE>
 __device__ __forceinline__ void dma16(const char* base, unsigned off, bf16_t* lds_dst) {
     if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr)
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr)
                      : "memory", "m0");
     } else {
         __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_dst), 16, 0, 0);
@@ -67,7 +67,7 @@ template <bool HIDE>
 __device__ __forceinline__ void dma16_lane(const char* src, bf16_t* lds_dst) {        // per-lane 64-bit source address
     if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
     } else {
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
     }
@@ -514,7 +514,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             kloop(std::integral_constant<bool, TO>{});
         }
     } else {
-    constexpr bool TOQ = TO;
+    auto kloop4 = [&](auto to_tag) {
+    constexpr bool TOQ = decltype(to_tag)::value;
     for (int T = 0; T < nk; ++T) {
         const int bbuf = T & 1;
         // ---- P0: quadrant (m0,n0)
@@ -552,6 +553,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         MMA_QUAD(1, 0, af, b0);
         SEG_BARRIER();
         abuf = abuf == 2 ? 0 : abuf + 1;
+    }
+    };
+    if constexpr (GRP) {               // grouped launch: the output orientation is a per-problem property
+        if (cto) kloop4(std::true_type{});
+        else kloop4(std::false_type{});
+    } else {
+        kloop4(std::integral_constant<bool, TO>{});
     }
     }
     if (wr == 0) SEG_BARRIER();               // balance the stagger barrier (every LDS read of this tile has returned)
@@ -720,6 +728,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 int g_group_m = 4;
 int g_schedule = -1;              // 256x256 kernel: -1 = per form, 0 = four phases per K-tile, 1 = two phases per K-tile
+// Per-form default.  Round 1 ran the k-major-B forms (dgrad, wgrad) on the two-phase schedule, measured +3-4 % — while hipcc
+// was draining the LDS-DMA pipeline in front of their transposed reads (dma16 above).  With the DMA issued from asm the
+// four-phase schedule wins on every form (same-box: gate|up dgrad 1387 vs 1320 TF/s, qkv dgrad 1296 vs 1279), so -1 now
+// means four phases everywhere; 1 still selects two.
+inline bool two_phase(bool /*b_kmajor*/) { return g_schedule == 1; }
 int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile
 int g_min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
 int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
@@ -790,7 +803,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
         const int grid = g_persist_blocks > 0 ? min(nwork, g_persist_blocks) : nwork;
         // two-phase schedule where it measured faster: a k-major B operand (dgrad, wgrad); -1 = this choice, 0 / 1 = forced
-        if (g_schedule == 1 || (g_schedule < 0 && BT)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
+        if (two_phase(BT)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
         else hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false>), dim3(grid), dim3(512), 163840, st, p);
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
@@ -925,11 +938,16 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, true, false, true, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, true, false, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr = true;
     }
     const int grid = g_persist_blocks > 0 ? min(work, g_persist_blocks) : work;
     g_last_cfg = 512 + 1000 + 100000 * count;
-    hipLaunchKernelGGL((gemm256_kernel<false, true, false, true, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
+    if (two_phase(true))
+        hipLaunchKernelGGL((gemm256_kernel<false, true, false, true, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((gemm256_kernel<false, true, false, false, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -339,6 +339,14 @@ def embed_bwd(g, order, seg_start, uid, n_unique, dE, row_scale=None, n_unique_d
                n_unique_dev)
 
 
+def reduce_rows(x2d, out):
+    """out[i] = bf16(sum_r x2d[r, i]) in fp32, fixed row order (the local reduction of the all-to-all reduce-scatter)."""
+    _chk(x2d, BF16, "x2d"); _chk(out, BF16, "out")
+    assert x2d.is_contiguous() and out.is_contiguous() and x2d.shape[1] == out.numel()
+    lib().call("molly_reduce_rows_bf16", _stream(), x2d, x2d.shape[0], x2d.shape[1], out)
+    return out
+
+
 def sqnorm(g, out, workspace, accumulate=False):
     lib().call("molly_sqnorm_bf16", _stream(), g, g.numel(), workspace, out, int(accumulate))
 

@@ -48,10 +48,19 @@ class _DistComm:
     `staged=True` goes through a scratch chunk instead (one extra copy per bucket) — selected by `preflight_collectives`
     if the in-place forms ever returned a wrong answer on the installed backend."""
 
-    def __init__(self, group=None, staged: bool = False):
+    def __init__(self, group=None, staged: bool = False, rs_algo: str = "rccl", reduce_rows=None):
+        """rs_algo: "rccl" = the library's reduce_scatter (ring or tree, its choice) | "a2a" = SURVEY.md §5 option 2:
+        `all_to_all_single` (rank r's chunk j travels straight to rank j: on the fully connected xGMI mesh all 7 links of every
+        GPU carry one chunk at once, whatever algorithm the library would have picked for a reduce-scatter) + a LOCAL fp32
+        reduction of the `world` received copies in rank order (reduce_rows: the HIP kernel, or a torch stand-in in the CPU
+        tests) — one rounding per element, an order no collective algorithm can change (SURVEY.md §7.3 'ZeRO-2 result parity')."""
+        assert rs_algo in ("rccl", "a2a")
         self.group = group
         self.staged = staged
+        self.rs_algo = rs_algo
+        self.reduce_rows = reduce_rows
         self._scratch = None
+        self._recv = None
 
     def _tmp(self, like):
         if self._scratch is None or self._scratch.numel() < like.numel() or self._scratch.dtype != like.dtype:
@@ -59,6 +68,14 @@ class _DistComm:
         return self._scratch[:like.numel()]
 
     def reduce_scatter(self, out_chunk, region):
+        if self.rs_algo == "a2a":
+            if self._recv is None or self._recv.numel() < region.numel() or self._recv.dtype != region.dtype:
+                self._recv = torch.empty(region.numel(), dtype=region.dtype, device=region.device)
+            recv = self._recv[:region.numel()]
+            dist.all_to_all_single(recv, region, group=self.group)           # equal splits: chunk j -> rank j
+            world = region.numel() // out_chunk.numel()
+            self.reduce_rows(recv.view(world, out_chunk.numel()), out_chunk)
+            return
         if self.staged:
             tmp = self._tmp(out_chunk)
             dist.reduce_scatter_tensor(tmp, region, group=self.group)
@@ -147,12 +164,15 @@ class _HipKernels:
     def adamw(self, master, m, v, grad, param_out, lr, b1, b2, eps, wd, step, gscale):
         self.ops.adamw_step(master, m, v, grad, param_out, lr, b1, b2, eps, wd, step, gscale, getattr(self, "skipped", None))
 
+    def reduce_rows(self, x2d, out):
+        self.ops.reduce_rows(x2d, out)
+
 
 class Zero2Optimizer:
     def __init__(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, n_decay: int, lr: float = 3e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, max_grad_norm: float = 1.0,
                  group=None, chunk_elems: int = 16 * 1024 * 1024, kernels=None, overlap: Optional[bool] = None,
-                 comm=None, stage: int = 2):
+                 comm=None, stage: int = 2, rs_algo: Optional[str] = None):
         assert stage in (0, 2), "stage: 2 = sharded optimizer state (ZeRO-2), 0 = replicated (plain DP all-reduce)"
         self.stage = stage
         self.P, self.G = flat_params, flat_grads
@@ -191,7 +211,10 @@ class Zero2Optimizer:
         self.k = kernels if kernels is not None else _HipKernels(dev)
         self.t = 0
         # ---- overlap machinery -------------------------------------------------------------------------------
-        self.comm = comm if comm is not None else _DistComm(group, staged=_STAGED_DEFAULT)
+        rs_algo = rs_algo or os.environ.get("MOLLY_RS_ALGO", "rccl")
+        self.comm = comm if comm is not None else _DistComm(group, staged=_STAGED_DEFAULT, rs_algo=rs_algo,
+                                                            reduce_rows=self.k.reduce_rows)
+        self.rs_algo = getattr(self.comm, "rs_algo", "rccl")
         self.overlap = (self.world > 1) if overlap is None else overlap
         self.overlap = self.overlap and flat_params.is_cuda
         self.P_out = flat_params                # AdamW writes here; the all-gather publishes into P (same buffer in production)

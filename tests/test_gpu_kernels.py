@@ -617,3 +617,16 @@ def test_argmax_matches_torch_first_maximum():
     wide = torch.randn(6, 4096, generator=g).to(DEV)
     view = wide[:, :1000]                              # row pitch != V
     assert torch.equal(ops.argmax(view), view.argmax(-1))
+
+
+def test_reduce_rows_is_the_fp32_sum_in_row_order():
+    """molly_reduce_rows_bf16 (local half of the all-to-all reduce-scatter): bit-exact against an fp32 accumulation in row order."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for rows, n in ((8, 1 << 20), (2, 4096), (5, 8)):
+        x = (torch.randn(rows, n, device=DEV, generator=g) * 3).to(BF)
+        out = torch.empty(n, dtype=BF, device=DEV)
+        ops.reduce_rows(x, out)
+        acc = torch.zeros(n, dtype=torch.float32, device=DEV)
+        for r in range(rows):
+            acc += x[r].float()
+        assert torch.equal(out, acc.to(BF))

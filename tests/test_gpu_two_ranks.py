@@ -27,14 +27,14 @@ def _args(b):
     return [b[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")]
 
 
-def _worker(rank, world, port, meta, ret, stage=2):
+def _worker(rank, world, port, meta, ret, stage=2, rs_algo=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from molly_amd.trainer import Zero2Optimizer
     m = _model(meta)
     opt = Zero2Optimizer(m._rt.P.flat, m._rt.G.flat, m.n_decay, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0,
-                         chunk_elems=1 << 18, stage=stage)                 # several buckets even on the tiny model
+                         chunk_elems=1 << 18, stage=stage, rs_algo=rs_algo)   # several buckets even on the tiny model
     assert opt.overlap and opt.world == 2 and len(opt.buckets) > 2
     m.attach_optimizer(opt)
     b = _batches(meta)[rank]
@@ -93,3 +93,17 @@ def test_two_ranks_zero0_fallback_equals_zero2(tiny_meta):
     a, b = res[0][0].float(), res[2][0].float()
     assert ((a - b).abs() <= 2 ** -6 * b.abs() + 1e-30).all()              # measured: 15 of 1.9 M differ, by <= 2 bf16 steps
     assert (a != b).float().mean().item() < 1e-4
+
+
+def test_two_ranks_all_to_all_reduce_scatter(tiny_meta):
+    """rs_algo="a2a" (SURVEY.md 5 option 2) on the real kernels: all_to_all_single + molly_reduce_rows_bf16 (fp32 sum of the
+    received copies in rank order), overlapped like the library reduce-scatter.  Two ranks: one rounding per sum either way, so
+    the parameters equal the library path bit for bit."""
+    mgr = mp.Manager()
+    res = {}
+    for algo, port in (("rccl", 29581), ("a2a", 29583)):
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, tiny_meta, ret, 2, algo), nprocs=2, join=True)
+        assert torch.equal(ret[0][0], ret[1][0]) and ret[0][1] == ret[1][1]
+        res[algo] = ret[0]
+    assert torch.equal(res["a2a"][0], res["rccl"][0]) and res["a2a"][1] == res["rccl"][1]

@@ -25,8 +25,11 @@ class TorchKernels:
         R.adamw_step(master, grad.float() * gscale[0], m, v, step, lr, wd, b1, b2, eps)
         param_out.copy_(master.to(param_out.dtype))
 
+    def reduce_rows(self, x2d, out):
+        out.copy_(x2d.float().sum(0).to(out.dtype))
 
-def _worker(rank, world, port, n, n_decay, chunk, ret, stage=2, staged=False):
+
+def _worker(rank, world, port, n, n_decay, chunk, ret, stage=2, staged=False, rs_algo=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from molly_amd.trainer.zero2 import Zero2Optimizer
@@ -37,7 +40,7 @@ def _worker(rank, world, port, n, n_decay, chunk, ret, stage=2, staged=False):
     G = grads[rank].clone()
     from molly_amd.trainer.zero2 import _DistComm
     opt = Zero2Optimizer(P, G, n_decay, lr=1e-2, max_grad_norm=1.0, chunk_elems=chunk, kernels=TorchKernels(), stage=stage,
-                         comm=_DistComm(staged=True) if staged else None)
+                         comm=_DistComm(staged=True) if staged else None, rs_algo=rs_algo)
     for _ in range(2):
         G.copy_(grads[rank])
         norm = opt.step()
@@ -135,4 +138,14 @@ def test_staged_collectives_equal_inplace():
     a, b = mgr.dict(), mgr.dict()
     mp.spawn(_worker, args=(2, 29573, 1024, 768, 64, a, 2, True), nprocs=2, join=True)
     mp.spawn(_worker, args=(2, 29575, 1024, 768, 64, b), nprocs=2, join=True)
+    assert torch.equal(a[0][0], a[1][0]) and torch.equal(a[0][0], b[0][0]) and a[0][1] == b[0][1]
+
+
+def test_all_to_all_reduce_scatter_equals_library_reduce_scatter():
+    """rs_algo="a2a" (SURVEY.md §5 option 2: all_to_all_single + local fp32 reduction in rank order): with two ranks a bf16 sum
+    has one rounding whatever the order, so parameters and norm match the library reduce-scatter bit for bit."""
+    mgr = mp.Manager()
+    a, b = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(2, 29577, 1024, 768, 64, a, 2, False, "a2a"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29579, 1024, 768, 64, b), nprocs=2, join=True)
     assert torch.equal(a[0][0], a[1][0]) and torch.equal(a[0][0], b[0][0]) and a[0][1] == b[0][1]
