@@ -37,8 +37,13 @@ enum {
     MOLLY_GEMM_RESIDUAL = 4,    /* + res[m,n] (bf16, ldres)                       */
     MOLLY_GEMM_ACCUMULATE = 8,  /* C += result (same dtype as C)                  */
     MOLLY_GEMM_OUT_F32 = 16,    /* C is fp32 instead of bf16                      */
-    MOLLY_GEMM_TRANS_OUT = 32   /* store C^T: the output buffer is [N][M] (ldc >= M); molly_gemm_bf16 with a_kmajor=0,
+    MOLLY_GEMM_TRANS_OUT = 32,  /* store C^T: the output buffer is [N][M] (ldc >= M); molly_gemm_bf16 with a_kmajor=0,
                                    b_kmajor=1 only — the wgrad form  dW[N',K'] = (x^T)[K',tok] dy[tok,N']  stored as dW */
+    MOLLY_GEMM_SWIGLU = 64      /* Qwen3MLP's gate|up projection with the activation fused (HF:models/qwen3/modeling_qwen3.py:
+                                   76-83, Liger swiglu in the reference: src/train.py:130-132): B = [gate_proj | up_proj] weights
+                                   ([2*ff][K]), C = [gate | up] [M][2*ff] as usual, and `res` is an OUTPUT: act[M][ff] (ldres)
+                                   = silu(gate) * up, bit-identical to molly_swiglu_fwd on C.  NT form, ff % 128 == 0, no
+                                   other flag. */
 };
 int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
                        int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags);
@@ -91,6 +96,10 @@ int molly_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float
 int molly_rmsnorm_bwd_blocks(int rows);
 int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres_or_null, void* dx,
                       void* dw, int dw_f32, int dw_accumulate, float* workspace, int rows, int H, float eps);
+/* Deferred gain gradients: molly_rmsnorm_bwd with dw == NULL and molly_norm_rope_bwd with dq_w == dk_w == NULL leave their
+ * per-block partials in the workspace; ONE launch then reduces many of them: items_dev = device array of n_items records
+ * {const float* part; void* out; int nb, H, row_stride, pad} (32 bytes), out_t[j] (+)= sum_b part_t[b * row_stride + j], j < H. */
+int molly_colsum_batched(void* stream, const void* items_dev, int n_items, int max_H, int out_f32, int accumulate);
 
 /* per-head RMSNorm (optional) + q pre-scale (optional) + rotary (optional) over the q|k heads of a fused
  * projection buffer.  Qwen3: q_norm/k_norm then RoPE — HF:models/qwen3/modeling_qwen3.py:252-257,148-170.

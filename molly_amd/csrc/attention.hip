@@ -74,15 +74,16 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
         // put `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16 of every half tile (the intrinsic read carries no
         // alias information, so it waits for every pending LDS-DMA) — i.e. the prefetch of tile t+1 was drained in the
         // middle of tile t and never overlapped the P·V work.  The wait is now ours: dma_wait() in front of the barrier that
-        // ends the tile (guide §5.7 'Inline asm', §5 'Three .s-level traps').  `s_nop 4` opens the string: hipcc pads hazards
-        // only between ITS instructions, and an SGPR operand may come fresh from a v_readfirstlane (VALU write of an SGPR ->
-        // VMEM read of it: 5 wait states; §5.7 item 2).
+        // ends the tile (guide §5.7 'Inline asm', §5 'Three .s-level traps').  hipcc pads hazards only between ITS instructions;
+        // the one that could bite here (an SGPR base fresh from a VALU write, 5 wait states: §5.7 item 2) is ruled out on the
+        // generated code by tools/check_asm_dma_hazards.py (tests/test_abi.py) instead of an `s_nop 4` per piece, which cost
+        // 2-6 % in the GEMM.
         // Tried on top and dropped (same-box A/B, round 2): interior tiles as ONE 64-key step (both S^T halves, one max / rescale
         // decision, 32 exponentials, 16 P.V MFMAs; 252 VGPRs): 682-612 vs 692-652 TF/s — no gain; the cross-half maximum through
         // v_permlane32_swap: hipcc folded max(r[0], r[1]) of the swap of a value with itself to r[0] (the LOWER half's maximum
         // for both halves: correct O, but -inf LSE for rows whose only live keys sit in the upper half) — ds_bpermute stays.
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds + inst * 512));
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
     }
 }
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
             const size_t idx = ((size_t)b * p.nh + head) * T + q;
             const float* src = wave == 0 ? p.LSE + idx : p.delta + idx;
             const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(sStat + stg * 128 + wave * 64));
-            asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
         }
     };
     if (total > 0) stage(0, 0);

@@ -527,6 +527,41 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict
     }
 }
 
+// Many column reductions in ONE launch: item t reduces part_t[nb_t][row_stride_t] (first H_t columns) into out_t.  The decoder
+// backward leaves the per-block partials of its 2L+1 RMSNorm gain gradients and 2L q/k-norm gain gradients in their own
+// workspaces and reduces them all here, once, at the end — instead of one 64-block colsum launch (12.8 us on an otherwise
+// full timeline) behind every norm backward.  Same summation tree per item as colsum_kernel: bit-identical results.
+struct ColsumItem { const float* part; void* out; int nb, H, row_stride, pad; };
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const ColsumItem* __restrict__ items, int out_f32, int accumulate) {
+    __shared__ float red[32][33];
+    const ColsumItem it = items[blockIdx.y];
+    if (blockIdx.x * 32 >= it.H) return;
+    const int cq = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const int j = blockIdx.x * 32 + cq * 4;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j < it.H)
+        for (int b = rg; b < it.nb; b += 32) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(it.part + (size_t)b * it.row_stride + j);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg][cq * 4 + e] = s[e];
+    __syncthreads();
+    const int c = threadIdx.x, jj = blockIdx.x * 32 + c;
+    if (c < 32 && jj < it.H) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += red[g][c];
+        if (out_f32) {
+            float* o = reinterpret_cast<float*>(it.out);
+            o[jj] = accumulate ? o[jj] + t : t;
+        } else {
+            bf16_t* o = reinterpret_cast<bf16_t*>(it.out);
+            o[jj] = f2bf(accumulate ? bf2f(o[jj]) + t : t);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Classifier-head losses of the Enc-Head baselines (reference: baselines/model.py:196-204): logits [rows][V] bf16 with
 // any V (row pitch ld >= V; columns V..ld-1 are padding and get zero gradient).  One wave per row.
@@ -1120,7 +1155,17 @@ extern "C" int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, con
     NC_DISPATCH(H, RMS_BWD);
 #undef RMS_BWD
     MOLLY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 32)), dim3(256), 0, ST, workspace, nb, H, H, dw, dw_f32, dw_accumulate);
+    if (dw) {            // dw == NULL: the partials stay in `workspace` for a later molly_colsum_batched
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(H, 32)), dim3(256), 0, ST, workspace, nb, H, H, dw, dw_f32, dw_accumulate);
+        MOLLY_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int molly_colsum_batched(void* stream, const void* items_dev, int n_items, int max_H, int out_f32, int accumulate) {
+    MOLLY_CHECK(items_dev && n_items >= 1 && n_items <= 65535 && max_H >= 1, "colsum_batched: %d items, max_H=%d", n_items, max_H);
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3(cdiv(max_H, 32), n_items), dim3(256), 0, ST, (const ColsumItem*)items_dev,
+                       out_f32, accumulate);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }
@@ -1160,8 +1205,8 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
                   cos, sin, positions, workspace, M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_g, ld_out, eps, ipb, q_scale};
     hipLaunchKernelGGL(norm_rope_bwd_kernel, dim3(nb), dim3(256), 4096 * sizeof(float), ST, p);
     MOLLY_LAUNCH_CHECK();
-    if (q_norm_w) {
-        MOLLY_CHECK(dq_w && dk_w, "norm_rope_bwd: gain gradients requested without output pointers");
+    if (q_norm_w && (dq_w || dk_w)) {    // both NULL: partials stay in `workspace` ([nb][2*head_dim]: q | k) for molly_colsum_batched
+        MOLLY_CHECK(dq_w && dk_w, "norm_rope_bwd: give both gain-gradient outputs or neither");
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 32)), dim3(256), 0, ST, workspace, nb, head_dim, 2 * head_dim,
                            dq_w, dw_f32, dw_accumulate);
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(head_dim, 32)), dim3(256), 0, ST, workspace + head_dim, nb, head_dim,

@@ -50,6 +50,9 @@ struct GemmArgs {
 // prefetch of the k-major-operand forms (dgrad, wgrad) once per K-tile while the hand-placed counted waits sat unused beside it.
 // With HIDE every wait is the kernel's own (the 256x256 kernel's schedule already names them all); the 128x128 kernel keeps
 // the builtin because it relies on the waits hipcc derives.  (guide §5 'Three .s-level traps', §5.7)
+// Hazards inside the string are ours: m0 is written by an SALU move one wait state before the load (s_nop 0); the SGPR base
+// must not come from a VALU write in the 5 preceding instructions — checked on the generated code by
+// tools/check_asm_dma_hazards.py rather than padded with `s_nop 4` (which measured -2...-6 % on every form).
 #ifndef MOLLY_GEMM_ASM_DMA
 #define MOLLY_GEMM_ASM_DMA 1
 #endif
@@ -57,7 +60,7 @@ template <bool HIDE>
 __device__ __forceinline__ void dma16(const char* base, unsigned off, bf16_t* lds_dst) {
     if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr)
                      : "memory", "m0");
     } else {
         __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_dst), 16, 0, 0);
@@ -67,7 +70,7 @@ template <bool HIDE>
 __device__ __forceinline__ void dma16_lane(const char* src, bf16_t* lds_dst) {        // per-lane 64-bit source address
     if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
     } else {
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_dst), 16, 0, 0);
     }
@@ -75,9 +78,13 @@ __device__ __forceinline__ void dma16_lane(const char* src, bf16_t* lds_dst) {  
 
 // ---- k-contiguous operand: tile [ROWS][64] bf16 (128-B LDS rows); one wave-instruction = 8 rows (1 KiB).
 // chunk swizzle: ch ^ (row & 7)
+// remap_ff > 0 (SwiGLU-fused gate|up projection, MOLLY_GEMM_SWIGLU): the half-tile's 128 rows are not 128 consecutive weight
+// rows but, in 32-row groups, [gate c..c+31 | up c..c+31 | gate c+32..c+63 | up c+32..c+63] with c = row0 (an index into the
+// `ff` activation columns; up rows live `remap_ff` rows below their gate rows).  A wave's two 32-column n-halves are then the
+// gate and the up projection of the SAME 32 activation columns, so its epilogue holds both values of every element it owns.
 template <int ROWS, int NW, int BK, bool HIDE = false>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, int row0, int rows_total, int k0,
-                                         bf16_t* lds_tile, int wave, int lane) {
+                                         bf16_t* lds_tile, int wave, int lane, int remap_ff = 0) {
     constexpr int CPR = BK / 8;                   // chunks per row (8: 128-B rows, 4: 64-B rows)
     constexpr int RPI = 64 / CPR;                 // rows per wave-instruction
     constexpr int PER = ROWS / RPI / NW;
@@ -86,14 +93,15 @@ __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, i
     const int c_src = BK == 64 ? ((lane & 7) ^ r_in) : ((lane & 3) ^ ((r_in >> 2) & 3));
     // address = wave-uniform 64-bit base (tile row 0, K offset: SGPRs) + one 32-bit per-lane byte offset: the K advance
     // of the main loop then lives in scalar registers and each LDS-DMA costs ONE address VGPR
-    const int r0 = row0 < rows_total ? row0 : rows_total - 1;   // a half-tile may start past the last row
+    const int r0 = remap_ff ? 0 : (row0 < rows_total ? row0 : rows_total - 1);   // a half-tile may start past the last row
     const char* base = reinterpret_cast<const char*>(g + (size_t)r0 * ld + k0);
     const int last = rows_total - 1 - r0;         // clamp: OOB rows re-read a valid row, masked at store
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int inst = wave * PER + i;
         int rel = inst * RPI + r_in;
-        rel = rel < last ? rel : last;
+        if (remap_ff) rel = ((rel >> 5) & 1) * remap_ff + row0 + (rel >> 6) * 32 + (rel & 31);   // ff % 128 == 0: no ragged tile
+        else rel = rel < last ? rel : last;
         const unsigned off = ((unsigned)rel * (unsigned)ld + (unsigned)(c_src * 8)) * 2u;
         dma16<HIDE>(base, off, lds_tile + inst * 512);
     }
@@ -396,6 +404,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             else stage_kc<128, NWI, BK, true>(cA, clda, m0 + which * 128, cM, kt * BK, dst, wi, lane);
         } else {
             if (BT) stage_km<128, NWI, BK, true>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, p.K, p.zeros, dst, wi, lane);
+            else if (!AT && !TO && !GRP && (p.flags & MOLLY_GEMM_SWIGLU))
+                stage_kc<128, NWI, BK, true>(cB, cldb, (n0 >> 1) + (which - 2) * 64, cN, kt * BK, dst, wi, lane, cN >> 1);
             else stage_kc<128, NWI, BK, true>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, dst, wi, lane);
         }
     };
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         if (nk > 1) { issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3); }
     }
     exact_stores = em0 + 256 <= eM && en0 + 256 <= eN &&
-                   !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE));
+                   !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU));
 
     if (GRP ? eto : TO) {
         // transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr];
@@ -626,6 +636,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const int n = en0 + wc * 64 + j * 16 + (lane >> 4) * 4;
                 if (n >= eN) continue;
                 *reinterpret_cast<f32x4*>(slab + (size_t)m * eN + n) = acc[i][j];
+            }
+        }
+    } else if (!AT && !BT && !TO && !GRP && (p.flags & MOLLY_GEMM_SWIGLU)) {
+        // SwiGLU-fused gate|up projection: acc[i][jj] = gate, acc[i][2 + jj] = up of the SAME activation columns (stage_kc's
+        // row remap).  Stores gu = [gate | up] (what the backward reads) and act = silu(gate) * up with the roundings of the
+        // two-kernel path (GEMM output rounded to bf16, silu rounded, product rounded: bit-identical to molly_swiglu_fwd).
+        const int ff = eN >> 1;
+        bf16_t* act = const_cast<bf16_t*>(p.res);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = em0 + wr * 128 + i * 16 + fr;
+            if (m >= eM) continue;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int c = (en0 >> 1) + (wc >> 1) * 64 + (wc & 1) * 32 + jj * 16 + fq * 4;
+                const u32x2 gq = u32x2{pack_bf2(acc[i][jj][0], acc[i][jj][1]), pack_bf2(acc[i][jj][2], acc[i][jj][3])};
+                const u32x2 uq = u32x2{pack_bf2(acc[i][2 + jj][0], acc[i][2 + jj][1]), pack_bf2(acc[i][2 + jj][2], acc[i][2 + jj][3])};
+                bf16_t* gp = reinterpret_cast<bf16_t*>(eC) + (size_t)m * eldc + c;
+                *reinterpret_cast<u32x2*>(gp) = gq;
+                *reinterpret_cast<u32x2*>(gp + ff) = uq;
+                u32x2 o;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float ga = bflo(gq[e]), gb = bfhi(gq[e]);
+                    const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+                    o[e] = pack_bf2(sa * bflo(uq[e]), sb * bfhi(uq[e]));
+                }
+                *reinterpret_cast<u32x2*>(act + (size_t)m * p.ldres + c) = o;
             }
         }
     } else {
@@ -854,6 +892,13 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
     }
     p.zeros = zeros;
     hipStream_t st = (hipStream_t)stream;
+    if (flags & MOLLY_GEMM_SWIGLU) {
+        MOLLY_CHECK(!at && !bt && flags == MOLLY_GEMM_SWIGLU && res && N % 256 == 0 && ldres % 4 == 0,
+                    "gemm: MOLLY_GEMM_SWIGLU is the plain NT form with N = 2*ff, ff %% 128 == 0 (N=%d), res = the activation output", N);
+        launch_cfg<false, false>(st, p, 512);                  // the 256x256 kernel, one pass (no split-K slabs)
+        MOLLY_LAUNCH_CHECK();
+        return 0;
+    }
     if (flags & MOLLY_GEMM_TRANS_OUT) {
         MOLLY_CHECK(!at && bt, "gemm: MOLLY_GEMM_TRANS_OUT is built for the (k-contiguous A, k-major B) form only");
         MOLLY_CHECK(!(flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_GELU | MOLLY_GEMM_RESIDUAL)) && M % 4 == 0,

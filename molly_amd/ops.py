@@ -9,7 +9,7 @@ import torch
 from ._lib import lib
 
 BF16 = torch.bfloat16
-GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32, GEMM_TRANS_OUT = 1, 2, 4, 8, 16, 32
+GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32, GEMM_TRANS_OUT, GEMM_SWIGLU = 1, 2, 4, 8, 16, 32, 64
 
 
 # optional timing of the dominant kernel (bench.py roofline): list of (start_event | None, end_event | None, flops, cfg, layout).
@@ -67,6 +67,22 @@ def ensure_gemm_workspace(nbytes: int = 512 << 20, device="cuda"):
 def gemm_nt(a, b, out=None, bias=None, res=None, gelu=False, accumulate=False, out_dtype=BF16):
     """out[M,N] = a[M,K] @ b[N,K]^T (+bias) (gelu) (+res) (+= out).  2-D views with arbitrary row stride."""
     return gemm(a, b, out, bias, res, gelu, accumulate, out_dtype, False, False)
+
+
+def gemm_gate_up_swiglu(x, w_gu, gu, act):
+    """gu[M, 2ff] = x @ w_gu^T (w_gu = [gate_proj | up_proj] rows) and act[M, ff] = silu(gate) * up from ONE launch
+    (MOLLY_GEMM_SWIGLU): the activation is computed in the GEMM's epilogue from the accumulators of the tile."""
+    _chk(x, BF16, "x"); _chk(w_gu, BF16, "w_gu"); _chk(gu, BF16, "gu"); _chk(act, BF16, "act")
+    M, K = x.shape
+    N = w_gu.shape[0]
+    assert w_gu.shape[1] == K and tuple(gu.shape) == (M, N) and tuple(act.shape) == (M, N // 2) and N % 256 == 0
+    prof = GEMM_PROFILE
+    e0 = _prof_begin() if prof is not None else None
+    lib().call("molly_gemm_bf16", _stream(), x, w_gu, gu, None, act, M, N, K, x.stride(0), w_gu.stride(0), gu.stride(0),
+               act.stride(0), GEMM_SWIGLU, 0, 0)
+    if prof is not None:
+        _prof_end(prof, e0, 2.0 * M * N * K, (False, False))
+    return act
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
@@ -158,8 +174,8 @@ def rmsnorm_bwd(x, w, g, dw, eps, dres=None, dx=None, dw_accumulate=True, worksp
     if workspace is None:
         workspace = torch.empty(nb * H, dtype=torch.float32, device=x.device)
     assert workspace.numel() >= nb * H
-    lib().call("molly_rmsnorm_bwd", _stream(), x, w, g, dres, dx, dw, int(dw.dtype == torch.float32), int(dw_accumulate),
-               workspace, rows, H, float(eps))
+    lib().call("molly_rmsnorm_bwd", _stream(), x, w, g, dres, dx, dw, int(dw is not None and dw.dtype == torch.float32),
+               int(dw_accumulate), workspace, rows, H, float(eps))
     return dx
 
 
@@ -180,6 +196,19 @@ def norm_rope_bwd(src, g, dsrc, nq, nk, hd, T, qw, kw, cos, sin, dqw, dkw, posit
                int(dqw.dtype == torch.float32) if dqw is not None else 0, int(dw_accumulate), workspace, M, T, nq, nk, hd,
                src.stride(0), g.stride(0), dsrc.stride(0), float(eps), float(q_scale))
     return dsrc
+
+
+def colsum_items(entries, device):
+    """Device table for colsum_batched: entries = [(partials fp32 tensor, out tensor, nb, H, row_stride)]."""
+    import struct
+    raw = b"".join(struct.pack("<QQiiii", part.data_ptr(), out.data_ptr(), nb, H, rs, 0) for part, out, nb, H, rs in entries)
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return t, len(entries), max(e[3] for e in entries)
+
+
+def colsum_batched(table, out_f32=False, accumulate=False):
+    t, n, max_h = table
+    lib().call("molly_colsum_batched", _stream(), t, n, max_h, int(out_f32), int(accumulate))
 
 
 def swiglu_fwd(gu, out=None):

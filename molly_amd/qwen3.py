@@ -59,6 +59,9 @@ class Qwen3Engine:
         self.nqk = (self.nh + self.nkv) * self.hd
         self.ce_chunk_rows = ce_chunk_rows
         self.rope_table_dtype = rope_table_dtype
+        # SwiGLU in the gate|up GEMM's epilogue (MOLLY_GEMM_SWIGLU): not with LoRA (the adapters add to gate / up after the
+        # base GEMM), needs ff % 128 == 0 (every Qwen3 size); MOLLY_FUSED_SWIGLU=0 restores the two-kernel path
+        self.fused_swiglu = (lora is None and self.ff % 128 == 0 and os.environ.get("MOLLY_FUSED_SWIGLU", "1") != "0")
         self.cap = 0
         self.tT = None
         self.tTg, self._pend = None, []   # grouped per-layer weight gradients (reserve)
@@ -158,6 +161,21 @@ class Qwen3Engine:
             nb1 = ops.lib().query("molly_rmsnorm_bwd_blocks", M)
             nb2 = ops.lib().query("molly_norm_rope_bwd_blocks")
             self.ws = torch.empty(max(nb1 * h, nb2 * 2 * self.hd), dtype=torch.float32, device=dev)
+            # gain gradients deferred to ONE batched column reduction at the end of the backward: every norm backward keeps
+            # its per-block partials in a workspace of its own (2L + 1 RMSNorm gains: nb1 x h floats each — 8 MB at h 2048;
+            # 2L q/k-norm gains: nb2 x 2 hd) instead of launching a 64-block reduce behind itself
+            self.ws_defer = None
+            if self.train_base and os.environ.get("MOLLY_DEFER_COLSUM", "1") != "0":
+                L = self.L
+                self.ws_rms = torch.empty(2 * L + 1, nb1 * h, dtype=torch.float32, device=dev)
+                self.ws_qk = torch.empty(L, nb2 * 2 * self.hd, dtype=torch.float32, device=dev)
+                ent = [(self.ws_rms[2 * L], self.d_norm_w, nb1, h, h)]
+                for i in range(L):
+                    g = self.dW[i]
+                    ent += [(self.ws_rms[2 * i], g["ln2"], nb1, h, h), (self.ws_rms[2 * i + 1], g["ln1"], nb1, h, h),
+                            (self.ws_qk[i], g["qn"], nb2, self.hd, 2 * self.hd),
+                            (self.ws_qk[i][self.hd:], g["kn"], nb2, self.hd, 2 * self.hd)]
+                self.ws_defer = ops.colsum_items(ent, dev)
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward(self, inputs_embeds: torch.Tensor, B: int, T: int, kv_lo=None, kv_hi=None,
@@ -200,11 +218,15 @@ class Qwen3Engine:
             if self.lora is not None:
                 self._lora_fwd(i, a, "o_proj", a["attn"], a["x2"], training)
             ops.rmsnorm_fwd(a["x2"], w["ln2"], cfg.rms_norm_eps, out=a["xn2"])
-            ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
-            if self.lora is not None:
-                self._lora_fwd(i, a, "gate_proj", a["xn2"], a["gu"][:, :self.ff], training)
-                self._lora_fwd(i, a, "up_proj", a["xn2"], a["gu"][:, self.ff:], training)
-            ops.swiglu_fwd(a["gu"], out=a["act"])
+            if self.fused_swiglu:
+                # gate|up projection with the activation in its epilogue: one launch, no second pass over gu
+                ops.gemm_gate_up_swiglu(a["xn2"], w["gu"], a["gu"], a["act"])
+            else:
+                ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
+                if self.lora is not None:
+                    self._lora_fwd(i, a, "gate_proj", a["xn2"], a["gu"][:, :self.ff], training)
+                    self._lora_fwd(i, a, "up_proj", a["xn2"], a["gu"][:, self.ff:], training)
+                ops.swiglu_fwd(a["gu"], out=a["act"])
             nxt = self.A[i + 1]["x"] if (training and i + 1 < self.L) else self.x_out
             ops.gemm_nt(a["act"], w["down"], out=nxt, res=a["x2"])
             if self.lora is not None:
@@ -377,8 +399,10 @@ class Qwen3Engine:
         lora = self.lora
         # final norm backward
         dx = self.d_b
-        ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, self.d_norm_w if tb else junk[:self.h], cfg.rms_norm_eps, dx=dx,
-                        dw_accumulate=accumulate and tb, workspace=self.ws)
+        defer = tb and getattr(self, "ws_defer", None) is not None
+        ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, None if defer else (self.d_norm_w if tb else junk[:self.h]),
+                        cfg.rms_norm_eps, dx=dx, dw_accumulate=accumulate and tb,
+                        workspace=self.ws_rms[2 * self.L] if defer else self.ws)
         spare = [self.d_a, self.d_c]
         acc_n = accumulate and tb
         nq, nk_ = self.nh * self.hd, self.nkv * self.hd
@@ -400,8 +424,8 @@ class Qwen3Engine:
             if tb:
                 self._wgrad_layer(2, self.d_gu, a["xn2"], g["gu"], accumulate)
             dx2 = spare[1]
-            ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, gw(g, "ln2"), cfg.rms_norm_eps, dres=dx, dx=dx2,
-                            dw_accumulate=acc_n, workspace=self.ws)
+            ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, None if defer else gw(g, "ln2"), cfg.rms_norm_eps, dres=dx, dx=dx2,
+                            dw_accumulate=acc_n, workspace=self.ws_rms[2 * i] if defer else self.ws)
             # ---- attention: x2 = x + o_proj(attn)
             self._dgrad(dx2, w["o"], self.d_attn)
             if lora is not None:
@@ -412,8 +436,8 @@ class Qwen3Engine:
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
                          self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta)
             ops.norm_rope_bwd(a["qkv"], self.d_qk, self.d_qkv, self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos,
-                              self.sin, gw(g, "qn"), gw(g, "kn"), eps=cfg.rms_norm_eps, dw_accumulate=acc_n,
-                              workspace=self.ws)
+                              self.sin, None if defer else gw(g, "qn"), None if defer else gw(g, "kn"), eps=cfg.rms_norm_eps,
+                              dw_accumulate=acc_n, workspace=self.ws_qk[i] if defer else self.ws)
             dxn = spare[0]
             self._dgrad(self.d_qkv, w["qkv"], dxn)
             if lora is not None:
@@ -425,8 +449,10 @@ class Qwen3Engine:
                 self._wgrad_layer(0, self.d_qkv, a["xn"], g["qkv"], accumulate)
                 # dx, d_gu, dx2 and d_qkv are all still intact here (the norm backward below overwrites dx)
                 self._wgrad_flush(accumulate)
-            ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, gw(g, "ln1"), cfg.rms_norm_eps, dres=dx2, dx=dx,
-                            dw_accumulate=acc_n, workspace=self.ws)
+            ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, None if defer else gw(g, "ln1"), cfg.rms_norm_eps, dres=dx2, dx=dx,
+                            dw_accumulate=acc_n, workspace=self.ws_rms[2 * i + 1] if defer else self.ws)
             if tb and final_micro and self.grads_final_hook is not None:
                 self.grads_final_hook(self.layer_lo[i], self.layers_hi)       # matrices of layers i..L-1 are final
+        if defer:
+            ops.colsum_batched(self.ws_defer, accumulate=acc_n)                # all 4L + 1 gain gradients, one launch
         return dx

@@ -47,3 +47,14 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith(".py"):
                 txt = open(os.path.join(dp, fn)).read()
                 assert not pat.search(txt), f"{fn} references the oracle"
+
+
+def test_asm_issued_lds_dma_has_no_sgpr_hazard():
+    """The GEMM / attention LDS-DMA is issued from inline asm, where hipcc pads no hazards: prove on the generated assembly
+    that no SGPR base of such a load was written by a VALU instruction within the 5 preceding instructions."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_dma_hazards.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 hazards" in r.stdout

@@ -630,3 +630,19 @@ def test_reduce_rows_is_the_fp32_sum_in_row_order():
         for r in range(rows):
             acc += x[r].float()
         assert torch.equal(out, acc.to(BF))
+
+
+@pytest.mark.parametrize("M,ff,K", [(300, 256, 128), (1024, 3072, 1024), (16384, 6144, 2048)])
+def test_gate_up_gemm_with_fused_swiglu_is_bit_identical_to_two_kernels(M, ff, K):
+    """MOLLY_GEMM_SWIGLU: gu = x W_gu^T and act = silu(gate) * up from one launch (the B tile interleaves gate and up rows so a
+    wave owns both values of every element) == molly_gemm + molly_swiglu_fwd, bit for bit, ragged M included."""
+    x = _rand(M, K, seed=61).to(BF)
+    w = _rand(2 * ff, K, seed=62, scale=0.05).to(BF)
+    gu_ref = ops.gemm_nt(x, w)
+    act_ref = ops.swiglu_fwd(gu_ref)
+    gu = torch.full((M, 2 * ff), 7.0, dtype=BF, device=DEV)
+    act = torch.full((M, ff), 7.0, dtype=BF, device=DEV)
+    ops.gemm_gate_up_swiglu(x, w, gu, act)
+    torch.cuda.synchronize()
+    assert torch.equal(gu, gu_ref)
+    assert torch.equal(act, act_ref)

@@ -22,6 +22,7 @@ SHAPES = [  # (name, form, M, N, K)
     ("head fwd 4k", "nt", 4096, 151936, 2048), ("head dgrad 4k", "nn", 4096, 2048, 151936),
     ("head wgrad 4k", "tn", 151936, 2048, 4096),
     ("esm qkv", "nt", 4096, 3840, 1280), ("esm ffn1", "nt", 4096, 5120, 1280), ("esm ffn2", "nt", 4096, 1280, 5120),
+    ("esm o", "nt", 4096, 1280, 1280), ("esm proj", "nt", 4096, 2048, 1280),
 ]
 
 
