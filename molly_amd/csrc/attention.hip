@@ -10,6 +10,8 @@
 // query column (lane&31) with its keys in registers -> the row max/sum are per-lane (+1 cross-half exchange), and P^T
 // converted to bf16 is directly the B operand of O^T = V^T·P^T; V^T fragments come from the row-major V tile through
 // ds_read_b64_tr_b16 (guide T10).  Q lives in registers for the whole kernel.
+#include <stdlib.h>
+
 #include "common.h"
 #include "molly_hip.h"
 
@@ -753,13 +755,21 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         attr_set = true;
     }
     dim3 gq(n_heads * B, cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));
+    // MOLLY_ATTN_DKV_ONE_PASS=1: dK and dV from one pass (7 MFMA products in the backward instead of 8, but 256 accumulator
+    // registers = one wave per SIMD); default: two passes at two waves per SIMD (measured faster: DESIGN.md §4)
+    static const bool one_pass = [] { const char* e = getenv("MOLLY_ATTN_DKV_ONE_PASS"); return e && atoi(e) != 0; }();
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk, dim3(256), lds_dkv, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2>), gk, dim3(256), lds_dkv, st, p);
+        if (one_pass) {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk, dim3(256), lds_dkv, st, p);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk, dim3(256), lds_dkv, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2>), gk, dim3(256), lds_dkv, st, p);
+        }
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), lds_dq, st, p);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 0>), gk, dim3(256), lds_dkv, st, p);
