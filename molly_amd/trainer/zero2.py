@@ -213,7 +213,7 @@ class Zero2Optimizer:
         # ---- overlap machinery -------------------------------------------------------------------------------
         rs_algo = rs_algo or os.environ.get("MOLLY_RS_ALGO", "rccl")
         self.comm = comm if comm is not None else _DistComm(group, staged=_STAGED_DEFAULT, rs_algo=rs_algo,
-                                                            reduce_rows=self.k.reduce_rows)
+                                                            reduce_rows=getattr(self.k, "reduce_rows", None))
         self.rs_algo = getattr(self.comm, "rs_algo", "rccl")
         self.overlap = (self.world > 1) if overlap is None else overlap
         self.overlap = self.overlap and flat_params.is_cuda

@@ -139,3 +139,45 @@ def test_stand_in_tokenizers_are_refused_for_pretrained_weights(tmp_path):
     from molly_amd.loaders import setup_tokenizers
     *_, real = setup_tokenizers("qwen3-0.6b", "nt-500m", "esm2-650m", log=lambda *_: None)
     assert real is False
+
+
+def test_get_omics_one_config_reads_three_hf_config_dirs(tmp_path):
+    """reference: src/model/config.py:49-86 — three model paths -> one OmicsModalConfig (the reference goes through
+    transformers.AutoConfig; the fields the arithmetic reads must come out the same from the plain JSON)."""
+    from molly_amd.config import get_omics_one_config
+    qwen = dict(model_type="qwen3", vocab_size=151936, hidden_size=2048, intermediate_size=6144, num_hidden_layers=28,
+                num_attention_heads=16, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6, tie_word_embeddings=True,
+                rope_parameters={"rope_theta": 1000000.0, "rope_type": "default"}, max_position_embeddings=40960,
+                eos_token_id=151645, attention_bias=False, torch_dtype="bfloat16")
+    nt = dict(model_type="esm", vocab_size=4105, hidden_size=1280, intermediate_size=5120, num_hidden_layers=24,
+              num_attention_heads=20, max_position_embeddings=1002, position_embedding_type="absolute", token_dropout=False,
+              pad_token_id=1, mask_token_id=2, layer_norm_eps=1e-12, emb_layer_norm_before=False)
+    esm = dict(model_type="esm", vocab_size=33, hidden_size=1280, intermediate_size=5120, num_hidden_layers=33,
+               num_attention_heads=20, max_position_embeddings=1026, position_embedding_type="rotary", token_dropout=True,
+               pad_token_id=1, mask_token_id=32, layer_norm_eps=1e-5)
+    dirs = []
+    for name, c in (("qwen", qwen), ("nt", nt), ("esm", esm)):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "config.json").write_text(json.dumps(c))
+        dirs.append(str(d))
+    cfg = get_omics_one_config(*dirs)
+    assert cfg.dna_rna_project_token_num == 64 and cfg.protein_project_token_num == 64          # reference defaults
+    t = cfg.text_config
+    assert (t.hidden_size, t.num_hidden_layers, t.num_key_value_heads, t.head_dim, t.rope_theta, t.tie_word_embeddings) == \
+        (2048, 28, 8, 128, 1e6, True)
+    assert cfg.dna_rna_config.position_embedding_type == "absolute" and cfg.dna_rna_config.max_position_embeddings == 1002
+    assert cfg.dna_rna_config.layer_norm_eps == 1e-12 and cfg.protein_config.token_dropout is True
+    assert cfg.text_config.use_cache is False and cfg.protein_config.gradient_checkpointing is False   # reference :80-84
+    # the presets are these same shapes
+    from molly_amd import config as C
+    p = C.molly("1.7b")
+    for k in ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "head_dim",
+              "vocab_size", "tie_word_embeddings", "rope_theta"):
+        assert getattr(p.text_config, k) == getattr(t, k), k
+    for k in ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "vocab_size",
+              "position_embedding_type", "max_position_embeddings", "token_dropout", "mask_token_id"):
+        assert getattr(p.dna_rna_config, k) == getattr(cfg.dna_rna_config, k), k
+        assert getattr(p.protein_config, k) == getattr(cfg.protein_config, k), k
+    with pytest.raises(NotImplementedError):
+        C.LlmConfig.from_dict({**qwen, "attention_bias": True})
