@@ -84,6 +84,12 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
         // decision, 32 exponentials, 16 P.V MFMAs; 252 VGPRs): 682-612 vs 692-652 TF/s — no gain; the cross-half maximum through
         // v_permlane32_swap: hipcc folded max(r[0], r[1]) of the swap of a value with itself to r[0] (the LOWER half's maximum
         // for both halves: correct O, but -inf LSE for rows whose only live keys sit in the upper half) — ds_bpermute stays.
+        // An 8-wave ping-pong form of this kernel (one 512-thread workgroup per CU = 256 query rows, 3-stage K/V ring, the two
+        // waves of a SIMD alternating a 16-MFMA segment [P.V of half h-1 + S^T of half h] with a load + softmax segment behind
+        // workgroup barriers, group 1 one segment behind group 0; 208 VGPRs; passed every attention test): 510-520 TF/s against
+        // 734-747 for this kernel in the same process — the softmax segment (24 LDS reads, ~86 vector instructions, 16
+        // transcendentals, DMA issue) is longer than the 512-cycle matrix segment it is paired with, four 8-wave barriers per
+        // tile pay for the slowest wave, and one workgroup per CU has nobody to cover its prologue and diagonal tail.  Removed.
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds + inst * 512));
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
