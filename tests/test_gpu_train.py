@@ -241,3 +241,34 @@ def test_step_loop_trajectory_vs_reference_pieces(tiny_meta):
         cos = torch.nn.functional.cosine_similarity(upd_got, upd_ref, dim=0).item()
         assert cos > 0.9 or upd_ref.abs().max().item() < 2 ** -8 * ref.abs().max().item(), (n, cos)
     print(f"worst update error / tolerance {worst:.3f}")
+
+
+def test_non_finite_gradient_skips_the_step_like_deepspeed():
+    """An inf/NaN gradient must not poison the fp32 master, the moments or the bf16 parameters (DeepSpeed's ZeRO step skips the
+    update on overflow and does not advance Adam): the clip kernel turns a non-finite norm into a NaN coefficient, AdamW leaves
+    everything untouched for it and counts the skip; the next finite step uses the bias corrections of step 1."""
+    from molly_amd.trainer import Zero2Optimizer
+    n, n_decay = 1 << 16, 1 << 15
+    g = torch.Generator(device="cuda").manual_seed(0)
+    P = torch.randn(n, device="cuda", generator=g).bfloat16()
+    G = (torch.randn(n, device="cuda", generator=g) * 0.1).bfloat16()
+    good = G.clone()
+    opt = Zero2Optimizer(P, G, n_decay, lr=1e-2, max_grad_norm=1.0)
+    ref = Zero2Optimizer(P.clone(), good.clone(), n_decay, lr=1e-2, max_grad_norm=1.0)
+    p0 = P.clone()
+    G[123] = float("inf")
+    norm = opt.step()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(norm).item()
+    assert torch.equal(P, p0) and opt.skipped_steps() == 1
+    assert float(opt.m.abs().max()) == 0.0 and float(opt.v.abs().max()) == 0.0
+    G.copy_(good)
+    opt.step()                                     # host step counter is 2, one skipped: Adam's t = 1
+    ref.step()
+    torch.cuda.synchronize()
+    assert torch.equal(P, ref.P) and torch.equal(opt.master, ref.master) and torch.equal(opt.m, ref.m)
+    G[7] = float("nan")
+    before = P.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(P, before) and opt.skipped_steps() == 2

@@ -107,3 +107,48 @@ def test_two_ranks_all_to_all_reduce_scatter(tiny_meta):
         assert torch.equal(ret[0][0], ret[1][0]) and ret[0][1] == ret[1][1]
         res[algo] = ret[0]
     assert torch.equal(res["a2a"][0], res["rccl"][0]) and res["a2a"][1] == res["rccl"][1]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_launches_its_own_ranks_end_to_end():
+    """`python bench.py --gpus 2` with NO launcher around it (what the driver runs): bench.py starts the two ranks itself, they
+    run the pre-flight, the timed steps and the exposed-communication measurement, and rank 0 prints the one JSON line.  Both
+    ranks share the one GPU of the test box and gloo moves the bytes (RCCL refuses two ranks per device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MOLLY_BENCH_DEVICE="0", MOLLY_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--seq", "1024", "--k-protein", "256", "--exposed-comm-steps", "2"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # exactly ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    c = d["comm"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and c["preflight"]["all_reduce"] is True
+    assert c["comm_bytes_per_step_per_gpu"] > 0 and c["buckets"] >= 1 and "step_ms_p50_no_overlap" in c
+    assert d["config"]["global_batch"] == 4
+
+
+def test_world2_smoke_entry_point():
+    """__graft_entry__.smoke() under a 2-rank launcher: pre-flight, two overlapped ZeRO-2 steps, replicas bit-identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MOLLY_BENCH_DEVICE="0", MOLLY_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "__graft_entry__.py"), "smoke"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "smoke_dist ok: world 2" in r.stdout
