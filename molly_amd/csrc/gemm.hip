@@ -449,6 +449,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
     if (nk > 1) { issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3); }
     bool exact_stores = false;                // previous epilogue issued exactly 32 plain stores per lane (and no loads)
+    bool exact_stores48 = false;              // ... or exactly 48 (SwiGLU-fused epilogue: gate, up and activation quads)
 
     for (;;) {
 #pragma unroll
@@ -461,6 +462,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     if (exact_stores) {
         if (nk > 1) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    } else if (exact_stores48) {
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
     } else {
         if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -588,6 +592,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
     exact_stores = em0 + 256 <= eM && en0 + 256 <= eN &&
                    !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU));
+    exact_stores48 = !AT && !BT && !TO && !GRP && em0 + 256 <= eM && en0 + 256 <= eN && p.flags == MOLLY_GEMM_SWIGLU;
 
     if (GRP ? eto : TO) {
         // transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr];
