@@ -699,6 +699,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
 extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
                               const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim,
                               int ldq, int ldk, int ldv, int ldo, float scale, int causal) {
+    MOLLY_ENTER();
     MOLLY_CHECK(head_dim == 128 || head_dim == 64 || head_dim == 16 || head_dim == 32 || head_dim == 8 || head_dim == 24 ||
                     head_dim == 40 || head_dim == 48,
                 "attn_fwd: head_dim=%d not built (64 and 128 on the MFMA kernel; 8..48 in steps of 8 on the small-head kernel)",
@@ -737,6 +738,7 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
                               const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo,
                               const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk,
                               int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal) {
+    MOLLY_ENTER();
     MOLLY_CHECK(head_dim == 128 || head_dim == 64, "attn_bwd: head_dim=%d not built (64 and 128 are)", head_dim);
     MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_bwd: n_heads %% n_kv_heads != 0");
     MOLLY_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 &&

@@ -120,6 +120,7 @@ inline int key_bits(int vocab) {            // bits to sort ids in [0, vocab] (v
 }  // namespace
 
 extern "C" int molly_batch_sort_workspace(int M) {
+    MOLLY_ENTER();
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                                              (int*)nullptr, M, 0, 32, (hipStream_t)0);
@@ -132,6 +133,7 @@ extern "C" int molly_batch_assemble(void* stream, const int* ids32, const int* l
                                     int* scored_rows, int* n_scored, int64_t* omic64_g0, int* dst_g0, int64_t* omic64_g1,
                                     int* dst_g1, unsigned char* overwritten, int* keys_tmp, int* vals_tmp, int* order,
                                     int* seg_start, int64_t* uid, int* n_unique, void* sort_ws, long sort_ws_bytes) {
+    MOLLY_ENTER();
     const long M = (long)B * T;
     MOLLY_CHECK(M > 0 && M < (1L << 30) && overwritten, "batch_assemble: B*T = %ld rows", M);
     MOLLY_CHECK((labels32 != nullptr) == (labels_shifted != nullptr) && (!labels_shifted || (scored_rows && n_scored)),

@@ -102,6 +102,10 @@ void molly_set_error(const char* fmt, ...);
             return 1;                     \
         }                                 \
     } while (0)
+// Entry of every launching function: forget an error some OTHER library left in this thread's HIP error slot (found in round 2:
+// after torch.distributed's device probing hipcub's radix sort — and our own launch check — reported "no ROCm-capable device is
+// detected" for a launch that had worked), so that what MOLLY_LAUNCH_CHECK reports is ours.
+#define MOLLY_ENTER() (void)hipGetLastError()
 #define MOLLY_LAUNCH_CHECK()                                                   \
     do {                                                                       \
         hipError_t e_ = hipGetLastError();                                     \

@@ -179,6 +179,7 @@ extern "C" int molly_attn_decode_workspace(int B, int n_heads, int head_dim) {
 extern "C" int molly_attn_decode(void* stream, const void* q, const void* kcache, const void* vcache, void* out,
                                  const int* kv_lo, const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim,
                                  int ldq, float scale, int kv_len_hint, float* workspace, long workspace_floats) {
+    MOLLY_ENTER();
     MOLLY_CHECK(head_dim == 64 || head_dim == 128, "attn_decode: head_dim=%d (built for 64 and 128)", head_dim);
     MOLLY_CHECK(B > 0 && Tmax > 0 && kv_hi != nullptr, "attn_decode: kv_hi required, B=%d Tmax=%d", B, Tmax);
     MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_decode: n_heads=%d not a multiple of n_kv_heads=%d", n_heads, n_kv_heads);

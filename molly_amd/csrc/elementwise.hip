@@ -1115,6 +1115,7 @@ inline int grid_for(long items, int per_block = 256, int cap = 2048) {
     } while (0)
 
 extern "C" int molly_transpose_bf16(void* stream, const void* in, void* out, int R, int C, int ld_in, int ld_out) {
+    MOLLY_ENTER();
     MOLLY_CHECK(R > 0 && C > 0 && ld_in >= C && ld_out >= R, "transpose: bad shape R=%d C=%d", R, C);
     if (R % 64 == 0 && C % 64 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in % 16) == 0 &&
         ((uintptr_t)out % 16) == 0) {
@@ -1131,6 +1132,7 @@ extern "C" int molly_transpose_bf16(void* stream, const void* in, void* out, int
 
 extern "C" int molly_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* rstd, int rows, int H,
                                  float eps) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "rmsnorm: H=%d must be a multiple of 8 and <= %d", H,
                 RN_MAXC * 512);
 #define RMS_FWD(NC)                                                                                              \
@@ -1146,6 +1148,7 @@ extern "C" int molly_rmsnorm_bwd_blocks(int rows) { return grid_for(rows, 4, 102
 
 extern "C" int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres, void* dx,
                                  void* dw, int dw_f32, int dw_accumulate, float* workspace, int rows, int H, float eps) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "rmsnorm_bwd: bad H=%d", H);
     MOLLY_CHECK(workspace, "rmsnorm_bwd: workspace of molly_rmsnorm_bwd_blocks(rows)*H floats required");
     const int nb = molly_rmsnorm_bwd_blocks(rows);
@@ -1163,6 +1166,7 @@ extern "C" int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, con
 }
 
 extern "C" int molly_colsum_batched(void* stream, const void* items_dev, int n_items, int max_H, int out_f32, int accumulate) {
+    MOLLY_ENTER();
     MOLLY_CHECK(items_dev && n_items >= 1 && n_items <= 65535 && max_H >= 1, "colsum_batched: %d items, max_H=%d", n_items, max_H);
     hipLaunchKernelGGL(colsum_batched_kernel, dim3(cdiv(max_H, 32), n_items), dim3(256), 0, ST, (const ColsumItem*)items_dev,
                        out_f32, accumulate);
@@ -1173,6 +1177,7 @@ extern "C" int molly_colsum_batched(void* stream, const void* items_dev, int n_i
 extern "C" int molly_norm_rope_fwd(void* stream, const void* src, void* dst, const void* q_norm_w, const void* k_norm_w,
                                    const float* cos, const float* sin, const int* positions, int M, int T, int n_q_heads,
                                    int n_k_heads, int head_dim, int ld_src, int ld_dst, float eps, float q_scale) {
+    MOLLY_ENTER();
     MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0, "norm_rope: head_dim=%d", head_dim);
     MOLLY_CHECK(ld_src % 4 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 8) == 0, "norm_rope: 8-byte alignment required");
     MOLLY_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr), "norm_rope: give both norm gains or neither");
@@ -1193,6 +1198,7 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
                                    void* dq_w, void* dk_w, int dw_f32, int dw_accumulate, float* workspace, int M, int T,
                                    int n_q_heads, int n_k_heads, int head_dim, int ld_src, int ld_g, int ld_out,
                                    float eps, float q_scale) {
+    MOLLY_ENTER();
     MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0, "norm_rope_bwd: head_dim=%d",
                 head_dim);
     MOLLY_CHECK(workspace, "norm_rope_bwd: workspace of molly_norm_rope_bwd_blocks()*2*head_dim floats required");
@@ -1217,6 +1223,7 @@ extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g,
 }
 
 extern "C" int molly_swiglu_fwd(void* stream, const void* gate_up, void* out, long rows, int ff) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && ff % 8 == 0, "swiglu: ff=%d must be a multiple of 8", ff);
     hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (ff / 8))), dim3(256), 0, ST, (const bf16_t*)gate_up,
                        (bf16_t*)out, rows, ff);
@@ -1225,6 +1232,7 @@ extern "C" int molly_swiglu_fwd(void* stream, const void* gate_up, void* out, lo
 }
 
 extern "C" int molly_swiglu_bwd(void* stream, const void* gate_up, const void* dout, void* dgate_up, long rows, int ff) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && ff % 8 == 0, "swiglu_bwd: ff=%d must be a multiple of 8", ff);
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (ff / 8))), dim3(256), 0, ST, (const bf16_t*)gate_up,
                        (const bf16_t*)dout, (bf16_t*)dgate_up, rows, ff);
@@ -1234,6 +1242,7 @@ extern "C" int molly_swiglu_bwd(void* stream, const void* gate_up, const void* d
 
 extern "C" int molly_copy_rows(void* stream, const void* src, const int64_t* src_idx64, const int* src_idx32, void* dst,
                                const int* dst_idx32, long n, int H, int ld_src, int ld_dst, int accumulate) {
+    MOLLY_ENTER();
     MOLLY_CHECK(n >= 0 && H % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, "copy_rows: H/ld must be multiples of 8");
     MOLLY_CHECK(!(src_idx64 && src_idx32), "copy_rows: give at most one source index");
     if (n == 0) return 0;
@@ -1245,6 +1254,7 @@ extern "C" int molly_copy_rows(void* stream, const void* src, const int64_t* src
 
 extern "C" int molly_embed_bwd(void* stream, const void* g, const int* order, const int* seg_start, const int64_t* uid,
                                int n_unique, void* dE, int H, int ld_g, const float* row_scale, const int* n_unique_dev) {
+    MOLLY_ENTER();
     MOLLY_CHECK(H % 8 == 0 && ld_g % 8 == 0, "embed_bwd: H must be a multiple of 8");
     if (n_unique <= 0) return 0;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(n_unique, 4)), dim3(256), 0, ST, (const bf16_t*)g, order, seg_start,
@@ -1255,6 +1265,7 @@ extern "C" int molly_embed_bwd(void* stream, const void* g, const int* order, co
 
 extern "C" int molly_count_valid(void* stream, const int64_t* labels, long n, int ignore_index, float* scale_out,
                                  float* count_out) {
+    MOLLY_ENTER();
     hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(1024), 0, ST, (const long*)labels, n, ignore_index, scale_out,
                        count_out);
     MOLLY_LAUNCH_CHECK();
@@ -1263,6 +1274,7 @@ extern "C" int molly_count_valid(void* stream, const int64_t* labels, long n, in
 
 extern "C" int molly_ce_fwd_bwd(void* stream, void* logits, const int64_t* labels, float* row_loss, const float* scale,
                                 int rows, int V, int ld, int ignore_index, int write_grad) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && V % 8 == 0 && ld % 8 == 0, "ce: V=%d and ld=%d must be multiples of 8", V, ld);
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, ST, (bf16_t*)logits, (const long*)labels, row_loss,
                        scale, V, ld, ignore_index, write_grad);
@@ -1273,6 +1285,7 @@ extern "C" int molly_ce_fwd_bwd(void* stream, void* logits, const int64_t* label
 extern "C" int molly_cls_loss_fwd_bwd(void* stream, void* logits, const int64_t* labels, const float* targets,
                                      float* row_loss, const float* scale, int rows, int V, int ld, int mode,
                                      int ignore_index, int write_grad) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && V > 0 && ld >= V, "cls_loss: rows=%d V=%d ld=%d", rows, V, ld);
     MOLLY_CHECK(mode == 0 ? labels != nullptr : (mode == 1 && targets != nullptr), "cls_loss: mode %d without its labels", mode);
     MOLLY_CHECK(!write_grad || scale, "cls_loss: gradient requested without a scale");
@@ -1313,6 +1326,7 @@ __global__ __launch_bounds__(256) void argmax_f32_kernel(const float* __restrict
 }
 
 extern "C" int molly_argmax_f32(void* stream, const float* x, int64_t* out, int rows, int V, int ld) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && V > 0 && V < 0x40000000 && ld >= V, "argmax: rows=%d V=%d ld=%d", rows, V, ld);
     hipLaunchKernelGGL(argmax_f32_kernel, dim3(rows), dim3(256), 0, ST, x, (long*)out, V, ld);
     MOLLY_LAUNCH_CHECK();
@@ -1320,6 +1334,7 @@ extern "C" int molly_argmax_f32(void* stream, const float* x, int64_t* out, int 
 }
 
 extern "C" int molly_sum_f32(void* stream, const float* x, long n, const float* scale, float* out, int accumulate) {
+    MOLLY_ENTER();
     hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, ST, x, n, scale, out, accumulate);
     MOLLY_LAUNCH_CHECK();
     return 0;
@@ -1327,6 +1342,7 @@ extern "C" int molly_sum_f32(void* stream, const float* x, long n, const float* 
 
 extern "C" int molly_layernorm_fwd(void* stream, const void* x, const void* w, const void* b, void* y, int rows, int H,
                                    float eps) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "layernorm: bad H=%d", H);
 #define LN_FWD(NC)                                                                                                 \
     hipLaunchKernelGGL(layernorm_fwd_kernel<NC>, dim3(cdiv(rows, 4)), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)w, \
@@ -1342,6 +1358,7 @@ extern "C" int molly_layernorm_bwd_blocks(int rows) { return grid_for(rows, 4, 1
 extern "C" int molly_layernorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres, void* dx,
                                    void* dw, void* db, int dw_f32, int dw_accumulate, float* workspace, int rows, int H,
                                    float eps) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && H % 8 == 0 && H <= RN_MAXC * 512, "layernorm_bwd: bad H=%d", H);
     MOLLY_CHECK(workspace && dw && db, "layernorm_bwd: workspace of 2*molly_layernorm_bwd_blocks(rows)*H floats, dw, db required");
     const int nb = molly_layernorm_bwd_blocks(rows);
@@ -1359,6 +1376,7 @@ extern "C" int molly_layernorm_bwd(void* stream, const void* x, const void* w, c
 }
 
 extern "C" int molly_gelu_fwd(void* stream, const void* z, void* out, long n) {
+    MOLLY_ENTER();
     MOLLY_CHECK(n > 0 && n % 8 == 0, "gelu_fwd: n=%ld must be a positive multiple of 8", n);
     hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, ST, (const bf16_t*)z, (bf16_t*)out, n / 8);
     MOLLY_LAUNCH_CHECK();
@@ -1366,6 +1384,7 @@ extern "C" int molly_gelu_fwd(void* stream, const void* z, void* out, long n) {
 }
 
 extern "C" int molly_gelu_bwd(void* stream, const void* z, const void* dout, void* dz, long n) {
+    MOLLY_ENTER();
     MOLLY_CHECK(n > 0 && n % 8 == 0, "gelu_bwd: n=%ld must be a positive multiple of 8", n);
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, ST, (const bf16_t*)z, (const bf16_t*)dout,
                        (bf16_t*)dz, n / 8);
@@ -1376,6 +1395,7 @@ extern "C" int molly_gelu_bwd(void* stream, const void* z, const void* dout, voi
 extern "C" int molly_esm_embed(void* stream, const int64_t* ids, const void* word_emb, const void* pos_emb, void* out,
                                int* pos_ids_out, int* kv_len_out, int n_seq, int K, int H, int pad_id, int mask_id,
                                int token_dropout) {
+    MOLLY_ENTER();
     MOLLY_CHECK(n_seq > 0 && K > 0 && K <= 8192 && H % 8 == 0, "esm_embed: bad shape n_seq=%d K=%d H=%d", n_seq, K, H);
     // enough blocks to fill the chip whatever the number of sequences (one block per sequence left 8 CUs busy)
     const int parts = max(1, min(K / 8, cdiv(1024, n_seq)));
@@ -1389,6 +1409,7 @@ extern "C" int molly_esm_embed(void* stream, const int64_t* ids, const void* wor
 extern "C" int molly_sqnorm_blocks(void) { return 1024; }
 
 extern "C" int molly_sqnorm_bf16(void* stream, const void* g, long n, float* workspace, float* out, int accumulate) {
+    MOLLY_ENTER();
     MOLLY_CHECK(workspace && ((uintptr_t)g % 16) == 0, "sqnorm: workspace required, 16-byte aligned input");
     const int nb = molly_sqnorm_blocks();
     hipLaunchKernelGGL(sqnorm_part_kernel, dim3(nb), dim3(256), 0, ST, (const bf16_t*)g, n, workspace);
@@ -1400,6 +1421,7 @@ extern "C" int molly_sqnorm_bf16(void* stream, const void* g, long n, float* wor
 }
 
 extern "C" int molly_reduce_rows_bf16(void* stream, const void* in, int rows, long n, void* out) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows >= 1 && n >= 0 && n % 8 == 0, "reduce_rows: rows=%d, n=%ld must be a multiple of 8", rows, n);
     MOLLY_CHECK(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "reduce_rows: buffers must be 16-byte aligned");
     if (n == 0) return 0;
@@ -1410,6 +1432,7 @@ extern "C" int molly_reduce_rows_bf16(void* stream, const void* in, int rows, lo
 
 extern "C" int molly_clip_coef(void* stream, const float* norm_sq, float max_norm, float pre_scale, float* norm_out,
                                float* coef_out, float* skipped_count_or_null) {
+    MOLLY_ENTER();
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST, norm_sq, max_norm, pre_scale, norm_out, coef_out,
                        skipped_count_or_null);
     MOLLY_LAUNCH_CHECK();
@@ -1419,6 +1442,7 @@ extern "C" int molly_clip_coef(void* stream, const float* norm_sq, float max_nor
 extern "C" int molly_adamw_step(void* stream, float* master, float* exp_avg, float* exp_avg_sq, const void* grad,
                                 void* param_out, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, const float* grad_scale, const float* skipped_count_or_null) {
+    MOLLY_ENTER();
     MOLLY_CHECK(n % 4 == 0 && step >= 1, "adamw: n=%ld must be a multiple of 4 and step >= 1", n);
     if (n == 0) return 0;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ST, master, exp_avg, exp_avg_sq,
@@ -1433,6 +1457,7 @@ extern "C" int molly_colsum_parts(int rows) { return rows >= 1024 ? 64 : (rows >
 
 extern "C" int molly_colsum_bf16(void* stream, const void* x, int rows, int H, int ld, void* out, int out_f32,
                                  int accumulate, float* workspace) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && H > 0 && H % 4 == 0 && workspace,
                 "colsum: H=%d must be a positive multiple of 4; workspace of molly_colsum_parts(rows)*H floats required", H);
     const int np = molly_colsum_parts(rows);
@@ -1445,6 +1470,7 @@ extern "C" int molly_colsum_bf16(void* stream, const void* x, int rows, int H, i
 }
 
 extern "C" int molly_cast_f32_to_bf16(void* stream, const float* in, void* out, long n) {
+    MOLLY_ENTER();
     if (n == 0) return 0;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, ST, in, (bf16_t*)out, n);
     MOLLY_LAUNCH_CHECK();
@@ -1452,6 +1478,7 @@ extern "C" int molly_cast_f32_to_bf16(void* stream, const float* in, void* out, 
 }
 
 extern "C" int molly_cast_bf16_to_f32(void* stream, const void* in, float* out, long n) {
+    MOLLY_ENTER();
     if (n == 0) return 0;
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, ST, (const bf16_t*)in, out, n);
     MOLLY_LAUNCH_CHECK();

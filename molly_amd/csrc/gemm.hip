@@ -871,6 +871,7 @@ int g_force_tile = 0;
 
 int launch_gemm(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
                 int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
+    MOLLY_ENTER();
     MOLLY_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     MOLLY_CHECK((at && bt) || K % 64 == 0, "gemm: K=%d must be a multiple of %d when an operand is k-contiguous", K, 64);
     MOLLY_CHECK(N % 4 == 0 || (flags & MOLLY_GEMM_TRANS_OUT), "gemm: N=%d must be a multiple of 4", N);
@@ -953,6 +954,7 @@ extern "C" int molly_gemm_set_group_m(int g) {
 }
 
 extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {
+    MOLLY_ENTER();
     MOLLY_CHECK(problems && count >= 1 && count <= 16, "gemm_grouped: 1..16 problems (count=%d)", count);
     MOLLY_CHECK(K > 0 && !(flags & ~(MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_OUT_F32)),
                 "gemm_grouped: K=%d, flags 0x%x (accumulate / fp32 output only)", K, flags);

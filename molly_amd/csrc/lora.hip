@@ -49,6 +49,7 @@ inline int grid_for(long items) { return (int)((items + 255) / 256 < 4096 ? (ite
 }  // namespace
 
 extern "C" int molly_dropout_bf16(void* stream, const void* x, void* out, long n, float p, uint64_t seed, int accumulate) {
+    MOLLY_ENTER();
     MOLLY_CHECK(n > 0 && n % 8 == 0, "dropout: n=%ld must be a positive multiple of 8", n);
     MOLLY_CHECK(p >= 0.f && p < 1.f, "dropout: p=%f not in [0,1)", (double)p);
     const uint32_t thr = (uint32_t)(p * 65536.f + 0.5f);
@@ -63,6 +64,7 @@ extern "C" int molly_dropout_bf16(void* stream, const void* x, void* out, long n
 }
 
 extern "C" int molly_scale_bf16(void* stream, void* x, long n, float s) {
+    MOLLY_ENTER();
     MOLLY_CHECK(n > 0 && n % 8 == 0, "scale: n=%ld must be a positive multiple of 8", n);
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n / 8, s);
     MOLLY_LAUNCH_CHECK();

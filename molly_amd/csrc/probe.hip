@@ -36,11 +36,13 @@ __global__ void probe_tr16(const bf16_t* tile, bf16_t* out, int stride) {
 }  // namespace
 
 extern "C" int molly_probe_mfma16(void* stream, const void* A, const void* B, float* D) {
+    MOLLY_ENTER();
     hipLaunchKernelGGL(probe_mfma16, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)B, D);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int molly_probe_tr16(void* stream, const void* tile, void* out, int stride) {
+    MOLLY_ENTER();
     MOLLY_CHECK(stride >= 16 && stride % 4 == 0 && stride <= 512, "probe_tr16: bad stride %d", stride);
     hipLaunchKernelGGL(probe_tr16, dim3(1), dim3(64), 16 * stride * 2, (hipStream_t)stream, (const bf16_t*)tile,
                        (bf16_t*)out, stride);

@@ -148,6 +148,7 @@ extern "C" int molly_sample_logits(void* stream, float* logits, int rows, int V,
                                    int ld_generated, float repetition_penalty, float temperature, int top_k, float top_p,
                                    uint64_t seed, int step, int64_t* next_token, float* probs_out_or_null,
                                    int64_t* ids_out_or_null, int* n_out_or_null, int cap_out) {
+    MOLLY_ENTER();
     MOLLY_CHECK(rows > 0 && V > 0 && ld >= V, "sample_logits: rows=%d V=%d ld=%d", rows, V, ld);
     MOLLY_CHECK(top_k >= 1 && top_k <= CAP, "sample_logits: top_k=%d outside 1..%d (no-top-k sampling is not built)", top_k, CAP);
     MOLLY_CHECK(temperature > 0.f && top_p > 0.f && repetition_penalty > 0.f, "sample_logits: temperature / top_p / penalty must be > 0");

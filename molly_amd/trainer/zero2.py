@@ -119,13 +119,25 @@ def preflight_collectives(device, group=None, n_per_rank: int = 4096) -> dict:
         comm = _DistComm(group, staged=staged)
         buf = fresh()
         mine = buf[rank * n_per_rank:(rank + 1) * n_per_rank]
-        comm.reduce_scatter(mine, buf)
-        ok_rs = bool(torch.equal(mine.float(), want_sum[rank * n_per_rank:(rank + 1) * n_per_rank]))
+        try:                                    # a backend may also REFUSE the aliased form outright: same verdict as a wrong sum
+            comm.reduce_scatter(mine, buf)
+            ok_rs = bool(torch.equal(mine.float(), want_sum[rank * n_per_rank:(rank + 1) * n_per_rank]))
+        except (RuntimeError, ValueError) as e:
+            if staged:
+                raise
+            rep["inplace_error"] = str(e)[:200]
+            ok_rs = False
         buf2 = torch.zeros(n_per_rank * world, dtype=torch.bfloat16, device=device)
         buf2[rank * n_per_rank:(rank + 1) * n_per_rank] = rank + 1
-        comm.all_gather(buf2, buf2[rank * n_per_rank:(rank + 1) * n_per_rank])
         want_ag = (torch.arange(n_per_rank * world, device=device) // n_per_rank + 1).float()
-        ok_ag = bool(torch.equal(buf2.float(), want_ag))
+        try:
+            comm.all_gather(buf2, buf2[rank * n_per_rank:(rank + 1) * n_per_rank])
+            ok_ag = bool(torch.equal(buf2.float(), want_ag))
+        except (RuntimeError, ValueError) as e:
+            if staged:
+                raise
+            rep["inplace_error"] = str(e)[:200]
+            ok_ag = False
         flags = torch.tensor([float(ok_rs), float(ok_ag)], device=device)
         dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)              # every rank takes the same decision
         ok_rs, ok_ag = bool(flags[0] > 0), bool(flags[1] > 0)
