@@ -72,6 +72,7 @@ int molly_gemm_set_workspace(void* ptr, long bytes);
 /* configuration the most recent GEMM call used: 128 (128x128 kernel) | 512 (the 256x256 ping-pong kernel) + 1000 * split-K factor */
 int molly_gemm_last_config(void);
 /* tuning hook: M-tiles per group in the 256x256 kernel's tile walk (L2 locality; default 4) */
+int molly_gemm_set_small_grid_tile(int tile);   /* A/B knob: 128 (default) | 512 for grids that fill the chip neither plain nor split-K */
 int molly_gemm_set_group_m(int g);
 /* tuning hook: resident blocks of the persistent 256x256 kernel (default 256 = one per CU; multiple of 8);
  * 0 = launch one block per tile. */

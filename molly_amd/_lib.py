@@ -48,6 +48,23 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[Tuple[str, 
     return protos
 
 
+def _bind_torch_hip_runtime():
+    """ONE HIP runtime per process.  libmolly_hip.so needs `libamdhip64.so.7`; PyTorch's ROCm wheels bundle their own copy under
+    torch/lib with the same soname and load it lazily (at the first torch.cuda call, not at `import torch`).  Loaded before
+    that, this library pulled in the system runtime (/opt/rocm) and the process ended up with two: kernels launched through one
+    onto streams and buffers owned by the other — which happens to work for plain launches, and fails where a launch consults
+    the runtime's device state (rocPRIM's radix sort inside molly_batch_assemble: "no ROCm-capable device is detected"; found by
+    the world-2 smoke in round 2).  Loading torch's copy first (RTLD_GLOBAL, no device is touched) makes the dynamic loader
+    resolve our dependency to it, whatever the import order of the caller."""
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except (ImportError, OSError):
+        pass                      # no torch / no bundled runtime: the system runtime is the only one there is
+
+
 class MollyLib:
     def __init__(self, path: str = LIB_PATH):
         if not os.path.exists(path):
@@ -55,6 +72,7 @@ class MollyLib:
                 f"molly_amd: HIP library {path} is missing — build it with `python -m molly_amd.build` "
                 f"(or __graft_entry__.build()).  There is no CPU fallback.")
         self.path = path
+        _bind_torch_hip_runtime()
         self.cdll = ctypes.CDLL(path)
         self.protos = parse_header()
         self.fn = {}

@@ -777,6 +777,7 @@ int g_schedule = -1;              // 256x256 kernel: -1 = per form, 0 = four pha
 // means four phases everywhere; 1 still selects two.
 inline bool two_phase(bool /*b_kmajor*/) { return g_schedule == 1; }
 int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile
+int g_small_grid_tile = 128;     // kernel for grids that fill the chip neither plain nor split: 128 (128x128 ring) | 512 (256x256)
 int g_min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
 int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
 float* g_ws = nullptr;
@@ -828,7 +829,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
                 p.splits = best;
                 p.ws = g_ws;
             } else {
-                force_tile = TO ? 512 : 128;                   // transposed output exists in the 256x256 kernel only
+                force_tile = TO ? 512 : g_small_grid_tile;     // transposed output exists in the 256x256 kernel only
             }
         }
     }
@@ -946,6 +947,12 @@ extern "C" int molly_gemm_set_workspace(void* ptr, long bytes) {
 // which kernel configuration the most recent molly_gemm_* call on this thread's library instance used:
 // 128 = 128x128 tile, 256 = 256x128 ring, 512 = 256x256 ping-pong kernel; + 1000 * split-K factor
 extern "C" int molly_gemm_last_config(void) { return g_last_cfg; }
+
+extern "C" int molly_gemm_set_small_grid_tile(int tile) {
+    MOLLY_CHECK(tile == 128 || tile == 512, "gemm_set_small_grid_tile: 128 or 512 (got %d)", tile);
+    g_small_grid_tile = tile;
+    return 0;
+}
 
 extern "C" int molly_gemm_set_group_m(int g) {
     MOLLY_CHECK(g >= 1 && g <= 64, "gemm_set_group_m: %d", g);

@@ -58,3 +58,17 @@ def test_asm_issued_lds_dma_has_no_sgpr_hazard():
                        timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 hazards" in r.stdout
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """Loading the library before torch has loaded its bundled HIP runtime must not pull in a second one (round 2: with two
+    runtimes rocPRIM's radix sort inside molly_batch_assemble found "no ROCm-capable device")."""
+    import subprocess
+    import sys
+    code = "\n".join(["import sys; sys.path.insert(0, %r)" % ROOT, "from molly_amd import _lib", "_lib.lib()",
+                      "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})",
+                      "print('LIBS', len(libs), libs)"])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("LIBS")][-1]
+    assert line.split()[1] == "1", line
