@@ -13,6 +13,12 @@
  *  - bf16 tensors are uint16 storage, row-major, innermost dimension contiguous; `ld*` are in ELEMENTS;
  *  - return 0 on success; non-zero on a rejected argument or launch failure, message via
  *    molly_last_error() (thread-local).  Nothing is silently ignored.
+ *  - threading: ONE host thread drives the library per process — the reference's process model (one Python process per GPU,
+ *    a single host thread calls the model: SURVEY.md 8b; src/train.py:602-603).  The error message is thread-local, but the
+ *    tuning knobs (molly_gemm_set_*, molly_gemm_set_workspace, molly_gemm_force_tile) and molly_gemm_last_config() are
+ *    process-wide and unsynchronised: set them before launching, from that thread.  Launching from several host threads or
+ *    onto several streams concurrently is supported only with the knobs left alone and split-K scratch not shared
+ *    (molly_gemm_set_workspace(NULL, 0) disables split-K).
  */
 #ifndef MOLLY_HIP_H
 #define MOLLY_HIP_H

@@ -902,7 +902,7 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
     if (flags & MOLLY_GEMM_SWIGLU) {
         MOLLY_CHECK(!at && !bt && flags == MOLLY_GEMM_SWIGLU && res && N % 256 == 0 && ldres % 4 == 0,
                     "gemm: MOLLY_GEMM_SWIGLU is the plain NT form with N = 2*ff, ff %% 128 == 0 (N=%d), res = the activation output", N);
-        launch_cfg<false, false>(st, p, 512);                  // the 256x256 kernel, one pass (no split-K slabs)
+        if (launch_cfg<false, false>(st, p, 512)) return 1;    // the 256x256 kernel, one pass (no split-K slabs)
         MOLLY_LAUNCH_CHECK();
         return 0;
     }
@@ -911,10 +911,13 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
         MOLLY_CHECK(!(flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_GELU | MOLLY_GEMM_RESIDUAL)) && M % 4 == 0,
                     "gemm: MOLLY_GEMM_TRANS_OUT takes no bias/GELU/residual and needs M %% 4 == 0");
         if (launch_cfg<false, true, true>(st, p, g_force_tile == 0 ? 0 : 512)) return 1;
-    } else if (!at && !bt) launch_cfg<false, false>(st, p, g_force_tile);
-    else if (!at && bt) launch_cfg<false, true>(st, p, g_force_tile);
-    else if (at && bt) launch_cfg<true, true>(st, p, g_force_tile);
-    else {
+    } else if (!at && !bt) {
+        if (launch_cfg<false, false>(st, p, g_force_tile)) return 1;
+    } else if (!at && bt) {
+        if (launch_cfg<false, true>(st, p, g_force_tile)) return 1;
+    } else if (at && bt) {
+        if (launch_cfg<true, true>(st, p, g_force_tile)) return 1;
+    } else {
         molly_set_error("gemm: the (k-major A, k-contiguous B) form is not on the hot path and not built");
         return 1;
     }
