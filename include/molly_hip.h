@@ -45,11 +45,16 @@ enum {
     MOLLY_GEMM_OUT_F32 = 16,    /* C is fp32 instead of bf16                      */
     MOLLY_GEMM_TRANS_OUT = 32,  /* store C^T: the output buffer is [N][M] (ldc >= M); molly_gemm_bf16 with a_kmajor=0,
                                    b_kmajor=1 only — the wgrad form  dW[N',K'] = (x^T)[K',tok] dy[tok,N']  stored as dW */
-    MOLLY_GEMM_SWIGLU = 64      /* Qwen3MLP's gate|up projection with the activation fused (HF:models/qwen3/modeling_qwen3.py:
+    MOLLY_GEMM_SWIGLU = 64,     /* Qwen3MLP's gate|up projection with the activation fused (HF:models/qwen3/modeling_qwen3.py:
                                    76-83, Liger swiglu in the reference: src/train.py:130-132): B = [gate_proj | up_proj] weights
                                    ([2*ff][K]), C = [gate | up] [M][2*ff] as usual, and `res` is an OUTPUT: act[M][ff] (ldres)
                                    = silu(gate) * up, bit-identical to molly_swiglu_fwd on C.  NT form, ff % 128 == 0, no
                                    other flag. */
+    MOLLY_GEMM_SWIGLU_BWD = 128 /* the backward of the same activation fused into the down-projection's dgrad (what autograd runs
+                                   as a GEMM + Liger's swiglu backward): molly_gemm_bf16(A = d(out) [M][h], B = down_proj.weight
+                                   [h][ff] k-major, a_kmajor = 0, b_kmajor = 1), N = ff; `res` = [gate | up] [M][2*ff] (ldres) is
+                                   READ and C = d[gate | up] [M][2*ff] (ldc) is written — d(act) never reaches HBM.  Bit-identical
+                                   to the dgrad GEMM followed by molly_swiglu_bwd.  No other flag. */
 };
 int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
                        int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags);

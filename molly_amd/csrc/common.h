@@ -52,6 +52,18 @@ template <typename T> __device__ __forceinline__ void st_stream(void* p, T v) {
 #endif
 }
 
+// SwiGLU backward on one packed bf16 pair (HF:models/qwen3/modeling_qwen3.py:82, act = silu(gate) * up):
+// d(gate) = d * up * sigmoid(g) * (1 + g * (1 - sigmoid(g))), d(up) = d * g * sigmoid(g).  Shared by molly_swiglu_bwd and the
+// MOLLY_GEMM_SWIGLU_BWD epilogue so that the two paths agree bit for bit.
+// returns {d(gate) pair, d(up) pair}
+__device__ __forceinline__ u32x2 swiglu_bwd_pair(uint32_t g, uint32_t u, uint32_t d) {
+    const float ga = bflo(g), gb = bfhi(g);
+    const float siga = 1.f / (1.f + __expf(-ga)), sigb = 1.f / (1.f + __expf(-gb));
+    const float da = bflo(d), db = bfhi(d);
+    return u32x2{pack_bf2(da * bflo(u) * siga * (1.f + ga * (1.f - siga)), db * bfhi(u) * sigb * (1.f + gb * (1.f - sigb))),
+                 pack_bf2(da * ga * siga, db * gb * sigb)};
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 step): one v_rcp, one v_exp, a 5-term Horner —
 // a third of libm erff's instruction count; the GELU epilogue of the ESM FFN GEMM is VALU-bound on it.
 __device__ __forceinline__ float fast_erf(float x) {

@@ -452,12 +452,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
         u32x4 og, ou;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float ga = bflo(g[e]), gb = bfhi(g[e]);
-            const float siga = 1.f / (1.f + __expf(-ga)), sigb = 1.f / (1.f + __expf(-gb));
-            const float da = bflo(d[e]), db = bfhi(d[e]);
-            og[e] = pack_bf2(da * bflo(u[e]) * siga * (1.f + ga * (1.f - siga)),
-                             db * bfhi(u[e]) * sigb * (1.f + gb * (1.f - sigb)));
-            ou[e] = pack_bf2(da * ga * siga, db * gb * sigb);
+            const u32x2 r = swiglu_bwd_pair(g[e], u[e], d[e]);
+            og[e] = r[0];
+            ou[e] = r[1];
         }
         st_stream<u32x4>(dgu + (size_t)r * 2 * ff + c * 8, og);
         st_stream<u32x4>(dgu + (size_t)r * 2 * ff + ff + c * 8, ou);

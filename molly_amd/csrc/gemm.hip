@@ -148,6 +148,52 @@ __device__ __forceinline__ void stage_km(const bf16_t* __restrict__ g, int ld, i
     }
 }
 
+// ---- The 256x256 kernel splits stage_kc / stage_km in two: the per-lane byte offsets of a half-tile (row / column clamps of a
+// ragged edge included) depend on the work item, not on the K-tile, so they are computed when the staged work item changes
+// (once per tile, ~10 vector instructions per half-tile) and every LDS-DMA piece of the K loop is then a wave-uniform base that
+// advances by a constant per K-tile plus one of these registers: no vector arithmetic, no per-piece edge test, ONE code path.
+// Returns the row / column the wave-uniform base has to point at.
+template <int ROWS, int NW, int BK>
+__device__ __forceinline__ int stage_offsets_kc(int ld, int row0, int rows_total, int wave, int lane, int remap_ff,
+                                                unsigned (&off)[ROWS / (64 / (BK / 8)) / NW]) {
+    constexpr int CPR = BK / 8, RPI = 64 / CPR, PER = ROWS / RPI / NW;
+    const int r_in = lane / CPR;
+    const int c_src = BK == 64 ? ((lane & 7) ^ r_in) : ((lane & 3) ^ ((r_in >> 2) & 3));
+    const int r0 = remap_ff ? row0 : (row0 < rows_total ? row0 : rows_total - 1);       // a half-tile may start past the last row
+    const int last = rows_total - 1 - r0;                                               // clamp: see stage_kc
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int rel = (wave * PER + i) * RPI + r_in;
+        if (remap_ff) rel = ((rel >> 5) & 1) * remap_ff + (rel >> 6) * 32 + (rel & 31);   // ff % 128 == 0: no ragged tile
+        else rel = rel < last ? rel : last;
+        off[i] = ((unsigned)rel * (unsigned)ld + (unsigned)(c_src * 8)) * 2u;
+    }
+    return r0;
+}
+template <int COLS, int NW, int BK>
+__device__ __forceinline__ int stage_offsets_km(int ld, int col0, int cols_total, int wave, int lane,
+                                                unsigned (&off)[BK * COLS * 2 / 1024 / NW]) {
+    constexpr int NCB = COLS / 16, PER = BK * COLS * 2 / 1024 / NW;
+    const int c0 = col0 <= cols_total - 8 ? col0 : cols_total - 8;
+    const int last = cols_total - 8 - c0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int P = (wave * PER + i) * 64 + lane;
+        const int blk = P >> 3, cin = P & 7;
+        const int kblk = blk / NCB, cbs = blk % NCB;
+        const int kr = kblk * 4 + (cin >> 1);
+        int rel = col0 - c0 + ((cbs ^ ((kblk >> 1) & 1)) << 4) + ((cin & 1) << 3);
+        rel = rel < last ? rel : last;
+        off[i] = ((unsigned)kr * (unsigned)ld + (unsigned)rel) * 2u;
+    }
+    return c0;
+}
+template <int PER, bool HIDE>
+__device__ __forceinline__ void stage_pre(const char* base, const unsigned (&off)[PER], bf16_t* lds_tile, int wave) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) dma16<HIDE>(base, off[i], lds_tile + (wave * PER + i) * 512);
+}
+
 // fragment for mfma_16x16x32: lane (i = lane&15, g = lane>>4) gets tile[k = 32*kk + 8g + j][col16 + i], j = 0..7
 // (col16 a multiple of 16; kk, col16 compile-time / wave-uniform at the call sites)
 template <int COLS>
@@ -336,6 +382,26 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 // and the epilogue flags; each keeps its own pointers, sizes and transposed-output choice (TO is ignored).  The weight-
 // gradient GEMMs of one decoder layer are 64 + 128 + 192 + 384 = 768 tiles = three full rounds of 256 CUs: one launch, no
 // split-K slabs, no reduce launches.
+// (nontemporal epilogue stores measured 3x the fixed cost per tile: 8-byte pieces written through)
+// The epilogue's lane-row regrouping of a register pair (x0, x1) = quads (j even, j odd) of one accumulator row: swap the
+// register index with lane bit 5 (v_permlane32_swap), then with lane bit 4 (v_permlane16_swap).  Written as asm with both
+// registers read-write: the clang builtins return the pair by value, and hipcc (ROCm 7.2) folded chains of them over vector
+// elements into wrong code (3 of 4 columns of the residual path; the same family as the permlane32_swap(u, u) fold recorded in
+// attention.hip).
+__device__ __forceinline__ void regroup_rows(unsigned& x0, unsigned& x1) {
+    // (hipcc pads no hazards inside an asm string: two wait states around each swap cover a VALU write of its operands before
+    // it and a VALU read of its results after it)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+}
+
+#ifndef MOLLY_GEMM_NT_EPILOGUE
+#define MOLLY_GEMM_NT_EPILOGUE 0
+#endif
+#if MOLLY_GEMM_NT_EPILOGUE
+#define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<u32x2*>(ptr))
+#else
+#define EPI_STORE(ptr, val) (*reinterpret_cast<u32x2*>(ptr) = (val))
+#endif
 template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
@@ -350,64 +416,126 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // is more than one round, so a block's XCD label v&7 never changes).  The first two K-tiles of the NEXT tile are issued
     // before the epilogue stores of the current one, so neither the prologue load latency nor the store tail idles the
     // matrix pipe between tiles.
-    // the problem the block is working on (never changes outside a grouped launch)
-    const bf16_t* cA = p.A; const bf16_t* cB = p.B; void* cC = p.C;
-    int cM = p.M, cN = p.N, clda = p.lda, cldb = p.ldb, cldc = p.ldc, ctm = p.tiles_m, ctn = p.tiles_n;
-    bool cto = TO;
+    // One work item: the problem it belongs to (never changes outside a grouped launch), its tile and its K-slice
+    struct Tile { int gi, m0, n0, split, kt0, nk; };       // gi = problem of a grouped launch (0 otherwise)
+    // the problem's operands: launch constants outside a grouped launch (three Tile values are live in the K loop: kept small)
+    auto tA = [&](const Tile& t) { return GRP ? p.grp[t.gi].A : p.A; };
+    auto tB = [&](const Tile& t) { return GRP ? p.grp[t.gi].B : p.B; };
+    auto tC = [&](const Tile& t) { return GRP ? p.grp[t.gi].C : p.C; };
+    auto tM = [&](const Tile& t) { return GRP ? p.grp[t.gi].M : p.M; };
+    auto tN = [&](const Tile& t) { return GRP ? p.grp[t.gi].N : p.N; };
+    auto tlda = [&](const Tile& t) { return GRP ? p.grp[t.gi].lda : p.lda; };
+    auto tldb = [&](const Tile& t) { return GRP ? p.grp[t.gi].ldb : p.ldb; };
+    auto tldc = [&](const Tile& t) { return GRP ? p.grp[t.gi].ldc : p.ldc; };
+    auto tto = [&](const Tile& t) { return GRP ? p.grp[t.gi].trans_out != 0 : TO; };
     const int nwork = GRP ? p.grp[p.ngroup - 1].work0 + p.grp[p.ngroup - 1].tiles_m * p.grp[p.ngroup - 1].tiles_n
                           : p.tiles_m * p.tiles_n * p.splits;
-    int ntile = p.tiles_m * p.tiles_n;
     const int nk_all = (p.K + BK - 1) / BK;
-    int m0, n0, split, kt0, nk;
-    auto decode = [&](int v) {
+    auto decode = [&](int v) -> Tile {
+        Tile t;
+        t.gi = 0;
+        int ctm = p.tiles_m, ctn = p.tiles_n;
         const int q = nwork >> 3, r = nwork & 7, xcd = v & 7;
         int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
         if constexpr (GRP) {
             int gi = 0;
 #pragma unroll
-            for (int t = 1; t < 16; ++t)
-                if (t < p.ngroup && work >= p.grp[t].work0) gi = t;
+            for (int i = 1; i < 16; ++i)
+                if (i < p.ngroup && work >= p.grp[i].work0) gi = i;
             const GemmArgs::Group& G = p.grp[gi];
-            cA = G.A; cB = G.B; cC = G.C; cM = G.M; cN = G.N; clda = G.lda; cldb = G.ldb; cldc = G.ldc;
-            ctm = G.tiles_m; ctn = G.tiles_n; cto = G.trans_out != 0;
+            t.gi = gi;
+            ctm = G.tiles_m; ctn = G.tiles_n;
             work -= G.work0;
-            ntile = ctm * ctn;
         }
+        const int ntile = ctm * ctn;
         // K-slice is the SLOWEST index: the work items that run side by side on one XCD then belong to one slice and
         // keep sharing operand panels through its L2 (slices of one tile share nothing: they read different K ranges)
-        split = work / ntile;
-        const int swz = work - split * ntile;
+        t.split = work / ntile;
+        const int swz = work - t.split * ntile;
         const int GROUP_M = p.group_m;
         const int per_group = GROUP_M * ctn;
         const int grp = swz / per_group;
         const int first_m = grp * GROUP_M;
         const int gsz = min(ctm - first_m, GROUP_M);
-        m0 = (first_m + (swz % per_group) % gsz) * 256;
-        n0 = ((swz % per_group) / gsz) * 256;
-        kt0 = (int)((long)nk_all * split / p.splits);
-        nk = (int)((long)nk_all * (split + 1) / p.splits) - kt0;      // K-tiles of this slice
+        t.m0 = (first_m + (swz % per_group) % gsz) * 256;
+        t.n0 = ((swz % per_group) / gsz) * 256;
+        t.kt0 = (int)((long)nk_all * t.split / p.splits);
+        t.nk = (int)((long)nk_all * (t.split + 1) / p.splits) - t.kt0;      // K-tiles of this slice
+        return t;
     };
     int vcur = blockIdx.x;
-    decode(vcur);
+    Tile cur = decode(vcur);
 
     f32x4 acc[8][4];
     // LDS = 10 half-tile slots (all 160 KiB): A triple-buffered [3][A0|A1], then B double-buffered [2][B0|B1]
-    // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 ; ktl is slice-local
-    auto issue = [&](int ktl, int which) {
-        // P2 schedule: wave group 0 stages the A half-tiles, group 1 the B half-tiles (8 LDS-DMA per wave per K-tile either way)
-        if (P2 && ((which < 2) != (wr == 0))) return;
-        const int wi = P2 ? wc : wave;
-        const int kt = kt0 + ktl;
-        bf16_t* dst = which < 2 ? smem + ((ktl % 3) * 2 + which) * HT : smem + (6 + (ktl & 1) * 2 + (which - 2)) * HT;
-        if (which < 2) {
-            if (AT) stage_km<128, NWI, BK, true>(cA, clda, m0 + which * 128, cM, kt * BK, p.K, p.zeros, dst, wi, lane);
-            else stage_kc<128, NWI, BK, true>(cA, clda, m0 + which * 128, cM, kt * BK, dst, wi, lane);
-        } else {
-            if (BT) stage_km<128, NWI, BK, true>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, p.K, p.zeros, dst, wi, lane);
-            else if (!AT && !TO && !GRP && (p.flags & MOLLY_GEMM_SWIGLU))
-                stage_kc<128, NWI, BK, true>(cB, cldb, (n0 >> 1) + (which - 2) * 64, cN, kt * BK, dst, wi, lane, cN >> 1);
-            else stage_kc<128, NWI, BK, true>(cB, cldb, n0 + (which - 2) * 128, cN, kt * BK, dst, wi, lane);
+    constexpr int SPER = 128 / 8 / NWI;               // LDS-DMA pieces per wave per half-tile (2; two-phase schedule: 4)
+    const bool swiglu_b = !AT && !BT && !TO && !GRP && (p.flags & MOLLY_GEMM_SWIGLU);
+    // The STAGING STREAM: the work item whose K-tiles are being staged (under the rolling prefetch it runs two K-tiles ahead of
+    // the one being computed and switches to the next work item in the middle of the K loop): its operands (launch constants
+    // outside a grouped launch), the slice-local index of the K-tile it stages next, per half-tile the per-lane byte offsets
+    // (off0..3: A0, A1, B0, B1) and a running wave-uniform source pointer that advances by a constant per K-tile.
+    const bf16_t* s_A = p.A; const bf16_t* s_B = p.B;
+    int s_M = p.M, s_N = p.N, s_lda = p.lda, s_ldb = p.ldb, s_m0 = 0, s_n0 = 0, s_kt0 = 0, s_ktl = 0;
+    const char* sp0 = nullptr; const char* sp1 = nullptr; const char* sp2 = nullptr; const char* sp3 = nullptr;
+    unsigned off0[SPER], off1[SPER], off2[SPER], off3[SPER];
+    int stepA = AT ? BK * p.lda * 2 : BK * 2, stepB = BT ? BK * p.ldb * 2 : BK * 2;            // bytes per K-tile
+    const bool k_full = p.K % BK == 0;                // a ragged last K-tile: both operands k-major only (host check)
+    auto set_stream = [&](const Tile& t) {
+        s_m0 = t.m0; s_n0 = t.n0; s_kt0 = t.kt0; s_ktl = 0;
+        if constexpr (GRP) {                          // per-problem operands and strides
+            const GemmArgs::Group& G = p.grp[t.gi];
+            s_A = G.A; s_B = G.B; s_M = G.M; s_N = G.N; s_lda = G.lda; s_ldb = G.ldb;
+            stepA = AT ? BK * s_lda * 2 : BK * 2; stepB = BT ? BK * s_ldb * 2 : BK * 2;
         }
+        const int wi = P2 ? wc : wave;
+        const long ka = AT ? (long)t.kt0 * BK * s_lda : (long)t.kt0 * BK, kb = BT ? (long)t.kt0 * BK * s_ldb : (long)t.kt0 * BK;
+        int a0, a1, b0, b1;                           // row (k-contiguous) / column (k-major) the base points at
+        if (AT) {
+            a0 = stage_offsets_km<128, NWI, BK>(s_lda, t.m0, s_M, wi, lane, off0);
+            a1 = stage_offsets_km<128, NWI, BK>(s_lda, t.m0 + 128, s_M, wi, lane, off1);
+        } else {
+            a0 = stage_offsets_kc<128, NWI, BK>(s_lda, t.m0, s_M, wi, lane, 0, off0);
+            a1 = stage_offsets_kc<128, NWI, BK>(s_lda, t.m0 + 128, s_M, wi, lane, 0, off1);
+        }
+        if (BT) {
+            b0 = stage_offsets_km<128, NWI, BK>(s_ldb, t.n0, s_N, wi, lane, off2);
+            b1 = stage_offsets_km<128, NWI, BK>(s_ldb, t.n0 + 128, s_N, wi, lane, off3);
+        } else if (swiglu_b) {
+            b0 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0 >> 1, s_N, wi, lane, s_N >> 1, off2);
+            b1 = stage_offsets_kc<128, NWI, BK>(s_ldb, (t.n0 >> 1) + 64, s_N, wi, lane, s_N >> 1, off3);
+        } else {
+            b0 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0, s_N, wi, lane, 0, off2);
+            b1 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0 + 128, s_N, wi, lane, 0, off3);
+        }
+        sp0 = reinterpret_cast<const char*>(s_A + ka + (AT ? (long)a0 : (long)a0 * s_lda));
+        sp1 = reinterpret_cast<const char*>(s_A + ka + (AT ? (long)a1 : (long)a1 * s_lda));
+        sp2 = reinterpret_cast<const char*>(s_B + kb + (BT ? (long)b0 : (long)b0 * s_ldb));
+        sp3 = reinterpret_cast<const char*>(s_B + kb + (BT ? (long)b1 : (long)b1 * s_ldb));
+    };
+    // stage half-tile `which` (0 = A0, 1 = A1, 2 = B0, 3 = B1) of the stream's next K-tile into slots (ab, bb); the K-tile is
+    // complete after which == 3
+    auto stage_stream = [&](int which, int ab, int bb) {
+        if (P2 && ((which < 2) != (wr == 0))) { if (which == 3) ++s_ktl; return; }
+        const int wi = P2 ? wc : wave;
+        bf16_t* dst = which < 2 ? smem + (ab * 2 + which) * HT : smem + (6 + bb * 2 + (which - 2)) * HT;
+        bool done = false;
+        if constexpr (AT && BT) {
+            // a ragged last K-tile (contraction length not a multiple of 64): rows past K are read as exact zeros, lane by lane
+            if (!k_full && (s_kt0 + s_ktl + 1) * BK > p.K) {
+                const int kt = s_kt0 + s_ktl;
+                if (which < 2) stage_km<128, NWI, BK, true>(s_A, s_lda, s_m0 + which * 128, s_M, kt * BK, p.K, p.zeros, dst, wi, lane);
+                else stage_km<128, NWI, BK, true>(s_B, s_ldb, s_n0 + (which - 2) * 128, s_N, kt * BK, p.K, p.zeros, dst, wi, lane);
+                done = true;
+            }
+        }
+        if (!done) {
+            if (which == 0) stage_pre<SPER, true>(sp0, off0, dst, wi);
+            else if (which == 1) stage_pre<SPER, true>(sp1, off1, dst, wi);
+            else if (which == 2) stage_pre<SPER, true>(sp2, off2, dst, wi);
+            else stage_pre<SPER, true>(sp3, off3, dst, wi);
+        }
+        if (which == 0) sp0 += stepA; else if (which == 1) sp1 += stepA; else if (which == 2) sp2 += stepB; else sp3 += stepB;
+        if (which == 3) ++s_ktl;
     };
     const int fr = lane & 15, fq = lane >> 4;
     auto readA = [&](int abuf, int mh, bf16x8 (&af)[2][4]) {
@@ -446,12 +574,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     } while (0)
 
     // ---- prologue of the first tile: K-tiles 0 and 1 issued
-    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
-    if (nk > 1) { issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3); }
-    bool exact_stores = false;                // previous epilogue issued exactly 32 plain stores per lane (and no loads)
-    bool exact_stores48 = false;              // ... or exactly 48 (SwiGLU-fused epilogue: gate, up and activation quads)
+    set_stream(cur);
+    stage_stream(0, 0, 0); stage_stream(1, 0, 0); stage_stream(2, 0, 0); stage_stream(3, 0, 0);
+    if (cur.nk > 1) { stage_stream(0, 1, 1); stage_stream(1, 1, 1); stage_stream(2, 1, 1); stage_stream(3, 1, 1); }
+    // stores the previous epilogue left behind its loads, per lane, when that number is known (16: the fast paths' 16-byte
+    // stores; 32: plain 8-byte quads; 48: the SwiGLU-fused gate, up and activation quads); 0 = unknown: conservative waits
+    int pend_stores = 0;
+    // ROLLING prefetch (four-phase schedule, every slice >= 2 K-tiles): the staging pipeline does not drain at a tile boundary.
+    // K-tile T+2 of the loop is the NEXT work item's K-tile T+2-nk once T+2 >= nk, staged into the slot the ring would use
+    // anyway (abuf / bbuf keep rotating across tiles), so the next tile's first two K-tiles are in flight during this tile's last
+    // two and its K-tile 0 has landed — waited for by the loop's own counted vmcnt — before the epilogue starts.  Before: both
+    // were issued after the loop, every CU at the same moment (a 32 MB burst), and their latency was hidden only by the
+    // ~1.5 us epilogue: ~9 us of fixed cost per 256x256 tile = 6 K-tiles' worth, 16 % of a K = 2048 tile
+    // (tools/gemm_diag/run_kscan.py: time = fixed + per-K-tile * nk; run_tilestamp.py).
+    const bool roll = !P2 && !GRP && nk_all / p.splits >= 2;       // (grouped launches: 256-K-tile slices, per-problem strides)
+    bool landed0 = false;                     // K-tile 0 of the tile about to start has already been waited for
+    int abuf = 0, bbuf = 0;                   // LDS slots of the current K-tile (A: 0..2, B: 0..1)
 
     for (;;) {
+    const int vnext = vcur + gridDim.x;
+    const bool more = vnext < nwork;
+    const int nk = cur.nk;
+    const int t_stage_end = (roll && more) ? nk : nk - 2;       // loop iterations T < t_stage_end stage a K-tile (T + 2)
+    const bool cto = tto(cur);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -459,16 +604,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // wait for K-tile 0 only.  Outstanding, oldest first: [K-tile 0: 8][K-tile 1: 8 if nk > 1][previous epilogue stores].
     // vmcnt counts loads and stores together in issue order, so with exactly 32 stores behind the loads the counted wait
     // lets all of them (and K-tile 1) stay in flight; any other epilogue falls back to a conservative count.
-    if (exact_stores) {
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    } else if (exact_stores48) {
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-    } else {
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!landed0) {
+        if (nk > 1) {
+            if (pend_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (pend_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            else if (pend_stores == 48) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            if (pend_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (pend_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (pend_stores == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
+    // the first counted wait of a tile sits behind the previous epilogue's stores: [K-tile 1: 8][stores]
+    // [K-tile 2: 8] — K-tile 1 has landed once all but the stores and K-tile 2's pieces are done
+    const int first_wait = 8 + pend_stores;
     SEG_BARRIER();
     if (wr == 1) SEG_BARRIER();               // stagger: group 1 runs one segment behind group 0
 
@@ -479,7 +630,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // The only in-loop wait is P3's counted vmcnt(8): everything older than K-tile T+2's eight pieces — i.e. all of
     // K-tile T+1 — has landed; its first ds_read happens in the next phase, behind a barrier both groups have passed.
     bf16x8 af[2][4], b0[2][2], b1[2][2];
-    int abuf = 0;
+    // staging of loop K-tile T+2 (this work item's, or under the rolling prefetch the next one's) into the slots two ahead
+    auto stage2 = [&](int T, int which) {
+        const int a2 = abuf == 0 ? 2 : abuf - 1;                 // (abuf + 2) % 3; B: same parity as T
+        if (T < t_stage_end) stage_stream(which, a2, bbuf);
+    };
     if constexpr (P2) {
         auto kloop = [&](auto to_tag) {
         constexpr bool TOQ = decltype(to_tag)::value;
@@ -495,7 +650,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         // launcher picks per form.  (Staging B from group 1's LA — more flight time — was slower and races with group 0's
         // reads of that slot, which only return during the same segment.)
         for (int T = 0; T < nk; ++T) {
-            const int bbuf = T & 1;
             readB(bbuf, 0, b0);
             readB(bbuf, 1, b1);
             readA(abuf, 0, af);
@@ -507,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             SEG_BARRIER();
             readA(abuf, 1, af);
             if (T + 2 < nk) {
-                issue(T + 2, 0); issue(T + 2, 1); issue(T + 2, 2); issue(T + 2, 3);
+                stage2(T, 0); stage2(T, 1); stage2(T, 2); stage2(T, 3);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -519,6 +673,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             MMA_QUAD(1, 0, af, b0);
             SEG_BARRIER();
             abuf = abuf == 2 ? 0 : abuf + 1;
+            bbuf ^= 1;
         }
         };
         if constexpr (GRP) {
@@ -531,7 +686,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     auto kloop4 = [&](auto to_tag) {
     constexpr bool TOQ = decltype(to_tag)::value;
     for (int T = 0; T < nk; ++T) {
-        const int bbuf = T & 1;
+        // from here on the staged K-tiles are the next work item's (decoded again at the tile's end: a Tile kept live across the
+        // K loop costs more scalar registers than decoding twice)
+        if (T + 2 == nk && t_stage_end == nk) set_stream(decode(vnext));
         // ---- P0: quadrant (m0,n0)
         readB(bbuf, 0, b0);
         readA(abuf, 0, af);
@@ -542,7 +699,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         SEG_BARRIER();
         // ---- P1: quadrant (m0,n1)
         readB(bbuf, 1, b1);
-        if (T + 2 < nk) issue(T + 2, 0);
+        stage2(T, 0);
         SEG_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -550,16 +707,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         SEG_BARRIER();
         // ---- P2: quadrant (m1,n1)
         readA(abuf, 1, af);
-        if (T + 2 < nk) issue(T + 2, 1);
+        stage2(T, 1);
         SEG_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         MMA_QUAD(1, 1, af, b1);
         SEG_BARRIER();
         // ---- P3: quadrant (m1,n0); retire K-tile T+1
-        if (T + 2 < nk) {
-            issue(T + 2, 2); issue(T + 2, 3);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (T < t_stage_end) {
+            stage2(T, 2); stage2(T, 3);
+            if (T == 0 && first_wait != 8) {
+                if (first_wait == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                else if (first_wait == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -567,6 +730,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         MMA_QUAD(1, 0, af, b0);
         SEG_BARRIER();
         abuf = abuf == 2 ? 0 : abuf + 1;
+        bbuf ^= 1;
     }
     };
     if constexpr (GRP) {               // grouped launch: the output orientation is a per-problem property
@@ -578,23 +742,82 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
     if (wr == 0) SEG_BARRIER();               // balance the stagger barrier (every LDS read of this tile has returned)
 
-    // this tile's coordinates for the epilogue; then decode + prefetch the next tile BEFORE the stores
-    const int em0 = m0, en0 = n0, esplit = split;
-    void* const eC = cC;
-    const int eM = cM, eN = cN, eldc = cldc;
+    // this tile's coordinates for the epilogue.  Without the rolling prefetch (two-phase schedule, one-K-tile slices) the next
+    // tile's first two K-tiles are issued here, BEFORE the stores, into slots 0 and 1.
+    const int em0 = cur.m0, en0 = cur.n0, esplit = cur.split;
+    void* const eC = tC(cur);
+    const int eM = tM(cur), eN = tN(cur), eldc = tldc(cur);
     const bool eto = cto;
-    const int vnext = vcur + gridDim.x;
-    const bool more = vnext < nwork;
-    if (more) {
-        decode(vnext);
-        issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
-        if (nk > 1) { issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3); }
+    Tile nxt = cur;
+    if (more) nxt = decode(vnext);
+    if (more && !roll) {
+        abuf = 0; bbuf = 0;
+        set_stream(nxt);
+        stage_stream(0, 0, 0); stage_stream(1, 0, 0); stage_stream(2, 0, 0); stage_stream(3, 0, 0);
+        if (nxt.nk > 1) { stage_stream(0, 1, 1); stage_stream(1, 1, 1); stage_stream(2, 1, 1); stage_stream(3, 1, 1); }
     }
-    exact_stores = em0 + 256 <= eM && en0 + 256 <= eN &&
-                   !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU));
-    exact_stores48 = !AT && !BT && !TO && !GRP && em0 + 256 <= eM && en0 + 256 <= eN && p.flags == MOLLY_GEMM_SWIGLU;
-
-    if (GRP ? eto : TO) {
+    landed0 = roll && more;
+    // Fast paths first: a full interior tile with no epilogue flag (every qkv / dgrad launch) or with the residual add alone
+    // (o_proj, down_proj).  The accumulator layout gives a lane 4 consecutive columns of one row (8 bytes as bf16), and a
+    // wave-wide store of those touches 16 rows x 32 bytes: 4,096 32-byte requests per CU and tile, every CU at the same moment
+    // — stamped, the 32 stores of a tile took 4-7 us of a 55 us K = 2048 tile (tools/gemm_diag/run_tilestamp.py).  Two lane-row
+    // swaps per register pair (v_permlane32_swap, then v_permlane16_swap: a 3-cycle of the bits {register j&1, lane>>5,
+    // (lane>>4)&1}) regroup the quads so that lane-row fq holds columns s*32 + fq*8 .. +7 of its row for s = 0, 1: 16-byte
+    // stores, 64 contiguous bytes per row and instruction, half the requests and half the instructions.
+    const bool interior = em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && !(GRP ? eto : TO);
+    const bool fast16 = interior && (p.flags == 0 || p.flags == MOLLY_GEMM_RESIDUAL);
+    pend_stores = fast16 ? 16
+                : (em0 + 256 <= eM && en0 + 256 <= eN &&
+                   !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) ? 32
+                : (!AT && !BT && !TO && !GRP && em0 + 256 <= eM && en0 + 256 <= eN && p.flags == MOLLY_GEMM_SWIGLU) ? 48 : 0;
+    if (fast16) {
+        bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + en0 + wc * 64 + fq * 8;
+        if (p.flags == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bf16_t* c = c0 + (size_t)i * 16 * eldc;
+                unsigned d[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    d[j][0] = pack_bf2(acc[i][j][0], acc[i][j][1]);
+                    d[j][1] = pack_bf2(acc[i][j][2], acc[i][j][3]);
+                }
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        regroup_rows(d[2 * sh][w], d[2 * sh + 1][w]);
+                    }
+                    *reinterpret_cast<u32x4*>(c + sh * 32) = u32x4{d[2 * sh][0], d[2 * sh][1], d[2 * sh + 1][0], d[2 * sh + 1][1]};
+                }
+            }
+        } else {
+            const bf16_t* r0 = p.res + (size_t)(em0 + wr * 128 + fr) * p.ldres + en0 + wc * 64 + fq * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bf16_t* r = r0 + (size_t)i * 16 * p.ldres;
+                bf16_t* c = c0 + (size_t)i * 16 * eldc;
+                const u32x4 rv0 = *reinterpret_cast<const u32x4*>(r), rv1 = *reinterpret_cast<const u32x4*>(r + 32);
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    float v[2][4];                               // fp32 sums regrouped (one rounding, as before the regrouping)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (through named floats: __builtin_bit_cast applied to a vector ELEMENT read element 0 for every e)
+                        const float f0 = acc[i][2 * sh][e], f1 = acc[i][2 * sh + 1][e];
+                        unsigned x0 = __float_as_uint(f0), x1 = __float_as_uint(f1);
+                        regroup_rows(x0, x1);
+                        v[0][e] = __uint_as_float(x0);
+                        v[1][e] = __uint_as_float(x1);
+                    }
+                    const u32x4 rv = sh ? rv1 : rv0;
+                    *reinterpret_cast<u32x4*>(c + sh * 32) =
+                        u32x4{pack_bf2(v[0][0] + bflo(rv[0]), v[0][1] + bfhi(rv[0])), pack_bf2(v[0][2] + bflo(rv[1]), v[0][3] + bfhi(rv[1])),
+                              pack_bf2(v[1][0] + bflo(rv[2]), v[1][1] + bfhi(rv[2])), pack_bf2(v[1][2] + bflo(rv[3]), v[1][3] + bfhi(rv[3]))};
+                }
+            }
+        }
+    } else if (GRP ? eto : TO) {
         // transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr];
         // C^T is stored as [N][M] (ld = ldc), i.e. 4 consecutive m of one n -> 8-byte bf16 / 16-byte fp32 stores.
         const bool accum = p.flags & MOLLY_GEMM_ACCUMULATE, out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
@@ -671,6 +894,42 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 *reinterpret_cast<u32x2*>(act + (size_t)m * p.ldres + c) = o;
             }
         }
+    } else if (!AT && BT && !TO && !GRP && (p.flags & MOLLY_GEMM_SWIGLU_BWD)) {
+        // SwiGLU backward fused into the down-projection's dgrad: acc = d(act)[m][n], n < ff = N.  res = gu = [gate | up]
+        // [M][2ff] (ldres) is read, C = d(gu) [M][2ff] (ldc) is written: d(gate) at column n, d(up) at ff + n.  d(act) is rounded
+        // to bf16 first and the arithmetic is swiglu_bwd_pair (common.h), so the result is bit-identical to the dgrad GEMM
+        // followed by molly_swiglu_bwd — without d(act)'s round trip through HBM.
+        const int ff = eN;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = em0 + wr * 128 + i * 16 + fr;
+            if (m >= eM) continue;
+            u32x2 gq[4], uq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = en0 + wc * 64 + j * 16 + fq * 4;
+                if (n >= eN) continue;
+                const bf16_t* gp = p.res + (size_t)m * p.ldres + n;
+                gq[j] = *reinterpret_cast<const u32x2*>(gp);
+                uq[j] = *reinterpret_cast<const u32x2*>(gp + ff);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = en0 + wc * 64 + j * 16 + fq * 4;
+                if (n >= eN) continue;
+                const u32x2 dq = u32x2{pack_bf2(acc[i][j][0], acc[i][j][1]), pack_bf2(acc[i][j][2], acc[i][j][3])};
+                u32x2 og, ou;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const u32x2 r = swiglu_bwd_pair(gq[j][e], uq[j][e], dq[e]);
+                    og[e] = r[0];
+                    ou[e] = r[1];
+                }
+                bf16_t* c = reinterpret_cast<bf16_t*>(eC) + (size_t)m * eldc + n;
+                *reinterpret_cast<u32x2*>(c) = og;
+                *reinterpret_cast<u32x2*>(c + ff) = ou;
+            }
+        }
     } else {
 
     // ---- epilogue: lane owns C[m = .. + fr][n = .. + fq*4 + 0..3]
@@ -719,6 +978,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
     if (!more) break;
     vcur = vnext;
+    cur = nxt;
     }   // persistent tile loop
 #undef MMA_QUAD
 #undef SEG_BARRIER
@@ -903,6 +1163,14 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
         MOLLY_CHECK(!at && !bt && flags == MOLLY_GEMM_SWIGLU && res && N % 256 == 0 && ldres % 4 == 0,
                     "gemm: MOLLY_GEMM_SWIGLU is the plain NT form with N = 2*ff, ff %% 128 == 0 (N=%d), res = the activation output", N);
         if (launch_cfg<false, false>(st, p, 512)) return 1;    // the 256x256 kernel, one pass (no split-K slabs)
+        MOLLY_LAUNCH_CHECK();
+        return 0;
+    }
+    if (flags & MOLLY_GEMM_SWIGLU_BWD) {
+        MOLLY_CHECK(!at && bt && flags == MOLLY_GEMM_SWIGLU_BWD && res && ldres % 4 == 0 && ldres >= 2 * N && ldc >= 2 * N,
+                    "gemm: MOLLY_GEMM_SWIGLU_BWD is the dgrad form (k-contiguous A, k-major B) with N = ff (N=%d), res = [gate | up] "
+                    "[M][2*ff], C = d[gate | up] [M][2*ff]", N);
+        if (launch_cfg<false, true>(st, p, 512)) return 1;     // the 256x256 kernel, one pass (no split-K slabs)
         MOLLY_LAUNCH_CHECK();
         return 0;
     }

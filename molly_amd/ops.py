@@ -9,7 +9,7 @@ import torch
 from ._lib import lib
 
 BF16 = torch.bfloat16
-GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32, GEMM_TRANS_OUT, GEMM_SWIGLU = 1, 2, 4, 8, 16, 32, 64
+GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32, GEMM_TRANS_OUT, GEMM_SWIGLU, GEMM_SWIGLU_BWD = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 # optional timing of the dominant kernel (bench.py roofline): list of (start_event | None, end_event | None, flops, cfg, layout).
@@ -83,6 +83,23 @@ def gemm_gate_up_swiglu(x, w_gu, gu, act):
     if prof is not None:
         _prof_end(prof, e0, 2.0 * M * N * K, (False, False))
     return act
+
+
+def gemm_down_dgrad_swiglu_bwd(dy, w_down, gu, dgu):
+    """d[gate | up][M, 2ff] from ONE launch (MOLLY_GEMM_SWIGLU_BWD): d(act) = dy[M, h] @ w_down[h, ff] stays in the accumulators,
+    the SwiGLU backward runs in the epilogue against gu = [gate | up] — bit-identical to gemm(dy, w_down, b_kmajor=True) followed by
+    swiglu_bwd, without d(act)'s HBM round trip."""
+    _chk(dy, BF16, "dy"); _chk(w_down, BF16, "w_down"); _chk(gu, BF16, "gu"); _chk(dgu, BF16, "dgu")
+    M, K = dy.shape
+    ff = w_down.shape[1]
+    assert w_down.shape[0] == K and tuple(gu.shape) == (M, 2 * ff) and tuple(dgu.shape) == (M, 2 * ff)
+    prof = GEMM_PROFILE
+    e0 = _prof_begin() if prof is not None else None
+    lib().call("molly_gemm_bf16", _stream(), dy, w_down, dgu, None, gu, M, ff, K, dy.stride(0), w_down.stride(0), dgu.stride(0),
+               gu.stride(0), GEMM_SWIGLU_BWD, 0, 1)
+    if prof is not None:
+        _prof_end(prof, e0, 2.0 * M * ff * K, (False, True))
+    return dgu
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,

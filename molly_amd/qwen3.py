@@ -62,6 +62,9 @@ class Qwen3Engine:
         # SwiGLU in the gate|up GEMM's epilogue (MOLLY_GEMM_SWIGLU): not with LoRA (the adapters add to gate / up after the
         # base GEMM), needs ff % 128 == 0 (every Qwen3 size); MOLLY_FUSED_SWIGLU=0 restores the two-kernel path
         self.fused_swiglu = (lora is None and self.ff % 128 == 0 and os.environ.get("MOLLY_FUSED_SWIGLU", "1") != "0")
+        # its backward in the down-projection's dgrad epilogue (MOLLY_GEMM_SWIGLU_BWD): d(act) never reaches HBM.  Not with LoRA
+        # (the down_proj adapter adds to d(act)); MOLLY_FUSED_SWIGLU_BWD=0 restores dgrad + swiglu_bwd
+        self.fused_swiglu_bwd = lora is None and os.environ.get("MOLLY_FUSED_SWIGLU_BWD", "1") != "0"
         self.cap = 0
         self.tT = None
         self.tTg, self._pend = None, []   # grouped per-layer weight gradients (reserve)
@@ -410,12 +413,16 @@ class Qwen3Engine:
             a, w = self.A[i], self.W[i]
             g = self.dW[i] if tb else None
             # ---- MLP: x3 = x2 + down(silu(g)*u)
-            self._dgrad(dx, w["down"], self.d_act)
-            if lora is not None:
-                self._lora_bwd(i, a, "down_proj", a["act"], dx, self.d_act, accumulate)
+            if self.fused_swiglu_bwd:
+                ops.gemm_down_dgrad_swiglu_bwd(dx, w["down"], a["gu"], self.d_gu)
+            else:
+                self._dgrad(dx, w["down"], self.d_act)
+                if lora is not None:
+                    self._lora_bwd(i, a, "down_proj", a["act"], dx, self.d_act, accumulate)
             if tb:
                 self._wgrad_layer(3, dx, a["act"], g["down"], accumulate)
-            ops.swiglu_bwd(a["gu"], self.d_act, self.d_gu)
+            if not self.fused_swiglu_bwd:
+                ops.swiglu_bwd(a["gu"], self.d_act, self.d_gu)
             dxn2 = spare[0]
             self._dgrad(self.d_gu, w["gu"], dxn2)
             if lora is not None:

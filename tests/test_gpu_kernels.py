@@ -315,6 +315,11 @@ def test_ce_fwd_bwd_matches_torch():
     loss = torch.empty(1, dtype=torch.float32, device=DEV)
     ops.sum_f32(row_loss, loss, scale=scale)
     assert abs(loss.item() - ref.item()) < 2e-4 * max(1.0, abs(ref.item()))
+    # the per-row losses are fp32 values computed from the same bf16 logits: held to fp32 accuracy, not to a bf16 tolerance
+    per_row = torch.nn.functional.cross_entropy(logits.double(), labels, ignore_index=-100, reduction="none")
+    keep = labels != -100
+    assert (row_loss[keep].double() - per_row[keep]).abs().max().item() <= 4e-6 * per_row[keep].max().item()
+    assert row_loss[~keep].abs().max().item() == 0.0
     _close(work, lr.grad, 2e-5, 1e-2, "dlogits")     # bf16 output of values <= 1/n_valid
     assert work[::5].abs().max() == 0
 
@@ -343,14 +348,14 @@ def test_adamw_and_clip_match_torch():
     ws = torch.empty(1024, dtype=torch.float32, device=DEV)
     nsq = torch.empty(1, dtype=torch.float32, device=DEV)
     ops.sqnorm(gr, nsq, ws)
-    assert abs(nsq.item() - gr.float().pow(2).sum().item()) < 1e-3 * nsq.item()
+    assert abs(nsq.item() - gr.double().pow(2).sum().item()) < 2e-6 * nsq.item()      # fp32 sum of exact products: fp32-accurate
     norm = torch.empty(1, dtype=torch.float32, device=DEV)
     coef = torch.empty(1, dtype=torch.float32, device=DEV)
     ops.clip_coef(nsq, 1.0, 1.0, norm, coef)
     pt = torch.nn.Parameter(p0.clone())
     pt.grad = gr.float().clone()
     tn = torch.nn.utils.clip_grad_norm_([pt], 1.0)
-    assert abs(norm.item() - tn.item()) < 1e-4 * tn.item()
+    assert abs(norm.item() - tn.item()) < 4e-6 * tn.item()
     opt = torch.optim.AdamW([pt], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
     master, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
     pout = torch.empty(n, dtype=BF, device=DEV)
@@ -646,3 +651,23 @@ def test_gate_up_gemm_with_fused_swiglu_is_bit_identical_to_two_kernels(M, ff, K
     torch.cuda.synchronize()
     assert torch.equal(gu, gu_ref)
     assert torch.equal(act, act_ref)
+
+
+@pytest.mark.parametrize("M,ff,K", [(300, 200, 128), (1024, 3072, 1024), (16384, 6144, 2048)])
+def test_down_dgrad_with_fused_swiglu_bwd_is_bit_identical_to_two_kernels(M, ff, K):
+    """MOLLY_GEMM_SWIGLU_BWD: d[gate | up] from the down-projection's dgrad launch == molly_gemm (dgrad form) + molly_swiglu_bwd,
+    bit for bit (d(act) rounded to bf16 in the epilogue exactly as the GEMM would have stored it), ragged M and ff included;
+    against torch autograd within the bf16 tolerance of the unfused test."""
+    dy = _rand(M, K, seed=71).to(BF)
+    w = _rand(K, ff, seed=72, scale=0.05).to(BF)                 # down_proj.weight [h, ff]: the k-major B operand
+    gu = _rand(M, 2 * ff, seed=73).to(BF)
+    dact_ref = ops.gemm(dy, w, b_kmajor=True)
+    dgu_ref = ops.swiglu_bwd(gu, dact_ref)
+    dgu = torch.full((M, 2 * ff), 7.0, dtype=BF, device=DEV)
+    ops.gemm_down_dgrad_swiglu_bwd(dy, w, gu, dgu)
+    torch.cuda.synchronize()
+    assert torch.equal(dgu, dgu_ref)
+    if M <= 1024:
+        gr = gu.float().requires_grad_(True)
+        (torch.nn.functional.silu(gr[:, :ff]) * gr[:, ff:]).backward(dact_ref.float())
+        _close(dgu, gr.grad, 1e-2, 1e-2, "fused swiglu bwd vs autograd")

@@ -9,6 +9,7 @@ gemm256_kernel's MAIN LOOP and compiled to tools/gemm_diag/libgemm_<variant>.so 
     samet                     every block stages tile (0,0): all staging traffic hits in L2
     bal                       two LDS-DMA pieces per wave in every load segment     rb   B(n0) of the next K-tile read in P3
     mfma32                    the same flops through v_mfma_f32_32x32x16_bf16
+    nostore                   the plain epilogue converts its accumulators but never stores them
   valid builds:  base, swapab (B slots first in LDS), novm (timing-only: no counted vmcnt)
   stamped builds (s_memtime; read the SHARES, not the run time):
     seg      every barrier stamped on arrival and exit: per wave group and per K-tile, cycles of each load / compute segment
@@ -139,6 +140,16 @@ extern "C" int molly_exp_read_stamps(void* dst, int clear) {
     return 0;
 }
 """
+    if "nostore" in name or "lateprefetch" in name:
+        # timing-only: the plain epilogue converts but never stores (nostore) — what the output stores cost a tile, including
+        # their place in the in-order vmcnt queue in front of the next tile's K-tile 2;  lateprefetch (valid): the next tile's
+        # K-tiles 0 and 1 are issued AFTER the epilogue's stores instead of before them
+        k = tail.index("// ---- epilogue: lane owns C[m")
+        if "nostore" in name:
+            tail = tail.replace("exact_stores = em0 + 256 <= eM", "exact_stores = false && em0 + 256 <= eM")
+            st = "                *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};"
+            k2 = tail.index(st, k)
+            tail = tail[:k2] + "                if (v[0] == 1.2345e30f) " + st.strip() + tail[k2 + len(st):]
     head = src[:a]
     if "samet" in name:
         # timing-only: every block stages tile (0, 0): all LDS-DMA traffic hits in L2
