@@ -580,6 +580,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // stores the previous epilogue left behind its loads, per lane, when that number is known (16: the fast paths' 16-byte
     // stores; 32: plain 8-byte quads; 48: the SwiGLU-fused gate, up and activation quads); 0 = unknown: conservative waits
     int pend_stores = 0;
+    // s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate); n is a multiple of 8 up to 56, anything else waits
+    // for everything
+    auto wait_vm = [&](int n) {
+        if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (n == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (n == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (n == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else if (n == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        else if (n == 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     // ROLLING prefetch (four-phase schedule, every slice >= 2 K-tiles): the staging pipeline does not drain at a tile boundary.
     // K-tile T+2 of the loop is the NEXT work item's K-tile T+2-nk once T+2 >= nk, staged into the slot the ring would use
     // anyway (abuf / bbuf keep rotating across tiles), so the next tile's first two K-tiles are in flight during this tile's last
@@ -604,19 +616,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // wait for K-tile 0 only.  Outstanding, oldest first: [K-tile 0: 8][K-tile 1: 8 if nk > 1][previous epilogue stores].
     // vmcnt counts loads and stores together in issue order, so with exactly 32 stores behind the loads the counted wait
     // lets all of them (and K-tile 1) stay in flight; any other epilogue falls back to a conservative count.
-    if (!landed0) {
-        if (nk > 1) {
-            if (pend_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (pend_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-            else if (pend_stores == 48) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            if (pend_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (pend_stores == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (pend_stores == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
+    if (!landed0) wait_vm((nk > 1 ? 8 : 0) + pend_stores);
     // the first counted wait of a tile sits behind the previous epilogue's stores: [K-tile 1: 8][stores]
     // [K-tile 2: 8] — K-tile 1 has landed once all but the stores and K-tile 2's pieces are done
     const int first_wait = 8 + pend_stores;
@@ -716,13 +716,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         // ---- P3: quadrant (m1,n0); retire K-tile T+1
         if (T < t_stage_end) {
             stage2(T, 2); stage2(T, 3);
-            if (T == 0 && first_wait != 8) {
-                if (first_wait == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                else if (first_wait == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            }
+            if (T == 0 && first_wait != 8) wait_vm(first_wait);
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -766,10 +761,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // stores, 64 contiguous bytes per row and instruction, half the requests and half the instructions.
     const bool interior = em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && !(GRP ? eto : TO);
     const bool fast16 = interior && (p.flags == 0 || p.flags == MOLLY_GEMM_RESIDUAL);
-    pend_stores = fast16 ? 16
+    const bool swiglu16 = !AT && !BT && !TO && !GRP && p.flags == MOLLY_GEMM_SWIGLU && em0 + 256 <= eM;      // (N % 256 == 0)
+    const bool swiglu_bwd16 = !AT && BT && !TO && !GRP && p.flags == MOLLY_GEMM_SWIGLU_BWD && em0 + 256 <= eM && en0 + 256 <= eN;
+    pend_stores = fast16 ? 16 : swiglu16 ? 24 : swiglu_bwd16 ? 32
                 : (em0 + 256 <= eM && en0 + 256 <= eN &&
                    !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) ? 32
-                : (!AT && !BT && !TO && !GRP && em0 + 256 <= eM && en0 + 256 <= eN && p.flags == MOLLY_GEMM_SWIGLU) ? 48 : 0;
+                : 0;
     if (fast16) {
         bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + en0 + wc * 64 + fq * 8;
         if (p.flags == 0) {
@@ -864,6 +861,79 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const int n = en0 + wc * 64 + j * 16 + (lane >> 4) * 4;
                 if (n >= eN) continue;
                 *reinterpret_cast<f32x4*>(slab + (size_t)m * eN + n) = acc[i][j];
+            }
+        }
+    } else if (swiglu16) {
+        // SwiGLU-fused gate|up projection, interior rows: as the branch below, with gate, up and activation regrouped to 16-byte
+        // stores (the wave's 32 activation columns = 4 lane-rows x 8 columns: 64 contiguous bytes per row and instruction)
+        const int ff = eN >> 1;
+        const size_t col = (size_t)(en0 >> 1) + (wc >> 1) * 64 + (wc & 1) * 32 + fq * 8;
+        bf16_t* g0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + col;
+        bf16_t* a0 = const_cast<bf16_t*>(p.res) + (size_t)(em0 + wr * 128 + fr) * p.ldres + col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned gq[2][2], uq[2][2], aq[2][2];            // [jj][dword]
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                gq[jj][0] = pack_bf2(acc[i][jj][0], acc[i][jj][1]);
+                gq[jj][1] = pack_bf2(acc[i][jj][2], acc[i][jj][3]);
+                uq[jj][0] = pack_bf2(acc[i][2 + jj][0], acc[i][2 + jj][1]);
+                uq[jj][1] = pack_bf2(acc[i][2 + jj][2], acc[i][2 + jj][3]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float ga = bflo(gq[jj][e]), gb = bfhi(gq[jj][e]);
+                    const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+                    aq[jj][e] = pack_bf2(sa * bflo(uq[jj][e]), sb * bfhi(uq[jj][e]));
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                regroup_rows(gq[0][w], gq[1][w]);
+                regroup_rows(uq[0][w], uq[1][w]);
+                regroup_rows(aq[0][w], aq[1][w]);
+            }
+            bf16_t* gp = g0 + (size_t)i * 16 * eldc;
+            *reinterpret_cast<u32x4*>(gp) = u32x4{gq[0][0], gq[0][1], gq[1][0], gq[1][1]};
+            *reinterpret_cast<u32x4*>(gp + ff) = u32x4{uq[0][0], uq[0][1], uq[1][0], uq[1][1]};
+            *reinterpret_cast<u32x4*>(a0 + (size_t)i * 16 * p.ldres) = u32x4{aq[0][0], aq[0][1], aq[1][0], aq[1][1]};
+        }
+    } else if (swiglu_bwd16) {
+        // SwiGLU backward in the down-projection's dgrad, interior tile: as the general branch below, with d(act) regrouped
+        // first (packed bf16, the rounding the unfused path applies), gate / up loaded and d(gate) / d(up) stored 16 bytes per lane
+        const int ff = eN;
+        const size_t col = (size_t)en0 + wc * 64 + fq * 8;
+        const bf16_t* g0 = p.res + (size_t)(em0 + wr * 128 + fr) * p.ldres + col;
+        bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16_t* gp = g0 + (size_t)i * 16 * p.ldres;
+            bf16_t* c = c0 + (size_t)i * 16 * eldc;
+            u32x4 gv[2], uv[2];
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                gv[sh] = *reinterpret_cast<const u32x4*>(gp + sh * 32);
+                uv[sh] = *reinterpret_cast<const u32x4*>(gp + ff + sh * 32);
+            }
+            unsigned d[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[j][0] = pack_bf2(acc[i][j][0], acc[i][j][1]);
+                d[j][1] = pack_bf2(acc[i][j][2], acc[i][j][3]);
+            }
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                regroup_rows(d[2 * sh][0], d[2 * sh + 1][0]);
+                regroup_rows(d[2 * sh][1], d[2 * sh + 1][1]);
+                const unsigned dq[4] = {d[2 * sh][0], d[2 * sh][1], d[2 * sh + 1][0], d[2 * sh + 1][1]};
+                u32x4 og, ou;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32x2 r = swiglu_bwd_pair(gv[sh][e], uv[sh][e], dq[e]);
+                    og[e] = r[0];
+                    ou[e] = r[1];
+                }
+                *reinterpret_cast<u32x4*>(c + sh * 32) = og;
+                *reinterpret_cast<u32x4*>(c + ff + sh * 32) = ou;
             }
         }
     } else if (!AT && !BT && !TO && !GRP && (p.flags & MOLLY_GEMM_SWIGLU)) {
