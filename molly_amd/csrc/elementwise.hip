@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void transpose64_kernel(const bf16_t* __restri
     {
         const int row = t >> 2, col = (t & 3) * 16;
         const u32x4* src = reinterpret_cast<const u32x4*>(in + (size_t)(r0 + row) * ld_in + c0 + col);
-        const u32x4 a = ld_stream<u32x4>(src), b = ld_stream<u32x4>(src + 1);
+        const u32x4 a = src[0], b = src[1];      // (plain: with the nontemporal hint this kernel measured 41 us against 27)
         // pitch 144 B keeps 16-byte alignment only for even rows; write as 8-byte pieces
         u32x2* dst = reinterpret_cast<u32x2*>(tile + row * 72 + col);
         dst[0] = u32x2{a[0], a[1]}; dst[1] = u32x2{a[2], a[3]}; dst[2] = u32x2{b[0], b[1]}; dst[3] = u32x2{b[2], b[3]};
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void transpose64_kernel(const bf16_t* __restri
         const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
         const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
         const bf16x8 v = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-        st_stream<bf16x8>(out + (size_t)(c0 + oc + i) * ld_out + r0 + rr, v);
+        *reinterpret_cast<bf16x8*>(out + (size_t)(c0 + oc + i) * ld_out + r0 + rr) = v;
     }
 }
 

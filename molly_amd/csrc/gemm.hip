@@ -389,9 +389,9 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 // elements into wrong code (3 of 4 columns of the residual path; the same family as the permlane32_swap(u, u) fold recorded in
 // attention.hip).
 __device__ __forceinline__ void regroup_rows(unsigned& x0, unsigned& x1) {
-    // (hipcc pads no hazards inside an asm string: two wait states around each swap cover a VALU write of its operands before
-    // it and a VALU read of its results after it)
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x0), "+v"(x1));
+    // (hipcc pads no hazards inside an asm string.  What it pads around the builtins, on a test kernel: `s_nop 1` between a VALU
+    // write of an operand and the swap that reads it — the second swap reads the first one's results — and nothing behind a swap)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
 }
 
 #ifndef MOLLY_GEMM_NT_EPILOGUE
