@@ -89,7 +89,10 @@ def test_two_ranks_zero0_fallback_equals_zero2(tiny_meta):
         mp.spawn(_worker, args=(2, port, tiny_meta, ret, stage), nprocs=2, join=True)
         assert torch.equal(ret[0][0], ret[1][0]) and ret[0][1] == ret[1][1]
         res[stage] = ret[0]
-    assert all(abs(a - b) <= 1e-5 * b for a, b in zip(res[0][1], res[2][1]))
+    # step 1: same gradients, two summation orders of the squared norm -> fp32 resolution.  Step 2 starts from parameters that
+    # differ in a few dozen bf16 roundings (below): its norm moves with them (measured 1.4e-4 on this fixture)
+    assert abs(res[0][1][0] - res[2][1][0]) <= 4e-7 * res[2][1][0], (res[0][1], res[2][1])
+    assert abs(res[0][1][1] - res[2][1][1]) <= 1e-3 * res[2][1][1], (res[0][1], res[2][1])
     a, b = res[0][0].float(), res[2][0].float()
     assert ((a - b).abs() <= 2 ** -6 * b.abs() + 1e-30).all()              # measured: 15 of 1.9 M differ, by <= 2 bf16 steps
     assert (a != b).float().mean().item() < 1e-4
