@@ -1064,13 +1064,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
             const long c = c0 + u * 256;
             if (c >= nch) continue;
             const float g[4] = {bflo(gr[u][0]) * gs, bfhi(gr[u][0]) * gs, bflo(gr[u][1]) * gs, bfhi(gr[u][1]) * gs};
+            // Every operation is named (no contraction left to the compiler): under -ffp-contract=fast hipcc fused the four
+            // elements of a chunk differently (packed fma for two of them), so an element's result depended on its position in
+            // its chunk, i.e. on where a bucket or shard starts — ZeRO-2 and ZeRO-0 runs of the same step then differed in the
+            // last fp32 bit of thousands of masters (tests/test_gpu_two_ranks.py caught the second-step norm moving by 1.4e-4).
+            const float decay = 1.f - lr * wd, omb1 = 1.f - b1, omb2 = 1.f - b2, nstep = -(lr / bc1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                p[u][e] *= (1.f - lr * wd);
-                mm[u][e] = b1 * mm[u][e] + (1.f - b1) * g[e];
-                vv[u][e] = b2 * vv[u][e] + (1.f - b2) * g[e] * g[e];
-                const float denom = sqrtf(vv[u][e]) / bc2_sqrt + eps;
-                p[u][e] -= (lr / bc1) * (mm[u][e] / denom);
+                const float pd = __fmul_rn(p[u][e], decay);
+                mm[u][e] = __fmaf_rn(b1, mm[u][e], __fmul_rn(omb1, g[e]));
+                vv[u][e] = __fmaf_rn(b2, vv[u][e], __fmul_rn(__fmul_rn(omb2, g[e]), g[e]));
+                const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv[u][e]), bc2_sqrt), eps);
+                p[u][e] = __fmaf_rn(nstep, __fdiv_rn(mm[u][e], denom), pd);
             }
             st_stream<f32x4>(master + c * 4, p[u]);
             st_stream<f32x4>(m + c * 4, mm[u]);

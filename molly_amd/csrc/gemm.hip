@@ -599,7 +599,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // were issued after the loop, every CU at the same moment (a 32 MB burst), and their latency was hidden only by the
     // ~1.5 us epilogue: ~9 us of fixed cost per 256x256 tile = 6 K-tiles' worth, 16 % of a K = 2048 tile
     // (tools/gemm_diag/run_kscan.py: time = fixed + per-K-tile * nk; run_tilestamp.py).
-    const bool roll = !P2 && !GRP && nk_all / p.splits >= 2;       // (grouped launches: 256-K-tile slices, per-problem strides)
+    // (not in a grouped launch: its slices are 256 K-tiles long, and with the per-problem operands re-derived inside the K loop
+    // hipcc no longer keeps the LDS-DMA's scalar base in SGPRs)
+    const bool roll = !P2 && !GRP && nk_all / p.splits >= 2;
     bool landed0 = false;                     // K-tile 0 of the tile about to start has already been waited for
     int abuf = 0, bbuf = 0;                   // LDS slots of the current K-tile (A: 0..2, B: 0..1)
 
@@ -763,11 +765,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const bool fast16 = interior && (p.flags == 0 || p.flags == MOLLY_GEMM_RESIDUAL);
     const bool swiglu16 = !AT && !BT && !TO && !GRP && p.flags == MOLLY_GEMM_SWIGLU && em0 + 256 <= eM;      // (N % 256 == 0)
     const bool swiglu_bwd16 = !AT && BT && !TO && !GRP && p.flags == MOLLY_GEMM_SWIGLU_BWD && em0 + 256 <= eM && en0 + 256 <= eN;
-    pend_stores = fast16 ? 16 : swiglu16 ? 24 : swiglu_bwd16 ? 32
+    // transposed output (weight gradients), interior tile, plain bf16 store: the lane owns 4 consecutive m of one n
+    const bool to16 = (GRP ? eto : TO) && em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && p.flags == 0;
+    pend_stores = (fast16 || to16) ? 16 : swiglu16 ? 24 : swiglu_bwd16 ? 32
                 : (em0 + 256 <= eM && en0 + 256 <= eN &&
                    !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) ? 32
                 : 0;
-    if (fast16) {
+    if (to16) {
+        // C^T[n][m]: the quads of row-blocks (i even, i odd) regrouped so that lane-row fq holds m = s*32 + fq*8 .. +7 of its n
+        bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(en0 + wc * 64 + fr) * eldc + em0 + wr * 128 + fq * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16_t* c = c0 + (size_t)j * 16 * eldc;
+#pragma unroll
+            for (int sh = 0; sh < 4; ++sh) {
+                unsigned d0[2], d1[2];
+                d0[0] = pack_bf2(acc[2 * sh][j][0], acc[2 * sh][j][1]);
+                d0[1] = pack_bf2(acc[2 * sh][j][2], acc[2 * sh][j][3]);
+                d1[0] = pack_bf2(acc[2 * sh + 1][j][0], acc[2 * sh + 1][j][1]);
+                d1[1] = pack_bf2(acc[2 * sh + 1][j][2], acc[2 * sh + 1][j][3]);
+                regroup_rows(d0[0], d1[0]);
+                regroup_rows(d0[1], d1[1]);
+                *reinterpret_cast<u32x4*>(c + sh * 32) = u32x4{d0[0], d0[1], d1[0], d1[1]};
+            }
+        }
+    } else if (fast16) {
         bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + en0 + wc * 64 + fq * 8;
         if (p.flags == 0) {
 #pragma unroll

@@ -38,13 +38,14 @@ def _worker(rank, world, port, meta, ret, stage=2, rs_algo=None):
     assert opt.overlap and opt.world == 2 and len(opt.buckets) > 2
     m.attach_optimizer(opt)
     b = _batches(meta)[rank]
-    norms = []
+    norms, after = [], []
     for _ in range(2):
         m.forward_backward(*_args(b))
         norms.append(float(opt.step(lr=1e-3).item()))
-    opt.wait_all_params()
-    torch.cuda.synchronize()
-    ret[rank] = (m._rt.P.flat.cpu().clone(), norms)
+        opt.wait_all_params()
+        torch.cuda.synchronize()
+        after.append(m._rt.P.flat.cpu().clone())
+    ret[rank] = (after[1], norms, after[0])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,7 +54,7 @@ def test_two_ranks_on_one_gpu_overlapped_zero2(tiny_meta):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, 29571, tiny_meta, ret), nprocs=2, join=True)
-    (P0, n0), (P1, n1) = ret[0], ret[1]
+    (P0, n0, _), (P1, n1, _) = ret[0], ret[1]
     assert torch.equal(P0, P1) and n0 == n1                       # replicas bit-identical after the all-gather
     # single process: same two micro-batches, gradients summed (GA semantics) then averaged by the 1/world the optimizer
     # folds into its clip scale -> emulate with grad_scale through two accumulate steps and a halved gradient
@@ -89,13 +90,18 @@ def test_two_ranks_zero0_fallback_equals_zero2(tiny_meta):
         mp.spawn(_worker, args=(2, port, tiny_meta, ret, stage), nprocs=2, join=True)
         assert torch.equal(ret[0][0], ret[1][0]) and ret[0][1] == ret[1][1]
         res[stage] = ret[0]
-    # step 1: same gradients, two summation orders of the squared norm -> fp32 resolution.  Step 2 starts from parameters that
-    # differ in a few dozen bf16 roundings (below): its norm moves with them (measured 1.4e-4 on this fixture)
+    # Step 1 starts from identical parameters and gradients; the squared norm is summed in two orders -> fp32 resolution, and
+    # the clip coefficient's last bits put a handful of parameters on the other side of a bf16 rounding (measured: 3-4 of 1.9 M).
     assert abs(res[0][1][0] - res[2][1][0]) <= 4e-7 * res[2][1][0], (res[0][1], res[2][1])
+    a, b = res[0][2].float(), res[2][2].float()
+    assert ((a - b).abs() <= 2 ** -6 * b.abs() + 1e-30).all()
+    assert (a != b).float().mean().item() < 1e-4
+    # Step 2 is the same computation from parameters that differ in those few roundings.  How far its gradient norm moves depends
+    # on WHICH weights they hit (one bf16 step on one 3.8e-3 weight moved it by 1.4e-4; flips on 1e-7-sized weights by 1e-7), and
+    # the clip coefficient, hence every update, moves with it: bounded, not pinned.
     assert abs(res[0][1][1] - res[2][1][1]) <= 1e-3 * res[2][1][1], (res[0][1], res[2][1])
     a, b = res[0][0].float(), res[2][0].float()
-    assert ((a - b).abs() <= 2 ** -6 * b.abs() + 1e-30).all()              # measured: 15 of 1.9 M differ, by <= 2 bf16 steps
-    assert (a != b).float().mean().item() < 1e-4
+    assert (a - b).abs().max().item() <= 2.5e-3                          # <= the two updates of lr = 1e-3 themselves
 
 
 def test_two_ranks_all_to_all_reduce_scatter(tiny_meta):
