@@ -342,7 +342,7 @@ def main(argv=None):
         comm = {"backend": backend, "world_size": dist.get_world_size(), "preflight": comm_check,
                 "comm_bytes_per_step_per_gpu": opt.comm_bytes_per_step(), "bucket_mib": round(opt.bucket * 2 / (1 << 20), 1),
                 "per_link_mib_per_bucket": round(opt.chunk * 2 / (1 << 20), 1), "buckets": len(opt.buckets),
-                "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo, "persistent_gemm": os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "0") == "1"}
+                "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo, "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256)}
         if backend == "nccl":
             try:
                 comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())

@@ -86,7 +86,8 @@ int molly_gemm_last_config(void);
 int molly_gemm_set_small_grid_tile(int tile);   /* A/B knob: 128 (default) | 512 for grids that fill the chip neither plain nor split-K */
 int molly_gemm_set_group_m(int g);
 /* tuning hook: resident blocks of the persistent 256x256 kernel (default 256 = one per CU; multiple of 8);
- * 0 = launch one block per tile. */
+ * 0 = launch one block per tile; -t = blocks of t tiles each (ceil(work / t) blocks, placed by the hardware dispatcher on
+ * whatever CUs are free: the setting for a GEMM that runs beside a collective). */
 int molly_gemm_set_persistent_blocks(int n);
 /* split-K: shortest K-slice, in 64-wide K-tiles, the heuristic accepts for a grid that is not skinny (default 16). */
 int molly_gemm_set_min_ktiles(int n);

@@ -1128,7 +1128,18 @@ int g_schedule = -1;              // 256x256 kernel: -1 = per form, 0 = four pha
 // four-phase schedule wins on every form (same-box: gate|up dgrad 1387 vs 1320 TF/s, qkv dgrad 1296 vs 1279), so -1 now
 // means four phases everywhere; 1 still selects two.
 inline bool two_phase(bool /*b_kmajor*/) { return g_schedule == 1; }
-int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile
+int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile; -t = t tiles per block
+// grid of the 256x256 kernel for `nwork` work items.  n > 0: min(nwork, n) resident blocks that walk the work list (every CU
+// must be free for the whole launch, or the blocks that found none run as a second round).  0: one block per item.  -t: blocks of
+// at most t tiles each, a multiple of 256 of them (whole rounds when the chip is free; a block keeps its XCD) — the dispatcher
+// places them on whatever CUs are free (a collective running beside the GEMM owns some), and t - 1 of every t tile boundaries
+// still run under the rolling prefetch.
+inline int grid256(int nwork) {
+    if (g_persist_blocks > 0) return min(nwork, g_persist_blocks);
+    if (g_persist_blocks == 0) return nwork;
+    const int t = -g_persist_blocks;
+    return min(nwork, 256 * cdiv(nwork, 256 * t));                  // whole rounds of 256 blocks, at most t tiles per block
+}
 int g_small_grid_tile = 128;     // kernel for grids that fill the chip neither plain nor split: 128 (128x128 ring) | 512 (256x256)
 int g_min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
 int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
@@ -1197,7 +1208,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
 
         // persistent: at most g_persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
-        const int grid = g_persist_blocks > 0 ? min(nwork, g_persist_blocks) : nwork;
+        const int grid = grid256(nwork);
         // two-phase schedule where it measured faster: a k-major B operand (dgrad, wgrad); -1 = this choice, 0 / 1 = forced
         if (two_phase(BT)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
         else hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false>), dim3(grid), dim3(512), 163840, st, p);
@@ -1364,7 +1375,7 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr = true;
     }
-    const int grid = g_persist_blocks > 0 ? min(work, g_persist_blocks) : work;
+    const int grid = grid256(work);
     g_last_cfg = 512 + 1000 + 100000 * count;
     if (two_phase(true))
         hipLaunchKernelGGL((gemm256_kernel<false, true, false, true, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
@@ -1387,7 +1398,8 @@ extern "C" int molly_gemm_set_min_ktiles(int n) {
 }
 
 extern "C" int molly_gemm_set_persistent_blocks(int n) {
-    MOLLY_CHECK(n >= 0 && n % 8 == 0, "gemm_set_persistent_blocks: %d must be a non-negative multiple of 8", n);
+    MOLLY_CHECK((n >= 0 && n % 8 == 0) || (n < 0 && n >= -64),
+                "gemm_set_persistent_blocks: %d must be a non-negative multiple of 8, or -t (t tiles per block, t <= 64)", n);
     g_persist_blocks = n;
     return 0;
 }

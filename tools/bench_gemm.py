@@ -87,7 +87,7 @@ def main():
                 elif t >= 800000:
                     lib().call("molly_gemm_force_tile", 0)
                     lib().call("molly_gemm_set_schedule", t - 800010)
-                elif t >= 512000:
+                elif t >= 511000:
                     lib().call("molly_gemm_force_tile", 512)
                     lib().call("molly_gemm_set_persistent_blocks", t - 512000)
                 else:
