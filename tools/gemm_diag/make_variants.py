@@ -20,6 +20,11 @@ SCHEDS=0,1 python tools/gemm_diag/run_seg.py seg"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = open(os.path.join(ROOT, "molly_amd/csrc/gemm.hip")).read()
+if "    if constexpr (P2) {\n        // TWO phases per K-tile" not in src:
+    sys.exit("make_variants.py patches the round-1 text of gemm256_kernel's main loop (its findings: DESIGN.md 7, 'Where the GEMM's "
+             "cycles go').  The round-2 kernel (rolling prefetch, staging stream) no longer matches these patches: use "
+             "tools/build_variant.py (--patch nostore | tilestamp | githead, or -D flags) with tools/gemm_diag/run_kscan.py, "
+             "run_tilestamp.py and cmp_libs.py instead; `git checkout 259a1c5 -- molly_amd/csrc/gemm.hip` reproduces the round-1 builds.")
 a = src.index("    if constexpr (P2) {\n        // TWO phases per K-tile")
 b = src.index("    if (wr == 0) SEG_BARRIER();               // balance the stagger barrier")
 loop = src[a:b]
