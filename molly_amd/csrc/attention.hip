@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const bf16_t* Kb = p.K + (size_t)b * T * p.ldk + kvh * HD;
     const bf16_t* Vb = p.V + (size_t)b * T * p.ldv + kvh * HD;
 
-    // Q fragments (B operand of S^T = K Q^T): lane (r,h) holds Q[q0+r][16s + 8h .. +7]
+    // Q fragments (B operand of S^T = K Q^T): lane (r,h) holds Q[q0+r][16s + 8h .. +7].  (Tried: the block's 128 query rows as two
+    // 64-row tiles through the idle second K/V stage by LDS-DMA, fragments read back with row_frag — coalesced, but one more
+    // barrier and 8 LDS reads per wave: 171.8 -> 174.1 us at hd 128, 24.9 -> 24.3 us on the ESM shape; not kept.)
     bf16x8 qf[NS];
     {
         int qrow = q0 + r;
