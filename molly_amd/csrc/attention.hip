@@ -413,41 +413,14 @@ __global__ __launch_bounds__(128) void attn_fwd_small_kernel(AttnArgs p) {
 // for no cross-workgroup dQ reduction (guide Appendix B "Attention backward": dQ atomics are rate-limited).
 // ================================================================================================
 struct AttnBwdArgs {
-    const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO;
-    const float* LSE; const float* delta;
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO; const bf16_t* O;
+    const float* LSE; float* delta;            // delta[b, head, q] = sum_d dO[q,d] * O[q,d]: written by the dQ kernel, read by dK's
     bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     const int* kv_lo; const int* kv_hi;
     int T, nh, nkv, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float scale, scale_log2;
     int causal;
 };
-
-// delta[b, head, q] = sum_d dO[q,d] * O[q,d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO,
-                                                         float* __restrict__ delta, int B, int T, int nh, int hd, int ldo,
-                                                         int lddo) {
-    const int lanes = hd / 8;                         // threads per (token, head)
-    const long item = ((long)blockIdx.x * 256 + threadIdx.x) / lanes;
-    const int c = threadIdx.x % lanes;
-    const long total = (long)B * T * nh;
-    float s = 0.f;
-    if (item < total) {
-        const long tok = item / nh;
-        const int head = (int)(item % nh);
-        const u32x4 a = *reinterpret_cast<const u32x4*>(O + (size_t)tok * ldo + head * hd + c * 8);
-        const u32x4 d = *reinterpret_cast<const u32x4*>(dO + (size_t)tok * lddo + head * hd + c * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += bflo(a[e]) * bflo(d[e]) + bfhi(a[e]) * bfhi(d[e]);
-    }
-    for (int o = lanes >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (item < total && c == 0) {
-        const long tok = item / nh;
-        const int head = (int)(item % nh);
-        const long b = tok / T, t = tok % T;
-        delta[((size_t)b * nh + head) * T + t] = s;
-    }
-}
-
 
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
@@ -471,18 +444,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int qi = q0 + r;
     const int qrow = qi < T ? qi : T - 1;
     bf16x8 qf[NS], dof[NS];
+    float dlt = 0.f;
     {
         const bf16_t* qp = p.Q + ((size_t)b * T + qrow) * p.ldq + head * HD + 8 * h;
         const bf16_t* dp = p.dO + ((size_t)b * T + qrow) * p.ldo + head * HD + 8 * h;
+        const bf16_t* op = p.O + ((size_t)b * T + qrow) * p.ldo + head * HD + 8 * h;
+        u32x4 of[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
             dof[s] = *reinterpret_cast<const bf16x8*>(dp + 16 * s);
+            of[s] = *reinterpret_cast<const u32x4*>(op + 16 * s);
         }
+        // delta = rowsum(dO * O) of this lane's query row (round 1: a kernel of its own, a second pass over O and dO): the lane
+        // holds half of the row's dO already; the other half-wave holds the rest
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const u32x4 dv = __builtin_bit_cast(u32x4, dof[s]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dlt += bflo(of[s][e]) * bflo(dv[e]) + bfhi(of[s][e]) * bfhi(dv[e]);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
     }
     float lse = p.LSE[((size_t)b * p.nh + head) * T + qrow];
     lse = (lse == -INFINITY) ? 0.f : lse;
-    const float dlt = p.delta[((size_t)b * p.nh + head) * T + qrow];
+    if (h == 0 && qi < T) p.delta[((size_t)b * p.nh + head) * T + qi] = dlt;       // for the dK pass
 #pragma unroll
     for (int s = 0; s < NS; ++s) { arrived(qf[s]); arrived(dof[s]); }
     arrived(lse); arrived(dlt);
@@ -762,12 +748,7 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
     MOLLY_CHECK(delta_ws && lse2, "attn_bwd: lse2 and a delta workspace of B*n_heads*T floats are required");
     MOLLY_CHECK(lddo == ldo, "attn_bwd: dO must share O's row stride");
     hipStream_t st = (hipStream_t)stream;
-    const long items = (long)B * T * n_heads;
-    const int per_blk = 256 / (head_dim / 8);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + per_blk - 1) / per_blk)), dim3(256), 0, st,
-                       (const bf16_t*)O, (const bf16_t*)dO, delta_ws, B, T, n_heads, head_dim, ldo, lddo);
-    MOLLY_LAUNCH_CHECK();
-    AttnBwdArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, lse2, delta_ws,
+    AttnBwdArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, (const bf16_t*)O, lse2, delta_ws,
                   (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, kv_lo, kv_hi, T, n_heads, n_kv_heads, ldq, ldk, ldv, ldo,
                   lddq, lddk, lddv, scale, scale * LOG2E, causal};
     const size_t lds_dq = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
