@@ -372,7 +372,9 @@ def main(argv=None):
         names = {(False, False): "NT gemm256_kernel<false,false>", (False, True): "NN gemm256_kernel<false,true>",
                  (True, True): "TN gemm256_kernel<true,true>"}
         def klass(kcfg, lay):
-            key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64>"
+            # (the 128x128 launches of the step are the frozen encoders' o / ffn1 projections: they run BESIDE the previous step's
+            # side-stream AdamW, so their per-launch time is a shared-chip time — in isolation 540-800 TF/s, tools/bench_gemm.py)
+            key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64> (encoder o/ffn1, beside the side-stream AdamW)"
             if kcfg >= 100000:                    # grouped launch: cfg = 512 + 1000 + 100000 * problems
                 key += f" grouped x{kcfg // 100000} (a layer's weight gradients in one launch)"
             elif kcfg // 1000 > 1:
