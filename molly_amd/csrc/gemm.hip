@@ -599,8 +599,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // were issued after the loop, every CU at the same moment (a 32 MB burst), and their latency was hidden only by the
     // ~1.5 us epilogue: ~9 us of fixed cost per 256x256 tile = 6 K-tiles' worth, 16 % of a K = 2048 tile
     // (tools/gemm_diag/run_kscan.py: time = fixed + per-K-tile * nk; run_tilestamp.py).
-    // (not in a grouped launch: its slices are 256 K-tiles long, and with the per-problem operands re-derived inside the K loop
-    // hipcc no longer keeps the LDS-DMA's scalar base in SGPRs)
+    // (not in a grouped launch: its slices are 256 K-tiles long; with the per-problem operands re-derived inside the K loop hipcc
+    // no longer keeps the LDS-DMA's scalar base in SGPRs, and with the tile state forced uniform by readfirstlane the launch
+    // measured 1,190 -> 1,209 us: the boundary saved less than the longer loop cost)
     const bool roll = !P2 && !GRP && nk_all / p.splits >= 2;
     bool landed0 = false;                     // K-tile 0 of the tile about to start has already been waited for
     int abuf = 0, bbuf = 0;                   // LDS slots of the current K-tile (A: 0..2, B: 0..1)
