@@ -382,7 +382,6 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
 // and the epilogue flags; each keeps its own pointers, sizes and transposed-output choice (TO is ignored).  The weight-
 // gradient GEMMs of one decoder layer are 64 + 128 + 192 + 384 = 768 tiles = three full rounds of 256 CUs: one launch, no
 // split-K slabs, no reduce launches.
-// (nontemporal epilogue stores measured 3x the fixed cost per tile: 8-byte pieces written through)
 // The epilogue's lane-row regrouping of a register pair (x0, x1) = quads (j even, j odd) of one accumulator row: swap the
 // register index with lane bit 5 (v_permlane32_swap), then with lane bit 4 (v_permlane16_swap).  Written as asm with both
 // registers read-write: the clang builtins return the pair by value, and hipcc (ROCm 7.2) folded chains of them over vector
@@ -394,14 +393,8 @@ __device__ __forceinline__ void regroup_rows(unsigned& x0, unsigned& x1) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
 }
 
-#ifndef MOLLY_GEMM_NT_EPILOGUE
-#define MOLLY_GEMM_NT_EPILOGUE 0
-#endif
-#if MOLLY_GEMM_NT_EPILOGUE
-#define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<u32x2*>(ptr))
-#else
-#define EPI_STORE(ptr, val) (*reinterpret_cast<u32x2*>(ptr) = (val))
-#endif
+// (nontemporal epilogue stores, tried on the 8-byte pieces before the regrouping: 3x the fixed cost per tile — written through
+// as partial lines)
 template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
