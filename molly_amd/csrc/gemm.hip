@@ -412,13 +412,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // One work item: the problem it belongs to (never changes outside a grouped launch), its tile and its K-slice
     struct Tile { int gi, m0, n0, split, kt0, nk; };       // gi = problem of a grouped launch (0 otherwise)
     // the problem's operands: launch constants outside a grouped launch (three Tile values are live in the K loop: kept small)
-    auto tA = [&](const Tile& t) { return GRP ? p.grp[t.gi].A : p.A; };
-    auto tB = [&](const Tile& t) { return GRP ? p.grp[t.gi].B : p.B; };
     auto tC = [&](const Tile& t) { return GRP ? p.grp[t.gi].C : p.C; };
     auto tM = [&](const Tile& t) { return GRP ? p.grp[t.gi].M : p.M; };
     auto tN = [&](const Tile& t) { return GRP ? p.grp[t.gi].N : p.N; };
-    auto tlda = [&](const Tile& t) { return GRP ? p.grp[t.gi].lda : p.lda; };
-    auto tldb = [&](const Tile& t) { return GRP ? p.grp[t.gi].ldb : p.ldb; };
     auto tldc = [&](const Tile& t) { return GRP ? p.grp[t.gi].ldc : p.ldc; };
     auto tto = [&](const Tile& t) { return GRP ? p.grp[t.gi].trans_out != 0 : TO; };
     const int nwork = GRP ? p.grp[p.ngroup - 1].work0 + p.grp[p.ngroup - 1].tiles_m * p.grp[p.ngroup - 1].tiles_n
