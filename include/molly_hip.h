@@ -282,6 +282,9 @@ int molly_scale_bf16(void* stream, void* x, long n, float s);
  * kernels rely on; not part of the product path) */
 int molly_probe_mfma16(void* stream, const void* A16x32, const void* B16x32, float* D16x16);
 int molly_probe_tr16(void* stream, const void* tile_in, void* lanes_out /* [64][4] u16 */, int row_stride_elems);
+/* diagnostic: `blocks` workgroups that each own one CU (all of its LDS) for `us` microseconds — a stand-in for a collective's
+ * kernel when timing the GEMM's launch shapes beside it (tools/diag/gemm_beside_hog.py); sink: any device word (never written) */
+int molly_probe_hog(void* stream, int blocks, int us, void* sink);
 
 #ifdef __cplusplus
 }

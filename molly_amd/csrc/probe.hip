@@ -33,7 +33,32 @@ __global__ void probe_tr16(const bf16_t* tile, bf16_t* out, int stride) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) out[l * 4 + e] = (bf16_t)v[e];
 }
+// A stand-in for a collective's kernel: `blocks` workgroups that each own a whole CU (all 160 KiB of LDS) and spin for `us`
+// microseconds of the 100 MHz s_memrealtime clock.  tools/diag/gemm_beside_hog.py times the GEMM's launch shapes beside it.
+__global__ __launch_bounds__(64) void probe_hog(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    unsigned long long t0, t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    do {
+        __builtin_amdgcn_s_sleep(16);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    } while (t - t0 < ticks);
+    if (sink && threadIdx.x == 0 && t == 0) sink[0] = (unsigned)sm[0];       // keeps the LDS allocation alive
+}
 }  // namespace
+
+extern "C" int molly_probe_hog(void* stream, int blocks, int us, void* sink) {
+    MOLLY_ENTER();
+    MOLLY_CHECK(blocks >= 1 && blocks <= 256 && us >= 1 && us <= 100000, "probe_hog: blocks=%d us=%d", blocks, us);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)probe_hog, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr = true;
+    }
+    hipLaunchKernelGGL(probe_hog, dim3(blocks), dim3(64), 163840, (hipStream_t)stream, (unsigned long long)us * 100ull, (unsigned*)sink);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int molly_probe_mfma16(void* stream, const void* A, const void* B, float* D) {
     MOLLY_ENTER();
