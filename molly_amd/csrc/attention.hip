@@ -90,6 +90,11 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
         // 734-747 for this kernel in the same process — the softmax segment (24 LDS reads, ~86 vector instructions, 16
         // transcendentals, DMA issue) is longer than the 512-cycle matrix segment it is paired with, four 8-wave barriers per
         // tile pay for the slowest wave, and one workgroup per CU has nobody to cover its prologue and diagonal tail.  Removed.
+        // A PERSISTENT form (512 resident workgroups walking a static snake-ordered item list; the next item's first K/V tile and Q
+        // fragments in flight during the current item's last tile and epilogue, O through a swizzled 32 KB slab in the consumed
+        // stage; passed every test): 213 us against 173.5 for this kernel in the same process (ESM shape 34.7 against 24.9) — the
+        // second Q fragment set takes the kernel to 256 registers with spills, and a static list loses what the hardware dispatcher
+        // gives for free (a finished workgroup's slot is refilled at once, whatever the item lengths).  Removed.
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds + inst * 512));
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :: "v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
