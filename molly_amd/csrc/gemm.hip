@@ -406,12 +406,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int wr = wave >> 2, wc = wave & 3;
 
     // ---- persistent tile loop: block b runs virtual ids b, b+G, b+2G, ... (G = gridDim.x, a multiple of 8 whenever there
-    // is more than one round, so a block's XCD label v&7 never changes).  The first two K-tiles of the NEXT tile are issued
-    // before the epilogue stores of the current one, so neither the prologue load latency nor the store tail idles the
-    // matrix pipe between tiles.
+    // is more than one round, so a block's XCD label v&7 never changes).  The NEXT work item's first two K-tiles are staged
+    // during the current item's last two (rolling prefetch, below); without it (two-phase schedule, grouped launches, one-K-tile
+    // slices) they are issued after the K loop, before the epilogue's stores.
     // One work item: the problem it belongs to (never changes outside a grouped launch), its tile and its K-slice
     struct Tile { int gi, m0, n0, split, kt0, nk; };       // gi = problem of a grouped launch (0 otherwise)
-    // the problem's operands: launch constants outside a grouped launch (three Tile values are live in the K loop: kept small)
+    // (kept small: the current and the next item's are live across the K loop)
     auto tC = [&](const Tile& t) { return GRP ? p.grp[t.gi].C : p.C; };
     auto tM = [&](const Tile& t) { return GRP ? p.grp[t.gi].M : p.M; };
     auto tN = [&](const Tile& t) { return GRP ? p.grp[t.gi].N : p.N; };
@@ -617,8 +617,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
     // LDS-DMA schedule (one K-tile = 4 half-tiles = 8 instructions per wave), every piece >= 4 phases ahead of its use:
     //   P0 (most operand reads) issues nothing | P1 -> A0(T+2) | P2 -> A1(T+2) | P3 (no reads) -> B0(T+2), B1(T+2)
-    //   A lives in 3 buffers (T%3): buffer of T+2 = buffer of T-1, last read at P2(T-1), restaged at P1(T): 3 phases later;
-    //   B lives in 2 buffers (T&1): slots die after P1(T), restaged at P3(T): 2 phases later.
+    //   A lives in 3 slots (abuf rotates 0,1,2 and keeps rotating across tiles): slot of T+2 = slot of T-1, last read at P2(T-1),
+    //   restaged at P1(T): 3 phases later;  B lives in 2 slots (bbuf toggles): slots die after P1(T), restaged at P3(T).
     // The only in-loop wait is P3's counted vmcnt(8): everything older than K-tile T+2's eight pieces — i.e. all of
     // K-tile T+1 — has landed; its first ds_read happens in the next phase, behind a barrier both groups have passed.
     bf16x8 af[2][4], b0[2][2], b1[2][2];
