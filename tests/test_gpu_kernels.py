@@ -671,3 +671,36 @@ def test_down_dgrad_with_fused_swiglu_bwd_is_bit_identical_to_two_kernels(M, ff,
         gr = gu.float().requires_grad_(True)
         (torch.nn.functional.silu(gr[:, :ff]) * gr[:, ff:]).backward(dact_ref.float())
         _close(dgu, gr.grad, 1e-2, 1e-2, "fused swiglu bwd vs autograd")
+
+
+@pytest.mark.parametrize("form,M,N,K,res", [("nt", 2048, 4096, 2048, False), ("nt", 4096, 2048, 2048, True),
+                                            ("nn", 4096, 6144, 2048, False), ("nn", 1024 + 40, 2048, 4096, False)])
+def test_gemm_launch_shapes_are_bit_identical(form, M, N, K, res):
+    """The 256x256 kernel launched as one block per CU (persistent, rolling prefetch across its tiles), as one block per tile, and
+    as blocks of at most t tiles (what Zero2Optimizer selects at N > 1: molly_gemm_set_persistent_blocks(-3)) computes every tile
+    the same way whoever runs it: bit-identical outputs, edge tiles included."""
+    from molly_amd._lib import lib
+    a = _rand(M, K, seed=81).to(BF)
+    b = (_rand(N, K, seed=82, scale=0.05) if form == "nt" else _rand(K, N, seed=82, scale=0.05)).to(BF)
+    r = _rand(M, N, seed=83).to(BF) if res else None
+    outs = []
+    try:
+        lib().call("molly_gemm_force_tile", 512)
+        for mode in (256, 0, -2, -3):
+            lib().call("molly_gemm_set_persistent_blocks", mode)
+            out = torch.full((M, N), 7.0, dtype=BF, device=DEV)
+            if form == "nt":
+                ops.gemm_nt(a, b, out=out, res=r)
+            else:
+                ops.gemm(a, b, out=out, res=r, b_kmajor=True)
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib().call("molly_gemm_set_persistent_blocks", 256)
+        lib().call("molly_gemm_force_tile", 0)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = a.float() @ (b.float().t() if form == "nt" else b.float())
+    if res:
+        ref = ref + r.float()
+    _close(outs[0], ref, 2e-2, 2e-2, "gemm vs fp32")
