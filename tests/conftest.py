@@ -26,6 +26,17 @@ def _release_gpu_memory(request):
         torch.cuda.empty_cache()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _gemm_launch_shape():
+    """MOLLY_TEST_GEMM_BLOCKS=-3 (or 0) runs the whole GPU suite with the 256x256 GEMM launched the way Zero2Optimizer launches it at
+    N > 1 (blocks of at most three tiles / one tile per block) instead of one persistent block per CU."""
+    mode = os.environ.get("MOLLY_TEST_GEMM_BLOCKS")
+    if mode is not None and torch.cuda.is_available():
+        from molly_amd._lib import lib
+        lib().call("molly_gemm_set_persistent_blocks", int(mode))
+    yield
+
+
 @pytest.fixture(scope="session")
 def tiny_meta():
     with open(os.path.join(GOLD, "tiny_meta.json")) as f:
