@@ -751,6 +751,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // swaps per register pair (v_permlane32_swap, then v_permlane16_swap: a 3-cycle of the bits {register j&1, lane>>5,
     // (lane>>4)&1}) regroup the quads so that lane-row fq holds columns s*32 + fq*8 .. +7 of its row for s = 0, 1: 16-byte
     // stores, 64 contiguous bytes per row and instruction, half the requests and half the instructions.
+    // (Tried on top: whole 128-byte rows through a per-wave 2 KB slab in the A slot that is free during the epilogue — 4 ds_write_b64
+    // + 2 ds_read_b128 per row-block instead of the swaps: K = 2048 launches 202.5 / 108.4 us against 200.1 / 101.5 with the swaps,
+    // bit-identical; not kept.)
     const bool interior = em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && !(GRP ? eto : TO);
     const bool fast16 = interior && (p.flags == 0 || p.flags == MOLLY_GEMM_RESIDUAL);
     const bool swiglu16 = !AT && !BT && !TO && !GRP && p.flags == MOLLY_GEMM_SWIGLU && em0 + 256 <= eM;      // (N % 256 == 0)

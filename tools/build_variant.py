@@ -85,11 +85,11 @@ def _patch_githead(t):
 
 
 def _patch_stamp_nostore(t):
-    """tilestamp + the fast-path epilogue converts but never stores (timing-only)."""
+    """tilestamp + the plain fast-path epilogue regroups but never stores (timing-only)."""
     t = _patch_tilestamp(t)
-    a = "#define EPI_STORE(ptr, val) (*reinterpret_cast<u32x2*>(ptr) = (val))"
+    a = "                    *reinterpret_cast<u32x4*>(c + sh * 32) = u32x4{d[2 * sh][0], d[2 * sh][1], d[2 * sh + 1][0], d[2 * sh + 1][1]};"
     assert t.count(a) == 1
-    return t.replace(a, "#define EPI_STORE(ptr, val) do { const u32x2 v_ = (val); if (v_[0] == 0x12345678u) *reinterpret_cast<u32x2*>(ptr) = v_; } while (0)")
+    return t.replace(a, "                    if (d[2 * sh][0] == 0x12345678u) " + a.strip())
 
 
 PATCHES = {"stamp_nostore": _patch_stamp_nostore, "githead": _patch_githead, "nostore": _patch_nostore, "lateprefetch": _patch_lateprefetch, "tilestamp": _patch_tilestamp}
