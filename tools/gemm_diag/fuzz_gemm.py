@@ -25,6 +25,17 @@ def main():
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
     ops.ensure_gemm_workspace(1 << 28)
     bad = 0
+    try:
+        bad = _cases(a, rng, rnd, dev)
+    finally:
+        lib().call("molly_gemm_set_persistent_blocks", 256)
+        lib().call("molly_gemm_force_tile", 0)
+    print(f"{a.cases} cases, {bad} failures")
+    sys.exit(1 if bad else 0)
+
+
+def _cases(a, rng, rnd, dev):
+    bad = 0
     for case in range(a.cases):
         form = rng.choice(["nt", "nn", "tn", "tn", "grp"])
         mode = rng.choice([256, 256, 0, -3])
@@ -84,10 +95,7 @@ def main():
         if not (err <= tol) or not bool(torch.isfinite(out.float()).all()):
             bad += 1
             print(f"case {case}: {form} M={M} N={N} K={K} mode={mode} tile={tile} cfg={lib().fn['molly_gemm_last_config']()}: max err {err:.4g} > {tol:.4g}")
-    lib().call("molly_gemm_set_persistent_blocks", 256)
-    lib().call("molly_gemm_force_tile", 0)
-    print(f"{a.cases} cases, {bad} failures")
-    sys.exit(1 if bad else 0)
+    return bad
 
 
 if __name__ == "__main__":
