@@ -143,7 +143,7 @@ def _run_cpu_config(which: str, threads: int, budget_s: float):
     return json.loads(line[-1]), None
 
 
-def cpu_baseline(budget_s: float = 45.0):
+def cpu_baseline(budget_s: float = 150.0):
     """The CPU oracle (`kind: port`, oracle/molly_ref.py, parity-pinned to the reference through tests/golden) timed on the
     host's physical cores, protocol of SURVEY.md §8d / BASELINE.md §3: the down-scaled C2 — the headline MODEL at full depth
     and vocabulary (Qwen3-1.7B + ESM2-650M, fp32), B=1, T=512, one 128-residue protein span — and C1 exactly (Qwen3-0.6B +
@@ -158,6 +158,9 @@ def cpu_baseline(budget_s: float = 45.0):
     d1, err1 = _run_cpu_config("c1", cores, budget_s / 2)
     if d2 is not None:
         out["value"] = round(d2["tokens_per_step"] / d2["median_seconds"], 2)
+        out["timed_steps"] = len(d2["step_seconds"])
+        out["warmup_steps"] = d2["warmups"]
+        out["median_step_seconds"] = round(d2["median_seconds"], 3)
         out["sample"] = (f"C2 down-scaled (SURVEY 8d): Molly-1.7B full depth fp32 (Qwen3-1.7B + ESM2-650M), B={d2['B']} T={d2['T']} "
                          f"protein K={d2['K']}, fwd+bwd+clipped AdamW, {d2['warmups']} warm-up + {len(d2['step_seconds'])} timed "
                          f"steps {d2['step_seconds']} s, median {d2['median_seconds']:.2f} s, {cores} threads on {physical} physical cores of {model} "
@@ -166,10 +169,116 @@ def cpu_baseline(budget_s: float = 45.0):
         out["sample"] = err2
     if d1 is not None:
         out["c1"] = {"value": round(d1["tokens_per_step"] / d1["median_seconds"], 2), "unit": "tokens/s",
+                     "timed_steps": len(d1["step_seconds"]), "median_step_seconds": round(d1["median_seconds"], 3),
                      "sample": (f"C1 exactly: Qwen3-0.6B + ESM2-t6-8M fp32, B={d1['B']} T={d1['T']} K={d1['K']}, {d1['warmups']} warm-up + "
                                 f"{len(d1['step_seconds'])} timed steps {d1['step_seconds']} s, median {d1['median_seconds']:.2f} s")}
     else:
         out["c1"] = {"value": None, "sample": err1}
+    return out
+
+
+HBM_PEAK_TBPS = 8.0                   # MI355X_MICROARCH.md "Chip-level parameters" (6.3 TB/s is what a float4 copy reaches)
+
+
+def _c5_worker():
+    """BASELINE configs[4] ('prefill + decode tokens/s for C5'; reference scripts/infer/inference_nt_lora.sh:18-33,
+    src/model/omics_one.py:220-232): Molly-8B with the LoRA adapter merged at load (= the base model's kernels), batch 32,
+    3072-token left-aligned prompts with one 1024-residue protein span, greedy decode over the KV cache.  Prefill is priced
+    against the MFMA roof, the decode step against HBM (it streams every weight and the whole KV cache once per token)."""
+    import molly_amd
+    from molly_amd import config as C
+    from molly_amd.generate import GenerationSession
+    from molly_amd.synth import synth_batch
+    dev = torch.device("cuda", 0)
+    B, T, K, NEW = 32, 3072, 1024, 48
+    cfg = C.molly("8b", k_tokens=K)
+    m = molly_amd.OmicsOne(cfg)
+    m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)
+    m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
+    m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
+    m.prepare(dev, train_llm=False, train_mlp=False, random_init_seed=1234)
+    b = synth_batch(B, T, [("protein", K)], seed=1)
+    res = None
+    for rep in range(2):                                   # first pass warms allocations and kernel attributes
+        sess = GenerationSession(m, NEW)
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        e0.record()
+        logits = sess.prefill(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"])
+        e1.record()
+        for _ in range(8):                                 # eager step + graph capture + first replays: not timed
+            logits = sess.step(logits.argmax(-1))
+        e2.record()
+        for _ in range(NEW - 8):
+            logits = sess.step(logits.argmax(-1))
+        e3.record()
+        torch.cuda.synchronize()
+        res = (e0.elapsed_time(e1), e2.elapsed_time(e3) / (NEW - 8))
+        del sess
+    pre_ms, dec_ms = res
+    t, pc = cfg.text_config, cfg.protein_config
+    h, hd, nh, nkv, ff, L, V = (t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size,
+                                t.num_hidden_layers, t.vocab_size)
+    p_layers = L * (h * nh * hd + 2 * h * nkv * hd + nh * hd * h + 3 * h * ff)
+    pre_flops = B * (T * (2 * p_layers + 4 * L * nh * hd * (T / 2)) + 2 * h * V +
+                     K * (enc_flops_per_token(pc, K) + 2 * pc.hidden_size * h))
+    t_mid = T + 8 + (NEW - 8) / 2                                   # average cache length over the timed steps
+    w_bytes = 2 * (p_layers + h * V)                                # every layer matrix + the (untied) lm_head, bf16
+    kv_bytes = 2 * L * B * t_mid * nkv * hd * 2
+    out = {"workload": f"Molly-8B, LoRA merged at load, batch {B}, prompt {T} (one {K}-residue protein span), greedy, {NEW - 8} timed "
+                       "decode steps through the captured hipGraph",
+           "prefill": {"ms": round(pre_ms, 1), "tokens_per_s": round(B * T / pre_ms * 1e3, 1),
+                       "achieved_tflops": round(pre_flops / pre_ms / 1e9, 1), "bound": "mfma",
+                       "frac": round(pre_flops / pre_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)},
+           "decode": {"ms_per_step": round(dec_ms, 3), "tokens_per_s": round(B / dec_ms * 1e3, 1), "bound": "hbm",
+                      "bytes_per_step": int(w_bytes + kv_bytes), "weights_bytes": int(w_bytes), "kv_cache_bytes": int(kv_bytes),
+                      "achieved_TBps": round((w_bytes + kv_bytes) / dec_ms / 1e9, 3), "peak_TBps": HBM_PEAK_TBPS,
+                      "frac": round((w_bytes + kv_bytes) / dec_ms / 1e9 / HBM_PEAK_TBPS, 4)}}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+SECONDARY = {
+    # BASELINE configs[2] / [3] at their DEFINING per-GPU batch (B = 1: scripts/train/examples/run_train_4B_z2_b1.sh:29,47,
+    # run_train_8B_z0_b1.sh:29,47), GA = 2
+    "c3": ["--model", "4b", "--batch", "1", "--seq", "3072", "--micro", "dna:512,rna:512,protein:512;dna:512,rna:512,protein:512"],
+    "c4": ["--model", "8b", "--batch", "1", "--seq", "4096", "--micro", "protein:1024;dna:1000"],
+    "c5": [],
+}
+
+
+def secondary_block(budget_s: float):
+    """BASELINE configs 3 / 4 / 5 beside the headline line: each in a child process of its own (fresh GPU memory,
+    a failure or a timeout becomes a string in the record, never an exception), all inside one wall-time box."""
+    import subprocess
+    t_end = time.time() + budget_s
+    out = {}
+    for name in ("c5", "c3", "c4"):
+        left = t_end - time.time()
+        if left < 45:
+            out[name] = "skipped: the secondary block's time box was used up"
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--secondary-worker", name, "--no-cpu-baseline", "--no-secondary",
+               "--steps", "4", "--warmup", "2", *SECONDARY[name]]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, env={**os.environ, "WORLD_SIZE": "1", "RANK": "0"})
+        except subprocess.TimeoutExpired:
+            out[name] = f"timed out after {left:.0f} s"
+            continue
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            out[name] = f"failed (rc {r.returncode}): {r.stderr[-300:]}"
+            continue
+        d = json.loads(line[-1])
+        if name == "c5":
+            out[name] = d
+        else:
+            rf = d["roofline"]
+            out[name] = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "tokens_per_s": d["value"],
+                         "executed_tflops_per_gpu": d["executed_tflops_per_gpu"],
+                         "mfma_roofline_frac_step_executed": d["mfma_roofline_frac_step_executed"],
+                         "gemm": {"bound": "mfma", "achieved": rf["achieved"], "peak": rf["peak"], "frac": rf["frac"],
+                                  "launches": rf["launches"], "gemm_share_of_step": rf["gemm_share_of_step"],
+                                  "by_kernel": {k: v["achieved_tflops"] for k, v in rf["by_kernel"].items()}}}
     return out
 
 
@@ -185,6 +294,9 @@ def _self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this pool
     env.setdefault("OMP_NUM_THREADS", "4")
+    if not args.dry_run_launch:
+        import __graft_entry__ as ge
+        ge.build()                                             # build (or verify the digests) ONCE, before any rank exists
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            *[a for a in argv if a != "--dry-run-launch"]]
@@ -194,11 +306,30 @@ def _self_launch(args, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def attention_flops_per_step(cfg, enc_cfg, B, T, K, train_bio=False):
+def parse_micro(spec: str):
+    """"protein:1024;dna:1000" -> [[("protein", 1024)], [("dna", 1000)]]: the micro-batches of one optimizer step (GA = their
+    number), each a list of omic spans every sample of that micro-batch carries."""
+    out = []
+    for mb in spec.split(";"):
+        spans = []
+        for sp in mb.split(","):
+            typ, k = sp.strip().split(":")
+            assert typ in ("dna", "rna", "protein"), typ
+            spans.append((typ, int(k)))
+        out.append(spans)
+    return out
+
+
+def attention_flops_per_step(cfg, enc_cfgs, B, T, micro, train_bio=False):
     """Executed attention matmul FLOPs counted the way SURVEY §8d counts them (causal half for the decoder, fwd + 2x bwd,
-    no recompute credit; full K x K forward only for the frozen encoder)."""
-    llm = 3 * 4 * cfg.num_hidden_layers * cfg.num_attention_heads * cfg.head_dim * (T / 2) * T * B
-    enc = (3 if train_bio else 1) * 4 * enc_cfg.num_hidden_layers * enc_cfg.hidden_size * K * K * B
+    no recompute credit; full K x K forward only for a frozen encoder).  enc_cfgs = {"dna_rna": cfg, "protein": cfg};
+    micro = parse_micro(...)."""
+    llm = 3 * 4 * cfg.num_hidden_layers * cfg.num_attention_heads * cfg.head_dim * (T / 2) * T * B * len(micro)
+    enc = 0.0
+    for spans in micro:
+        for typ, K in spans:
+            ec = enc_cfgs["protein" if typ == "protein" else "dna_rna"]
+            enc += (3 if train_bio else 1) * 4 * ec.num_hidden_layers * ec.hidden_size * K * K * B
     return llm + enc
 
 
@@ -228,7 +359,15 @@ def main(argv=None):
     ap.add_argument("--event-stride", type=int, default=7,
                     help="HIP events around every n-th GEMM launch of the timed region (1 = all: 2-3 %% slower steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=30.0, help="wall-time box (s) of the down-scaled-C2 CPU run; C1 gets half")
+    ap.add_argument("--cpu-budget", type=float, default=150.0,
+                    help="wall-time box (s) of the down-scaled-C2 CPU run (2 warm-ups + 5 timed steps of ~12 s fit); C1 gets half")
+    ap.add_argument("--micro", default=None,
+                    help='micro-batches of one optimizer step, ";"-separated, each a ","-list of type:K omic spans per sample '
+                         '(GA = their number).  Default "protein:<k-protein>".  C3: "dna:512,rna:512,protein:512;dna:512,rna:512,'
+                         'protein:512"   C4: "protein:1024;dna:1000"')
+    ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE configs 3 / 4 / 5 side measurements")
+    ap.add_argument("--secondary-budget", type=float, default=420.0, help="wall-time box (s) of the whole secondary block")
+    ap.add_argument("--secondary-worker", default=None, help="(internal) c3 | c4 | c5: run that side measurement, print its JSON")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("CONFIG", "THREADS", "BUDGET_S"))
     ap.add_argument("--dry-run-launch", action="store_true", help="print the rank launch command instead of running it")
     args = ap.parse_args(argv)
@@ -236,6 +375,8 @@ def main(argv=None):
         w = args.cpu_baseline_worker
         _cpu_step_worker(w[0], int(w[1]), float(w[2]))
         return 0
+    if args.secondary_worker == "c5":
+        return _c5_worker()
 
     # ---- N > 1 without a launcher: start the ranks ourselves (before any GPU call in this process) -----------------
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -250,6 +391,11 @@ def main(argv=None):
     # one device, MOLLY_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
     if "MOLLY_BENCH_DEVICE" in os.environ:
         local = int(os.environ["MOLLY_BENCH_DEVICE"])
+    # the library is built (normally: its digests verified, nothing compiled) BEFORE this process touches the GPU or joins a
+    # process group — under a file lock, so that under an external launcher every rank may call it: no hipcc child is ever
+    # spawned from a GPU-initialised rank while the others sit in a barrier
+    import __graft_entry__ as ge
+    ge.build()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import datetime
@@ -265,10 +411,6 @@ def main(argv=None):
         if world > 1:
             dist.barrier(**({"device_ids": [local]} if backend == "nccl" else {}))
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    barrier()
     import molly_amd
     from molly_amd import config as C, ops
     from molly_amd.synth import synth_batch
@@ -277,7 +419,9 @@ def main(argv=None):
 
     comm_check = preflight_collectives(dev) if world > 1 else None   # tiny in-place RS/AG/AR with known answers: fail fast
 
-    cfg = C.molly(args.model, k_tokens=args.k_protein)
+    micro = parse_micro(args.micro or f"protein:{args.k_protein}")
+    GA = len(micro)
+    cfg = C.molly(args.model, k_tokens=max(k for spans in micro for _, k in spans))
     m = molly_amd.OmicsOne(cfg)
     m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)
     m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
@@ -298,11 +442,13 @@ def main(argv=None):
     m.attach_optimizer(opt)
 
     B, T, K = args.batch, args.seq, args.k_protein
-    batches = [synth_batch(B, T, [("protein", K)], seed=42 + rank + 1000 * i) for i in range(4)]
+    # 4 different steps' worth of data; a step = GA micro-batches (gradients summed over the window, one optimizer step)
+    batches = [[synth_batch(B, T, spans, seed=42 + rank + 1000 * i + 100 * j) for j, spans in enumerate(micro)] for i in range(4)]
 
     def step(i):
-        b = batches[i % len(batches)]
-        loss = m.forward_backward(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"], b["labels"])
+        for j, b in enumerate(batches[i % len(batches)]):
+            loss = m.forward_backward(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"], b["labels"],
+                                      accumulate=j > 0, final_micro=j == GA - 1)
         opt.step(lr=3e-5)
         return loss
 
@@ -342,7 +488,12 @@ def main(argv=None):
         comm = {"backend": backend, "world_size": dist.get_world_size(), "preflight": comm_check,
                 "comm_bytes_per_step_per_gpu": opt.comm_bytes_per_step(), "bucket_mib": round(opt.bucket * 2 / (1 << 20), 1),
                 "per_link_mib_per_bucket": round(opt.chunk * 2 / (1 << 20), 1), "buckets": len(opt.buckets),
-                "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo, "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256)}
+                "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo,
+                # where the gradient sum is rounded: the library's reduce-scatter adds bf16 partial sums hop by hop (DeepSpeed's
+                # own behaviour with bf16 gradients); the all-to-all variant sums the `world` copies in fp32 on the owner, once
+                "reduce_dtype": ("fp32 on the owning rank, rank order, one rounding (all_to_all + molly_reduce_rows)"
+                                 if opt.rs_algo == "a2a" else "bf16 in the collective (RCCL reduce_scatter: one rounding per hop)"),
+                "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256)}
         if backend == "nccl":
             try:
                 comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
@@ -359,7 +510,7 @@ def main(argv=None):
             comm["exposed_comm_ms_removed_by_overlap"] = round(statistics.median(ms2) - statistics.median(step_ms), 2)
 
     if rank == 0:
-        tokens = world * B * T * args.steps
+        tokens = world * B * T * GA * args.steps
         # dominant kernel = gemm256_kernel (the 256x256 ping-pong MFMA GEMM); its three operand-layout instantiations
         # are separate rows in rocprofv3 --stats.  Launches that went to the 128x128 kernel (small grids) are listed apart.
         # every GEMM launch of the timed region is listed; HIP events bracket every `stride`-th one (7: coprime with the 4- and
@@ -396,24 +547,29 @@ def main(argv=None):
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         tj = next((os.path.join(prof_dir, f) for f in ("r02b_hbm_traffic.json", "r02_hbm_traffic.json", "r01b_hbm_traffic.json")
                    if os.path.exists(os.path.join(prof_dir, f))), None)
-        if args.train_mode == "full" and (B, T, K, args.model) == (8, 2048, 512, "1.7b") and tj:
+        if args.train_mode == "full" and (B, T, K, args.model) == (8, 2048, 512, "1.7b") and args.micro is None and tj:
             with open(tj) as f:
                 tr = json.load(f)
             traffic, traffic_src = tr["gemm_hbm_bytes_per_launch"], tr["source"]
-        flops_step = B * (T * algorithmic_flops_per_token(cfg.text_config, T) +
-                          K * (enc_flops_per_token(cfg.protein_config, K) + 3 * 2 * cfg.protein_config.hidden_size *
-                               cfg.text_config.hidden_size))
+        enc_cfgs = {"dna_rna": cfg.dna_rna_config, "protein": cfg.protein_config}
+        flops_step = 0.0
+        for spans in micro:
+            flops_step += B * T * algorithmic_flops_per_token(cfg.text_config, T)
+            for typ, k in spans:
+                ec = enc_cfgs["protein" if typ == "protein" else "dna_rna"]
+                flops_step += B * k * (enc_flops_per_token(ec, k) + 3 * 2 * ec.hidden_size * cfg.text_config.hidden_size)
         # executed = what the kernels really ran: every GEMM launch's 2MNK (lm_head on the scored rows only) + the attention
         # matmuls (causal half, no recompute credit)
-        exec_step = gemm_flops_step + attention_flops_per_step(cfg.text_config, cfg.protein_config, B, T, K,
-                                                                args.train_mode == "bio")
+        exec_step = gemm_flops_step + attention_flops_per_step(cfg.text_config, enc_cfgs, B, T, micro, args.train_mode == "bio")
         sps = dt / args.steps
         out = {
             "metric": f"training tokens/sec Molly-{args.model.upper()} bf16", "value": round(tokens / dt, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Molly-{args.model.upper()} (Qwen3-{args.model.upper()} + NT-500M + ESM2-650M) train step, "
-                                   f"seq_len {T} text + {K}-residue protein span per sample, {B} samples/GPU, GA=1, "
+                                   f"seq_len {T} text + " + ("; ".join(" + ".join(f"{k}-token {t} span" for t, k in spans) for spans in micro)
+                                                             if args.micro else f"{K}-residue protein span") +
+                                   f" per sample, {B} samples/GPU, GA={GA}, "
                                    + {"full": "LLM+projectors trainable", "bio": "LLM+projectors+encoders trainable (--train-bio)", "lora": "LoRA r=64 adapters+projectors trainable, base frozen",
                                       "mlp": "projectors trainable, LLM frozen"}[args.train_mode] +
                                    ("" if args.train_mode == "bio" else ", encoders frozen") + f", ZeRO-{args.zero_stage} dp{world}",
@@ -437,6 +593,13 @@ def main(argv=None):
         }
         if comm is not None:
             out["comm"] = comm
+        if world == 1 and not args.no_secondary and args.secondary_worker is None:
+            # the other BASELINE configs, each in a child of its own: release this process's HBM first
+            del m, opt, rt, batches
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_block(args.secondary_budget)
         if not args.no_cpu_baseline and world == 1:                  # rank 0 at N=1 only (contract)
             out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
         print(json.dumps(out), flush=True)

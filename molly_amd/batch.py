@@ -106,16 +106,22 @@ class BatchStager:
             slot[1].synchronize()                # the copy that last used this image (ring steps ago) has long finished
         return slot
 
+    DEV_CACHE = 8          # distinct (B, T, shapes, image size) buffer sets kept; least recently used beyond that are dropped
+
     def _device_buffers(self, key, n_img, M, shapes, want_sort):
-        d = self._dev.get(key)
+        d = self._dev.pop(key, None)           # re-inserted below: dict order = recency
         if d is None:
+            # inference batches vary T with the prompt length: without a bound every distinct shape would keep its buffer set
+            # (and, with want_sort, its radix-sort workspace) for the life of the process
+            while len(self._dev) >= self.DEV_CACHE:
+                self._dev.pop(next(iter(self._dev)))
             e = lambda n, dt: torch.empty(max(int(n), 1), dtype=dt, device=self.dev)
             d = dict(img=e(n_img, torch.int32), labels_shifted=e(M, torch.int64), scored=e(M, torch.int32),
                      counts=torch.zeros(2, dtype=torch.int32, device=self.dev), overwritten=e(M, torch.uint8))
             for g, (N, K) in enumerate(shapes):
                 d[f"om{g}"] = e(N * K, torch.int64)
                 d[f"dst{g}"] = e(N * K, torch.int32)
-            self._dev[key] = d
+        self._dev[key] = d
         if want_sort and "order" not in d:
             e = lambda n, dt: torch.empty(max(int(n), 1), dtype=dt, device=self.dev)
             d.update(keys=e(2 * M, torch.int32), vals=e(M, torch.int32), order=e(M, torch.int32), seg=e(M + 1, torch.int32),

@@ -55,10 +55,23 @@ def _compile(src):
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile what is stale and link.  Serialised across processes by a file lock: the ranks of a multi-GPU launch may all call
+    it (before they touch the GPU); the first one in builds, the others find every digest current and return."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     if force:
         for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+            if f != ".lock":
+                os.remove(os.path.join(OBJ, f))
     with ThreadPoolExecutor(max_workers=6) as ex:
         res = list(ex.map(_compile, _sources()))
     objs = [o for o, _ in res]

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int CAP = 1024;
+constexpr int MAXV = 262144;                                   // vocabulary bound of the penalty's "seen" bitmap (32 KiB of LDS)
 
 __device__ __forceinline__ unsigned fkey(float v) {            // larger float -> larger unsigned
     const unsigned u = __builtin_bit_cast(unsigned, v);
@@ -35,18 +36,27 @@ __global__ __launch_bounds__(1024) void sample_kernel(float* __restrict__ logits
     __shared__ int s_idx[CAP];
     __shared__ unsigned s_prefix, s_need;
     __shared__ int s_cnt;
+    __shared__ unsigned seen[MAXV / 32];
+    __shared__ int s_wave[16];
     const int row = blockIdx.x, t = threadIdx.x;
     float* x = logits + (size_t)row * ld;
 
-    // ---- 1. repetition penalty: read every listed token's score first, then write (duplicates write the same value)
+    // ---- 1. repetition penalty, once per DISTINCT generated token whatever their number: the thread that sets a token's bit in
+    // the `seen` bitmap owns that token and is the only one to touch its score (HF gathers, rescales and scatters the same
+    // value for every duplicate)
     if (pen != 1.0f && n_gen > 0) {
         const long* g = gen + (size_t)row * ld_gen;
-        float keep[4];
-        int ids[4];
-        int m = 0;
-        for (int i = t; i < n_gen && m < 4; i += 1024) { ids[m] = (int)g[i]; keep[m] = x[ids[m]]; ++m; }
+        for (int i = t; i < (V + 31) / 32; i += 1024) seen[i] = 0u;
         __syncthreads();
-        for (int j = 0; j < m; ++j) x[ids[j]] = keep[j] < 0.f ? keep[j] * pen : keep[j] / pen;
+        for (int i = t; i < n_gen; i += 1024) {
+            const int id = (int)g[i];
+            if (id < 0 || id >= V) continue;
+            const unsigned bit = 1u << (id & 31);
+            if (!(atomicOr(&seen[id >> 5], bit) & bit)) {
+                const float v = x[id];
+                x[id] = v < 0.f ? v * pen : v / pen;
+            }
+        }
         __syncthreads();
     }
 
@@ -93,6 +103,42 @@ __global__ __launch_bounds__(1024) void sample_kernel(float* __restrict__ logits
         }
     }
     __syncthreads();
+    if (s_cnt > CAP) {
+        // more than CAP scores tie with the k-th largest (block-uniform, rare): the atomic order above would decide which ties
+        // survive.  Redo it deterministically: every score strictly above the threshold (fewer than k <= CAP of them), then the
+        // ties by ascending token id until the list is full.
+        __syncthreads();
+        if (t == 0) s_cnt = 0;
+        s_val[t] = -INFINITY;
+        s_idx[t] = 0x7fffffff;
+        __syncthreads();
+        for (int i = t; i < V; i += 1024) {
+            const float v = x[i];
+            if (fkey(v) > thr) {
+                const int p = atomicAdd(&s_cnt, 1);
+                s_val[p] = v; s_idx[p] = i;
+            }
+        }
+        __syncthreads();
+        int filled = s_cnt;                                          // block-uniform from here on
+        for (int i0 = 0; i0 < V && filled < CAP; i0 += 1024) {
+            const int i = i0 + t;
+            const float v = i < V ? x[i] : 0.f;
+            const bool tie = i < V && fkey(v) == thr;
+            const unsigned long long bal = __ballot(tie);
+            const int lane = t & 63, w = t >> 6;
+            if (lane == 0) s_wave[w] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int j = 0; j < 16; ++j) { if (j < w) before += s_wave[j]; total += s_wave[j]; }
+            const int p = filled + before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (tie && p < CAP) { s_val[p] = v; s_idx[p] = i; }
+            filled = min(filled + total, CAP);
+            __syncthreads();
+        }
+        if (t == 0) s_cnt = filled;
+        __syncthreads();
+    }
     const int n = min(s_cnt, CAP);
     for (int size = 2; size <= CAP; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -152,7 +198,8 @@ extern "C" int molly_sample_logits(void* stream, float* logits, int rows, int V,
     MOLLY_CHECK(rows > 0 && V > 0 && ld >= V, "sample_logits: rows=%d V=%d ld=%d", rows, V, ld);
     MOLLY_CHECK(top_k >= 1 && top_k <= CAP, "sample_logits: top_k=%d outside 1..%d (no-top-k sampling is not built)", top_k, CAP);
     MOLLY_CHECK(temperature > 0.f && top_p > 0.f && repetition_penalty > 0.f, "sample_logits: temperature / top_p / penalty must be > 0");
-    MOLLY_CHECK(n_generated <= 4096, "sample_logits: at most 4096 generated tokens enter the repetition penalty (got %d)", n_generated);
+    MOLLY_CHECK(V <= MAXV, "sample_logits: V=%d exceeds the %d-token bitmap of the repetition penalty", V, MAXV);
+    MOLLY_CHECK(n_generated >= 0, "sample_logits: n_generated=%d", n_generated);
     MOLLY_CHECK(n_generated == 0 || generated, "sample_logits: %d generated tokens without their ids", n_generated);
     MOLLY_CHECK((probs_out_or_null == nullptr) == (ids_out_or_null == nullptr), "sample_logits: probs_out and ids_out go together");
     hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, V, ld, (const long*)generated,

@@ -210,7 +210,13 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
     # sampling with a top-k (the reference's inference settings: top_k 20) runs in ONE kernel per step: penalty, temperature,
     # top-k, top-p, softmax and the draw (csrc/sampling.hip).  Without a top-k the torch restatement below is used.
     fused = bool(do_sample and top_k and 1 <= top_k <= 1024 and logits.dtype == torch.float32)
-    seed = (generator.initial_seed() if generator is not None else torch.initial_seed()) & ((1 << 64) - 1)
+    # The Philox stream is keyed by (seed, step, row).  The seed is DRAWN from the generator (or torch's global one), so it is
+    # reproducible under manual_seed and — like torch.multinomial in the reference path — advances the generator's state:
+    # two calls with one generator (inference.py passes one for the whole dataset) get independent samples.
+    seed = 0
+    if fused:
+        gdev = generator.device if generator is not None else "cpu"
+        seed = int(torch.randint(0, 1 << 62, (1,), generator=generator, device=gdev, dtype=torch.int64).item())
     for it in range(max_new_tokens):
         if fused:
             nxt = ops.sample_logits(logits, out if out.shape[1] else None, repetition_penalty, temperature, top_k, top_p,

@@ -257,7 +257,10 @@ class OmicsOne(_MetaSafe):
 
         Trainable group (what `rt.P` / `rt.G` / `n_decay` describe and the ZeRO-2 optimizer steps) — reference
         src/utils/tools.py:313-338 (`set_up_trainable_param`) and :345-396 (`pre_train_lora`):
-          train_llm                      -> the whole LLM + the projectors (reference default `--train-llm --train-mlp`)
+          train_llm                      -> the whole LLM + the projectors (reference default `--train-llm --train-mlp`);
+                                            without train_mlp (`--train-llm` alone, tools.py:313-338 accepts any combination)
+                                            the projectors stay OUTSIDE the flat group as frozen buffers: the backward still
+                                            runs through the injected rows' text neighbours, nothing is computed for them
           lora=LoraConfig (`--use-lora`) -> rank-r adapters on every LLM Linear except lm_head + the projectors; base frozen
           train_mlp only                 -> the two projectors; the LLM is frozen (backward only propagates through it)
           neither                        -> nothing (inference)
@@ -279,8 +282,6 @@ class OmicsOne(_MetaSafe):
             dev = torch.device("cuda", torch.cuda.current_device())
         if train_llm and lora is not None:
             raise ValueError("lora and train_llm are exclusive: the reference freezes the base under --use-lora")
-        if train_llm and not train_mlp:
-            raise NotImplementedError("--train-llm without --train-mlp (frozen projectors inside the LLM's flat group)")
         sd = self.state_dict()
         pw, pb = projector_specs(self.text_config, self.dna_rna_config, self.protein_config)
         full = bool(train_llm)
@@ -295,8 +296,13 @@ class OmicsOne(_MetaSafe):
                 enc_d += [(n, sh) for n, sh in specs if not is_no_decay(n)]
                 enc_nd += [(n, sh) for n, sh in specs if is_no_decay(n)]
         Q = None
+        frozen_proj = None
         if full or not adapters:
             decay, no_decay = trainable_specs(self.text_config, self.dna_rna_config, self.protein_config)
+            if full and not train_mlp:
+                # `--train-llm` alone: the flat (ZeRO) group is the LLM only; the projectors are frozen buffers of their own
+                decay, no_decay = llm_param_specs(self.text_config), llm_norm_specs(self.text_config)
+                frozen_proj = FlatBuffer(pw + pb, dev)
             base = FlatBuffer(decay + enc_d + no_decay + enc_nd, dev, pad_to=8 * 64)
             n_decay = base.offsets[no_decay[0][0]]
         else:
@@ -316,7 +322,8 @@ class OmicsOne(_MetaSafe):
             # frozen encoders own a buffer each; trained ones live in the trainable group
             enc[pre] = (base if (full or not adapters) else Q) if train_bio else FlatBuffer(specs, dev)
         gen = None
-        bufs = [base] + ([Q] if Q is not None else []) + ([] if train_bio else list(enc.values()))
+        bufs = [base] + ([Q] if Q is not None else []) + ([frozen_proj] if frozen_proj is not None else []) + \
+            ([] if train_bio else list(enc.values()))
         for buf in bufs:
             for n, v in buf.views.items():
                 if ".lora_" in n:
@@ -370,6 +377,8 @@ class OmicsOne(_MetaSafe):
         rt.W = dict(base.views)                               # name -> weight view, whichever buffer owns it
         if Q is not None:
             rt.W.update(Q.views)
+        if frozen_proj is not None:
+            rt.W.update(frozen_proj.views)
         lora_rt = None
         if lora is not None:
             from .lora import LoraRuntime
@@ -402,8 +411,6 @@ class OmicsOne(_MetaSafe):
             devs = {t.device for t in list(self.parameters()) + list(self.buffers()) if t.is_cuda}
             device = devs.pop() if len(devs) == 1 else "cuda"
         llm, mlp, bio = self.infer_trainable() if self.training else (False, False, False)    # .eval(): inference only
-        if llm and not mlp:
-            raise NotImplementedError("--train-llm without --train-mlp (frozen projectors inside the LLM's flat group)")
         return self.prepare(device, train_llm=llm, train_mlp=mlp, train_bio=bio, **kw)
 
     def _runtime(self):

@@ -152,6 +152,18 @@ class Trainer:
             n_micro -= n_micro % self.world
         return n_micro // self.world
 
+    def _mirror_skipped(self):
+        scal = getattr(self.opt, "scal", None)
+        if scal is None or not scal.is_cuda:
+            return
+        if getattr(self, "_skip_host", None) is None:
+            self._skip_host = torch.zeros(1, dtype=torch.float32, pin_memory=True)
+        self._skip_host.copy_(scal[3:4], non_blocking=True)
+
+    def _skipped_seen(self) -> int:
+        h = getattr(self, "_skip_host", None)
+        return int(h[0]) if h is not None else 0
+
     def train(self):
         """Window bookkeeping of the pasted HF loop (reference src/trainer/domain_loss.py:584-608): an epoch of
         `steps_in_epoch` micro-batches makes ceil(steps_in_epoch / GA) optimizer steps — the LAST window of an epoch may be
@@ -180,8 +192,13 @@ class Trainer:
                 in_window += 1
                 if not do_sync:
                     continue
-                lr = linear_warmup_lr(step, a.learning_rate, warmup, total)
+                # DeepSpeed (what the reference runs under) does not step the LR scheduler on an overflow-skipped step: the
+                # schedule's tick is the number of steps APPLIED.  The skipped counter lives on the device; it is mirrored into
+                # pinned memory by an asynchronous copy after every step, so the tick trails a skip by at most one optimizer step
+                # and the loop never waits for the GPU.
+                lr = linear_warmup_lr(step - self._skipped_seen(), a.learning_rate, warmup, total)
                 gnorm = self.opt.step(lr=lr)
+                self._mirror_skipped()
                 step += 1
                 in_window = 0
                 if step % a.logging_steps == 0 or step == total:
@@ -194,8 +211,9 @@ class Trainer:
                            "grad_norm": float(gnorm.item()), "learning_rate": lr,
                            "epoch": round(epoch + (mi + 1) / micro_per_epoch, 4), "elapsed_s": round(time.time() - t0, 2)}
                     skipped = getattr(self.opt, "skipped_steps", None)
-                    if skipped is not None and int(skipped()) > 0:
-                        rec["skipped_steps"] = int(skipped())
+                    n_skipped = int(skipped()) if skipped is not None else 0      # one host read per log line
+                    if n_skipped > 0:
+                        rec["skipped_steps"] = n_skipped
                     last_logged = step
                     window_loss.zero_()
                     self.history.append(rec)

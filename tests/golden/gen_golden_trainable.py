@@ -22,7 +22,8 @@ import gen_golden as G  # noqa: E402
 def main():
     torch.manual_seed(0)
     out = {"config": {k: G.TINY[k] for k in ("text", "dna_rna", "protein", "K")}, "cases": []}
-    for train_llm, train_mlp, train_bio in ((True, True, False), (False, True, False), (True, True, True), (False, False, False)):
+    for train_llm, train_mlp, train_bio in ((True, True, False), (False, True, False), (True, True, True), (False, False, False),
+                                           (True, False, False)):
         m, shapes = G.build_reference_model(G.TINY)
         import utils.tools as T                      # the reference's module (sys.path set by build_reference_model)
         keys_before = [k for k in m.state_dict().keys()]

@@ -198,3 +198,67 @@ def test_sampling_kernel_matches_hf_logits_processors():
     a = ops.sample_logits(dev_logits.clone(), gen.cuda(), 1.1, 0.8, 20, 0.95, seed=7, step=5)
     b = ops.sample_logits(dev_logits.clone(), gen.cuda(), 1.1, 0.8, 20, 0.95, seed=7, step=5)
     assert torch.equal(a, b)
+
+
+def test_sampling_long_history_and_tie_overflow_are_deterministic():
+    """(a) more than 4096 generated tokens enter the repetition penalty (the kernel once took at most 4 per thread), each
+    DISTINCT token once; (b) more than 1024 scores tying with the k-th largest: the survivors are the strictly larger scores
+    plus the ties of lowest token id, the same set on every launch."""
+    from molly_amd import ops
+    V = 151936
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(2, V, generator=g) * 2.0
+    gen = torch.randint(0, V, (2, 9000), generator=g)
+    gen[:, 4500:] = gen[:, :4500]                                 # every token listed twice
+    top = logits.topk(20, dim=1).indices
+    gen[:, 8000:8020] = top                                       # the whole top-20 was generated before (positions > 4096)
+    want = logits.clone()
+    for r in range(2):
+        ids = gen[r].unique()
+        v = want[r, ids]
+        want[r, ids] = torch.where(v < 0, v * 1.3, v / 1.3)
+    wk = (want / 0.8).topk(20, dim=1)
+    _, (probs, ids, n_kept) = ops.sample_logits(logits.cuda(), gen.cuda(), 1.3, 0.8, 20, 1.0, seed=1, step=0, debug_cap=32)
+    torch.cuda.synchronize()
+    for r in range(2):
+        assert int(n_kept[r]) == 20
+        assert sorted(ids[r, :20].cpu().tolist()) == sorted(wk.indices[r].tolist())
+        assert torch.allclose(probs[r, :20].cpu(), wk.values[r].softmax(-1), rtol=1e-4, atol=1e-6)
+    # (b) 3000 scores tie at the top, top_k = 1024, five scores above them
+    tie = torch.full((1, V), -5.0)
+    pos = torch.randperm(V, generator=g)[:3000].sort().values
+    tie[0, pos] = 1.0
+    above = torch.tensor([17, 40000, 90001, 120000, 151935])
+    above = above[~torch.isin(above, pos)]
+    tie[0, above] = 2.0
+    expect = sorted(above.tolist() + pos[:1024 - len(above)].tolist())
+    got = None
+    for rep in range(3):
+        _, (p_, ids_, n_) = ops.sample_logits(tie.cuda(), None, 1.0, 1.0, 1024, 1.0, seed=2, step=rep, debug_cap=1024)
+        torch.cuda.synchronize()
+        assert int(n_[0]) == 1024
+        cur = sorted(ids_[0].cpu().tolist())
+        assert cur == expect
+        got = cur if got is None else got
+        assert cur == got
+
+
+def test_sampled_generate_calls_with_one_generator_are_independent(tiny_meta):
+    """Advisor finding (round 2): the Philox seed was generator.initial_seed(), which never advances — every generate() call of
+    a dataset drew the same uniforms.  The seed is now drawn from the generator: same manual_seed -> same tokens, two calls in
+    a row -> different streams (as torch.multinomial behaves in the reference path, src/inference_lora.py:293-298)."""
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)
+    kw = dict(do_sample=True, temperature=1.5, top_p=1.0, top_k=200, repetition_penalty=1.0, max_new_tokens=12)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = m.generate(ids, mask, omic, info, generator=g, **kw)
+    b = m.generate(ids, mask, omic, info, generator=g, **kw)
+    assert not torch.equal(a, b)                                   # 24 draws from >= 200 candidates each: equal only by a bug
+    g2 = torch.Generator(device="cuda").manual_seed(0)
+    assert torch.equal(a, m.generate(ids, mask, omic, info, generator=g2, **kw))
+    torch.manual_seed(123)                                         # no generator: torch's global stream, consumed per call
+    c = m.generate(ids, mask, omic, info, **kw)
+    d = m.generate(ids, mask, omic, info, **kw)
+    assert not torch.equal(c, d)
+    torch.manual_seed(123)
+    assert torch.equal(c, m.generate(ids, mask, omic, info, **kw))

@@ -197,6 +197,41 @@ def test_projector_only_mode_matches_full_mode_projector_grads(tiny_meta):
         ["dna_rna_projector.weight", "dna_rna_projector.bias", "protein_projector.weight", "protein_projector.bias"]
 
 
+def test_train_llm_without_train_mlp_keeps_the_projectors_frozen(tiny_meta):
+    """`--train-llm` alone (reference: src/utils/tools.py:313-338 accepts any flag combination; the set it leaves behind is the
+    (True, False, False) case of tests/golden/trainable_sets.json): the flat ZeRO group is the LLM only, every LLM gradient
+    equals the full mode's bit for bit, and an optimizer step leaves the projectors untouched."""
+    import json
+    from molly_amd.trainer import Zero2Optimizer
+    with open(os.path.join(os.path.dirname(__file__), "golden", "trainable_sets.json")) as f:
+        case = next(c for c in json.load(f)["cases"] if (c["train_llm"], c["train_mlp"], c["train_bio"]) == (True, False, False))
+    b = _batch(tiny_meta, seed=21)
+    full = _build(tiny_meta)
+    lf = full.forward_backward(*_args(b))
+    llm = _build(tiny_meta, train_llm=True, train_mlp=False)
+    ll = llm.forward_backward(*_args(b))
+    torch.cuda.synchronize()
+    assert lf.item() == ll.item()
+    assert not any("projector" in n for n in llm._rt.G.views)
+    assert set(llm._rt.G.views) == {n for n in full._rt.G.views if "projector" not in n}
+    for n, g in llm._rt.G.views.items():
+        assert torch.equal(g, full._rt.G.views[n]), n
+    keys = set(llm.state_dict().keys())
+    assert sorted(n for n, p_ in llm.named_parameters() if p_.requires_grad) == sorted(n for n in case["trainable"] if n in keys)
+    before = {n: llm._rt.W[n].clone() for n in llm._rt.W if "projector" in n}
+    emb0 = llm._rt.W["model.model.embed_tokens.weight"].clone()
+    opt = Zero2Optimizer(llm._rt.P.flat, llm._rt.G.flat, llm.n_decay, lr=1e-2)
+    llm.attach_optimizer(opt)
+    opt.step(lr=1e-2)
+    opt.wait_all_params()
+    torch.cuda.synchronize()
+    assert len(before) == 4 and all(torch.equal(v, llm._rt.W[n]) for n, v in before.items())
+    assert not torch.equal(emb0, llm._rt.W["model.model.embed_tokens.weight"])
+    # a second micro-step still runs (the injected rows read the frozen projectors) and the loss moved
+    l2 = llm.forward_backward(*_args(b))
+    assert torch.isfinite(l2).item() and l2.item() != ll.item()
+
+
 def test_lora_training_saves_a_peft_adapter_that_merges_back(tiny_meta, tmp_path):
     """A few optimizer steps on the adapter group, then: the loss went down, the base did not move, the pad stayed zero,
     `save_adapter` wrote the PEFT layout, and a fresh model with the adapter MERGED reproduces the live-adapter logits."""
