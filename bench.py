@@ -512,7 +512,8 @@ def main(argv=None):
     if rank == 0:
         tokens = world * B * T * GA * args.steps
         # dominant kernel = gemm256_kernel (the 256x256 ping-pong MFMA GEMM); its three operand-layout instantiations
-        # are separate rows in rocprofv3 --stats.  Launches that went to the 128x128 kernel (small grids) are listed apart.
+        # are separate rows in rocprofv3 --stats, its stream-K form (encoder projections and other grids that do not fill whole
+        # rounds of the chip) another three.  Launches that went to the 128x128 kernel (a side narrower than a tile) are listed apart.
         # every GEMM launch of the timed region is listed; HIP events bracket every `stride`-th one (7: coprime with the 4- and
         # 9-GEMM patterns of the decoder / encoder layers, so every shape is sampled).  Per class, the launches that were not
         # timed are priced at the class's sampled rate.
@@ -523,11 +524,12 @@ def main(argv=None):
         names = {(False, False): "NT gemm256_kernel<false,false>", (False, True): "NN gemm256_kernel<false,true>",
                  (True, True): "TN gemm256_kernel<true,true>"}
         def klass(kcfg, lay):
-            # (the 128x128 launches of the step are the frozen encoders' o / ffn1 projections: they run BESIDE the previous step's
-            # side-stream AdamW, so their per-launch time is a shared-chip time — in isolation 540-800 TF/s, tools/bench_gemm.py)
-            key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64> (encoder o/ffn1, beside the side-stream AdamW)"
-            if kcfg >= 100000:                    # grouped launch: cfg = 512 + 1000 + 100000 * problems
+            # cfg = 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems of a grouped launch)
+            key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64> (a side narrower than a tile)"
+            if kcfg >= 100000:
                 key += f" grouped x{kcfg // 100000} (a layer's weight gradients in one launch)"
+            elif kcfg // 1000 >= 50:
+                key += " stream-K (grids that do not fill whole rounds: encoder projections, B=1 decoder shapes)"
             elif kcfg // 1000 > 1:
                 key += " + splitk_reduce"
             return key

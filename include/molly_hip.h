@@ -13,12 +13,12 @@
  *  - bf16 tensors are uint16 storage, row-major, innermost dimension contiguous; `ld*` are in ELEMENTS;
  *  - return 0 on success; non-zero on a rejected argument or launch failure, message via
  *    molly_last_error() (thread-local).  Nothing is silently ignored.
- *  - threading: ONE host thread drives the library per process — the reference's process model (one Python process per GPU,
- *    a single host thread calls the model: SURVEY.md 8b; src/train.py:602-603).  The error message is thread-local, but the
- *    tuning knobs (molly_gemm_set_*, molly_gemm_set_workspace, molly_gemm_force_tile) and molly_gemm_last_config() are
- *    process-wide and unsynchronised: set them before launching, from that thread.  Launching from several host threads or
- *    onto several streams concurrently is supported only with the knobs left alone and split-K scratch not shared
- *    (molly_gemm_set_workspace(NULL, 0) disables split-K).
+ *  - threading: the error message and the DEFAULT GEMM context (what molly_gemm_bf16 / molly_gemm_grouped_bf16 launch through
+ *    and the molly_gemm_set_* setters edit) are thread-local: a host thread never inherits another's knobs or scratch memory.
+ *    Everything a GEMM launch decision reads — launch shape, schedule, tile choice, scratch — lives in a context
+ *    (molly_gemm_ctx_*); the *_ctx entry points launch through an explicit one, so two models (or a trainer and an evaluator)
+ *    in one process keep separate launch state.  One context must not launch onto two streams at the same time (its scratch
+ *    memory is shared by its launches); contexts with their own scratch may.
  */
 #ifndef MOLLY_HIP_H
 #define MOLLY_HIP_H
@@ -66,8 +66,6 @@ int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, cons
 int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N,
                     int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor, int b_kmajor);
 
-/* fp32 scratch the GEMM may use for split-K partial slabs (wgrad shapes whose 256x256 grid would not fill the chip);
- * caller-owned device memory, stays valid until replaced; NULL / 0 disables split-K. */
 /* Grouped launch of up to 16 GEMMs that share K, the operand layouts (A k-contiguous [M][K], B k-major [K][N]: the dgrad /
  * weight-gradient form) and the epilogue flags (MOLLY_GEMM_ACCUMULATE, MOLLY_GEMM_OUT_F32); each problem has its own
  * pointers, sizes and transposed-output choice (trans_out != 0: C is [N][M], ldc >= M).  One persistent launch walks the
@@ -79,23 +77,56 @@ typedef struct {
     int M, N, lda, ldb, ldc, trans_out;
 } molly_gemm_problem;
 int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* problems, int count, int K, int flags);
+
+/* ---- launch state: contexts.  A context holds the launch knobs (MOLLY_GEMM_KEY_*), the scratch memory and the record of the
+ * last configuration; NULL = the calling thread's default context.  The reference has no such state: cuBLAS picks its kernels
+ * per call (every nn.Linear, HF:models/qwen3/modeling_qwen3.py:76-83 et al.); this is the boundary's equivalent of a cuBLAS
+ * handle + workspace. */
+enum {
+    MOLLY_GEMM_KEY_PERSISTENT_BLOCKS = 1, /* 256x256 kernel: resident blocks (default 256 = one per CU; a multiple of 8); 0 = one
+                                             block per tile; -t = blocks of t tiles each (placed by the hardware dispatcher on
+                                             whatever CUs are free: the setting for a GEMM that runs beside a collective).
+                                             Stream-K launches take the same three forms (shares instead of tiles). */
+    MOLLY_GEMM_KEY_SCHEDULE = 2,          /* barrier schedule of the 256x256 kernel: -1 / 0 = four phases (16 MFMAs each) per
+                                             K-tile (default), 1 = two phases (32 MFMAs); an A/B knob */
+    MOLLY_GEMM_KEY_FORCE_TILE = 3,        /* 0 = heuristic, 128 = force the 128x128 kernel, 512 = force the 256x256 kernel */
+    MOLLY_GEMM_KEY_GROUP_M = 4,           /* M-tiles per group in the 256x256 kernel's tile walk (L2 locality; default 4) */
+    MOLLY_GEMM_KEY_SMALL_GRID_TILE = 5,   /* with stream-K off: 128 (default) | 512 for grids that fill the chip neither plain
+                                             nor split-K */
+    MOLLY_GEMM_KEY_MIN_KTILES = 6,        /* split-K: shortest K-slice, in 64-wide K-tiles, for a grid that is not skinny (16) */
+    MOLLY_GEMM_KEY_STREAMK = 7,           /* 1 (default): a grid with M, N >= 256 that does not fill whole rounds of the 256 CUs runs
+                                             as ONE stream-K launch (every block an equal share of all tiles' K-tiles; the pieces of
+                                             a cut tile combined inside the launch by whichever piece finishes last, in a fixed
+                                             order: deterministic) WHERE that beats split-K slabs + reduce launch / the 128x128
+                                             kernel by the launcher's cost model (long contractions just past a whole round);
+                                             2: wherever stream-K is able to run (tests, tools); 0: never */
+    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
+                                             of a grouped launch) of the context's most recent launch */
+};
+int molly_gemm_ctx_create(void** out);
+int molly_gemm_ctx_destroy(void* ctx);
+int molly_gemm_ctx_set(void* ctx, int key, long value);
+int molly_gemm_ctx_get(void* ctx, int key);                 /* the value (an answer, not a status); -1 = unknown key */
+/* scratch of a context: device memory the caller owns, 256-byte aligned, valid until replaced; NULL / 0 = none (no split-K, no
+ * stream-K).  Layout: a 512 KiB + 64 B header (stream-K's error word and one counter line per tile; cleared here, synchronously,
+ * once) followed by fp32 slabs: split-K partial sums [splits][M][N], or stream-K's two 256 KiB accumulator images per block.
+ * 129 MiB serve every stream-K launch of 256 blocks. */
+int molly_gemm_ctx_set_workspace(void* ctx, void* ptr, long bytes);
+int molly_gemm_ctx_streamk_timeouts(void* ctx);            /* diagnostics: non-zero = a stream-K wait gave up (device read) */
+int molly_gemm_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
+                        int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor, int b_kmajor);
+int molly_gemm_grouped_bf16_ctx(void* ctx, void* stream, const molly_gemm_problem* problems, int count, int K, int flags);
+
+/* The same knobs on the calling thread's DEFAULT context (kept for tools and tests) */
 int molly_gemm_set_workspace(void* ptr, long bytes);
-/* configuration the most recent GEMM call used: 128 (128x128 kernel) | 512 (the 256x256 ping-pong kernel) + 1000 * split-K factor */
 int molly_gemm_last_config(void);
-/* tuning hook: M-tiles per group in the 256x256 kernel's tile walk (L2 locality; default 4) */
-int molly_gemm_set_small_grid_tile(int tile);   /* A/B knob: 128 (default) | 512 for grids that fill the chip neither plain nor split-K */
+int molly_gemm_set_small_grid_tile(int tile);
 int molly_gemm_set_group_m(int g);
-/* tuning hook: resident blocks of the persistent 256x256 kernel (default 256 = one per CU; multiple of 8);
- * 0 = launch one block per tile; -t = blocks of t tiles each (ceil(work / t) blocks, placed by the hardware dispatcher on
- * whatever CUs are free: the setting for a GEMM that runs beside a collective). */
 int molly_gemm_set_persistent_blocks(int n);
-/* split-K: shortest K-slice, in 64-wide K-tiles, the heuristic accepts for a grid that is not skinny (default 16). */
 int molly_gemm_set_min_ktiles(int n);
-/* tuning hook: barrier schedule of the 256x256 kernel: 0 = four phases (16 MFMAs each) per K-tile, 1 = two phases (32 MFMAs),
- * -1 (default) = two phases for the forms with a k-major B operand, four for the rest (what measured faster). */
 int molly_gemm_set_schedule(int mode);
-/* tuning/test hook: 0 = heuristic, 128 = force the 128x128 kernel, 512 = force the 256x256 kernel. */
 int molly_gemm_force_tile(int bm);
+int molly_gemm_set_streamk(int on);
 
 /* out[C,R] = in[R,C]^T (bf16).  Used to keep W^T copies for dgrad and X^T / dY^T for wgrad. */
 int molly_transpose_bf16(void* stream, const void* in, void* out, int R, int C, int ld_in, int ld_out);

@@ -66,7 +66,8 @@ def _bind_torch_hip_runtime():
 
 
 class MollyLib:
-    def __init__(self, path: str = LIB_PATH):
+    def __init__(self, path: str = LIB_PATH, strict: bool = True):
+        """strict=False (tools only: an OLDER build loaded beside the in-tree one for an A/B) binds what that library exports."""
         if not os.path.exists(path):
             raise RuntimeError(
                 f"molly_amd: HIP library {path} is missing — build it with `python -m molly_amd.build` "
@@ -77,7 +78,12 @@ class MollyLib:
         self.protos = parse_header()
         self.fn = {}
         for name, (restype, al) in self.protos.items():
-            f = getattr(self.cdll, name)           # AttributeError = header/library mismatch: fail loudly
+            try:
+                f = getattr(self.cdll, name)       # AttributeError = header/library mismatch: fail loudly
+            except AttributeError:
+                if strict:
+                    raise
+                continue
             f.restype = restype
             f.argtypes = [t for _, t in al]
             self.fn[name] = f

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         bf16x8 kf[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) kf[s] = row_frag<HD>(sK, 32 * sub + r, s, h);
+        // every read in flight before the first MFMA: left alone hipcc recycles ONE fragment register and runs
+        // read -> lgkmcnt(0) -> MFMA eight times in a row (an LDS round trip per 32-cycle MFMA)
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 sc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[e] = 0.f;

@@ -36,6 +36,11 @@ struct GemmArgs {
     int splits;               // split-K factor of the 256x256 kernel (1 = none)
     int group_m;              // M-tiles per group in the tile walk of the 256x256 kernel
     float* ws;                // fp32 partial slabs [splits][M][N] when splits > 1
+    // stream-K (gemm256_kernel<..., SKM = true>): the K-tiles of ALL tiles, tile after tile, are cut evenly over the blocks
+    int sk;                   // K-tiles per unit (the granule a cut falls on, >= 2): every piece of a tile is >= sk K-tiles long
+    int sk_tile_aligned;      // 1: the 8 XCD labels own whole tiles each (no piece of a tile crosses from one label to the next)
+    unsigned* sk_flag;        // [tiles] units of the tile whose pieces have been written, 64 bytes apart, zero between launches
+    float* sk_slab;           // [grid][2][8 waves][32 quads][64 lanes] f32x4: the accumulators of the block's (at most two) pieces
     // grouped launch (gemm256_kernel<..., GRP>): up to 16 problems sharing K, layouts and epilogue flags; one work list
     int ngroup;
     struct Group {
@@ -395,8 +400,21 @@ __device__ __forceinline__ void regroup_rows(unsigned& x0, unsigned& x1) {
 
 // (nontemporal epilogue stores, tried on the 8-byte pieces before the regrouping: 3x the fixed cost per tile — written through
 // as partial lines)
-template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false>
+//
+// SKM: STREAM-K.  A grid whose tiles do not fill the 256 CUs in whole rounds (the encoders' 80 / 320-tile projections, the
+// decoder GEMMs of a B = 1 micro-batch: 288 tiles = 1.125 rounds, 120 tiles = 0.47) is cut by WORK instead of by tile: all
+// tiles' K-tiles form one sequence (tile-major), every block takes an equal contiguous share of it, so a block's share is
+// [the tail of one tile][whole tiles][the head of another].  A piece that ends its tile OWNS the tile: it adds the other
+// pieces' accumulators to its own and runs the epilogue.  A piece that does not end its tile (a head or a middle) writes its
+// accumulators to the block's slab (fp32, register order, write-through) and raises the block's flag.  Order inside a block:
+// the head piece FIRST, whole tiles, the owned tail LAST — so every slab a block waits for was written by a block of lower
+// index as the first thing it did, long before it is needed; nothing waits on a higher block (dispatch order can only help).
+// Same numbers on every run: the cut and the order of the additions are functions of the grid alone.  Blocks with the same
+// XCD label (blockIdx & 7) take neighbouring shares, so a tile's pieces and its operand panels meet in one L2.
+// Replaces split-K slabs + the reduce launch and the 128x128 kernel for every grid with M, N >= 256.
+template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    static_assert(!SKM || (!P2 && !GRP), "stream-K exists on the four-phase, single-problem kernel");
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
     constexpr int NWI = P2 ? 4 : 8;                   // waves that stage one operand
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -420,12 +438,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int nwork = GRP ? p.grp[p.ngroup - 1].work0 + p.grp[p.ngroup - 1].tiles_m * p.grp[p.ngroup - 1].tiles_n
                           : p.tiles_m * p.tiles_n * p.splits;
     const int nk_all = (p.K + BK - 1) / BK;
-    auto decode = [&](int v) -> Tile {
+    // stream-K share of this block, in units of p.sk K-tiles (the last unit of a tile also takes the K-tiles a division leaves over)
+    const int sk_upt = SKM ? nk_all / p.sk : 1;                    // units per tile (>= 1)
+    // units [u0, u1) of block `b`: label x = b & 7 owns the units [L0, L1) — whole tiles when sk_tile_aligned — and its blocks
+    // j = b >> 3 cut that range evenly
+    auto sk_range = [&](int b, int& u0, int& u1) {
+        // (32-bit unsigned arithmetic: tiles x units x 8 stays far below 2^32 — the host refuses stream-K beyond 8192 tiles)
+        const unsigned x = b & 7, j = b >> 3, nl = gridDim.x >> 3;            // (the grid is a multiple of 8)
+        const unsigned ntile = p.tiles_m * p.tiles_n, upt = sk_upt;
+        unsigned L0, L1;
+        if (p.sk_tile_aligned) { L0 = (ntile * x / 8u) * upt; L1 = (ntile * (x + 1u) / 8u) * upt; }
+        else { L0 = ntile * upt * x / 8u; L1 = ntile * upt * (x + 1u) / 8u; }
+        u0 = (int)(L0 + (L1 - L0) * j / nl);
+        u1 = (int)(L0 + (L1 - L0) * (j + 1u) / nl);
+    };
+    int sk_u0 = 0, sk_u1 = 0;
+    if constexpr (SKM) sk_range(blockIdx.x, sk_u0, sk_u1);
+    // this block's work items: stream-K — its pieces, highest tile first; otherwise the virtual ids b, b + G, b + 2G, ...
+    const int nitems = SKM ? (sk_u1 > sk_u0 ? (sk_u1 - 1) / sk_upt - sk_u0 / sk_upt + 1 : 0)
+                           : (nwork - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (nitems <= 0) return;                                       // (block-uniform: more blocks than pieces of work)
+    auto decode = [&](int it) -> Tile {
         Tile t;
         t.gi = 0;
         int ctm = p.tiles_m, ctn = p.tiles_n;
-        const int q = nwork >> 3, r = nwork & 7, xcd = v & 7;
-        int work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        int work;
+        if constexpr (SKM) {
+            work = (sk_u1 - 1) / sk_upt - it;                      // tile index (in the XCD-chunked order the labels already give)
+        } else {
+            const int v = blockIdx.x + it * gridDim.x;
+            const int q = nwork >> 3, r = nwork & 7, xcd = v & 7;
+            work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        }
         if constexpr (GRP) {
             int gi = 0;
 #pragma unroll
@@ -439,7 +483,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int ntile = ctm * ctn;
         // K-slice is the SLOWEST index: the work items that run side by side on one XCD then belong to one slice and
         // keep sharing operand panels through its L2 (slices of one tile share nothing: they read different K ranges)
-        t.split = work / ntile;
+        t.split = SKM ? 0 : work / ntile;
         const int swz = work - t.split * ntile;
         const int GROUP_M = p.group_m;
         const int per_group = GROUP_M * ctn;
@@ -448,11 +492,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int gsz = min(ctm - first_m, GROUP_M);
         t.m0 = (first_m + (swz % per_group) % gsz) * 256;
         t.n0 = ((swz % per_group) / gsz) * 256;
-        t.kt0 = (int)((long)nk_all * t.split / p.splits);
-        t.nk = (int)((long)nk_all * (t.split + 1) / p.splits) - t.kt0;      // K-tiles of this slice
+        if constexpr (SKM) {
+            // the piece of tile `work` inside [sk_u0, sk_u1); split = 0: the whole tile, 1: a piece (slab + ticket); gi = the tile
+            const int ua = max(sk_u0, work * sk_upt) - work * sk_upt, ub = min(sk_u1, (work + 1) * sk_upt) - work * sk_upt;
+            t.kt0 = ua * p.sk;
+            t.nk = (ub == sk_upt ? nk_all : ub * p.sk) - t.kt0;
+            t.split = t.nk == nk_all ? 0 : 1;
+            t.gi = work;
+        } else {
+            t.kt0 = (int)((long)nk_all * t.split / p.splits);
+            t.nk = (int)((long)nk_all * (t.split + 1) / p.splits) - t.kt0;      // K-tiles of this slice
+        }
         return t;
     };
-    int vcur = blockIdx.x;
+    int vcur = 0;                                                  // index of the current item in this block's list
     Tile cur = decode(vcur);
 
     f32x4 acc[8][4];
@@ -596,8 +649,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     int abuf = 0, bbuf = 0;                   // LDS slots of the current K-tile (A: 0..2, B: 0..1)
 
     for (;;) {
-    const int vnext = vcur + gridDim.x;
-    const bool more = vnext < nwork;
+    const int vnext = vcur + 1;
+    const bool more = vnext < nitems;
     const int nk = cur.nk;
     const int t_stage_end = (roll && more) ? nk : nk - 2;       // loop iterations T < t_stage_end stage a K-tile (T + 2)
     const bool cto = tto(cur);
@@ -744,6 +797,156 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         if (nxt.nk > 1) { stage_stream(0, 1, 1); stage_stream(1, 1, 1); stage_stream(2, 1, 1); stage_stream(3, 1, 1); }
     }
     landed0 = roll && more;
+    // ---- the generic store of one accumulator quad (bias -> GELU -> residual -> accumulate, fp32 or bf16 output), as a function of
+    // the quad's four values: used by the general epilogue on the accumulators and by stream-K's reducer on summed slab values.
+    // Normal orientation: the lane owns C[m = .. + fr][n = .. + fq*4 + 0..3]
+    auto store_quad = [&](int i, int j, float (&v)[4]) {
+        const int m = em0 + wr * 128 + i * 16 + fr, n = en0 + wc * 64 + j * 16 + fq * 4;
+        if (m >= eM || n >= eN) return;
+        if (p.flags & MOLLY_GEMM_BIAS) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+            v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+        }
+        if (p.flags & MOLLY_GEMM_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (p.flags & MOLLY_GEMM_RESIDUAL) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldres + n);
+            v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+        }
+        if (p.flags & MOLLY_GEMM_OUT_F32) {
+            float* c = reinterpret_cast<float*>(eC) + (size_t)m * eldc + n;
+            if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(c);
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(eC) + (size_t)m * eldc + n;
+            if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                const u32x2 o = *reinterpret_cast<const u32x2*>(c);
+                v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+            }
+            *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        }
+    };
+    // Transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr]; C^T is stored as
+    // [N][M] (ld = ldc), i.e. 4 consecutive m of one n -> 8-byte bf16 / 16-byte fp32 stores (no bias / GELU / residual: host check)
+    auto store_quad_t = [&](int i, int j, float (&v)[4]) {
+        const int m = em0 + wr * 128 + i * 16 + fq * 4, n = en0 + wc * 64 + j * 16 + fr;
+        if (m >= eM || n >= eN) return;                                  // M % 4 == 0 checked by the host
+        if (p.flags & MOLLY_GEMM_OUT_F32) {
+            float* c = reinterpret_cast<float*>(eC) + (size_t)n * eldc + m;
+            if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(c);
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(eC) + (size_t)n * eldc + m;
+            if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                const u32x2 o = *reinterpret_cast<const u32x2*>(c);
+                v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+            }
+            *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        }
+    };
+    // ---- stream-K: a PIECE of a tile (esplit == 1).  Its accumulators go to the block's slab as they stand (register order, 16
+    // bytes per lane, write-through: no release fence needed — guide 6 G16 R1, 'publish-large'); every wave drains its stores, a
+    // barrier, then ONE lane adds the piece's length to the tile's counter.  The block whose addition completes the tile (the
+    // LAST ARRIVER, whichever piece that is: nobody ever waits, so no dispatch order or residency can stall the launch) takes one
+    // agent-scope acquire and reduces: the slabs of all the tile's pieces in ascending-K order — so the sums do not depend on who
+    // reduces — through the generic store above, and leaves the counter zero for the next launch.  (Keeping the reducer's own
+    // piece in its accumulators and adding the others to them — by VALU or, exactly, through the matrix pipe as three bf16 terms
+    // — was built first: any update of the accumulator tuple after the K loop made hipcc keep a second copy of its 128 registers
+    // and spill 55-270 VGPRs, reloaded INSIDE the K loop.)
+    bool sk_done = false;
+    if constexpr (SKM) {
+        if (esplit != 0) {
+            const int tile = cur.gi, ua = cur.kt0 / p.sk;
+            const int my_units = (cur.kt0 + cur.nk == nk_all ? sk_upt : (cur.kt0 + cur.nk) / p.sk) - ua;
+            // a block can hold TWO pieces (the head of its share's last tile and the tail of its first): slab 0 of the block takes
+            // the piece that contains the share's last unit (its first item), slab 1 the other
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                p.sk_slab + ((size_t)blockIdx.x * 2 + (vcur == 0 ? 0 : 1)) * 65536, 0, 262144, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                                           ((wave * 32 + i * 4 + j) * 64 + lane) * 16, 0, 16 /* sc1 */);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave (this also lands the prefetched K-tiles)
+            SEG_BARRIER();
+            // the A slot the K loop read last is dead until the next item's P1: its first word carries the ticket to all waves
+            volatile unsigned* mail = reinterpret_cast<volatile unsigned*>(smem + ((abuf == 0 ? 2 : abuf - 1) * 2) * HT);
+            if (tid == 0)
+                *mail = __hip_atomic_fetch_add(p.sk_flag + (size_t)tile * 16, (unsigned)my_units, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SEG_BARRIER();
+            const int before = __builtin_amdgcn_readfirstlane((int)*mail);
+            if (before + my_units == sk_upt) {
+                // the tile's pieces in ascending K: walk down to the block that holds the tile's first unit, then up to its last
+                constexpr int SK_MAXC = 10;
+                const int nl = (int)gridDim.x >> 3;
+                const int tile_u0 = tile * sk_upt, tile_u1 = tile_u0 + sk_upt;
+                int first = blockIdx.x, u0 = 0, u1 = 0;
+                sk_range(first, u0, u1);
+                while (u0 > tile_u0) {
+                    first = (first >> 3) > 0 ? first - 8 : (nl - 1) * 8 + (first & 7) - 1;
+                    sk_range(first, u0, u1);
+                }
+                int cb[SK_MAXC];
+                int nc = 0;
+                for (int b2 = first;; b2 = (b2 >> 3) < nl - 1 ? b2 + 8 : (b2 & 7) + 1) {
+                    sk_range(b2, u0, u1);
+                    // (a block without work wrote nothing)  slab index = 2 * block + (0: the piece holds the block's last unit)
+                    if (u1 > u0 && nc < SK_MAXC) cb[nc++] = b2 * 2 + ((u1 - 1) / sk_upt == tile ? 0 : 1);
+                    if (u1 >= tile_u1) break;
+                }
+                if (wave == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                SEG_BARRIER();
+                asm volatile("" ::: "memory");
+                const float* sl0 = p.sk_slab + (size_t)(wave * 32 * 64 + lane) * 4;
+                // eight quads at a time (the kernel's 256 registers are 128 accumulator + 128 vector registers, and ~45 of the
+                // latter hold the K loop's lane constants: 64 is what fits without spilling into the K loop); the first TWO pieces'
+                // loads are issued together — a tile cut once, the common case, costs four round trips of 16 KB per wave
+#pragma unroll 1
+                for (int h = 0; h < 4; ++h) {
+                    f32x4 sum[8], v[8];
+                    const float* sa = sl0 + (size_t)cb[0] * 65536 + h * 8 * 256;
+                    const float* sb = sl0 + (size_t)cb[nc > 1 ? 1 : 0] * 65536 + h * 8 * 256;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sum[q] = *reinterpret_cast<const f32x4*>(sa + q * 256);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(sb + q * 256);
+                    if (nc > 1) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sum[q] += v[q];
+                    }
+                    for (int ci = 2; ci < nc; ++ci) {
+                        const float* sl = sl0 + (size_t)cb[ci] * 65536 + h * 8 * 256;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(sl + q * 256);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sum[q] += v[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float vv[4] = {sum[q][0], sum[q][1], sum[q][2], sum[q][3]};
+                        if (TO) store_quad_t(h * 2 + (q >> 2), q & 3, vv);
+                        else store_quad(h * 2 + (q >> 2), q & 3, vv);
+                    }
+                }
+                if (tid == 0) __hip_atomic_store(p.sk_flag + (size_t)tile * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sk_done = true;
+        }
+    }
     // Fast paths first: a full interior tile with no epilogue flag (every qkv / dgrad launch) or with the residual add alone
     // (o_proj, down_proj).  The accumulator layout gives a lane 4 consecutive columns of one row (8 bytes as bf16), and a
     // wave-wide store of those touches 16 rows x 32 bytes: 4,096 32-byte requests per CU and tile, every CU at the same moment
@@ -764,7 +967,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 : (em0 + 256 <= eM && en0 + 256 <= eN &&
                    !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) ? 32
                 : 0;
-    if (to16) {
+    if (sk_done) {
+        pend_stores = 0;                          // the dump drained everything; a reducer's stores behind it: conservative waits
+    } else if (to16) {
         // C^T[n][m]: the quads of row-blocks (i even, i odd) regrouped so that lane-row fq holds m = s*32 + fq*8 .. +7 of its n
         bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(en0 + wc * 64 + fr) * eldc + em0 + wr * 128 + fq * 8;
 #pragma unroll
@@ -830,36 +1035,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             }
         }
     } else if (GRP ? eto : TO) {
-        // transposed output: operands were passed un-swapped, so the lane owns C[m = .. + fq*4 + 0..3][n = .. + fr];
-        // C^T is stored as [N][M] (ld = ldc), i.e. 4 consecutive m of one n -> 8-byte bf16 / 16-byte fp32 stores.
-        const bool accum = p.flags & MOLLY_GEMM_ACCUMULATE, out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
-        const int fr_ = lane & 15, fq_ = lane >> 4;
+        // transposed output, general form (ragged edge, accumulate, fp32, or a split-K slab)
         float* slab = p.splits > 1 ? p.ws + (size_t)esplit * eM * eN : nullptr;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int m = em0 + wr * 128 + i * 16 + fq_ * 4;
-            if (m >= eM) continue;                                   // M % 4 == 0 checked by the host
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = en0 + wc * 64 + j * 16 + fr_;
-                if (n >= eN) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (slab) {
-                    *reinterpret_cast<f32x4*>(slab + (size_t)n * eM + m) = f32x4{v[0], v[1], v[2], v[3]};
-                } else if (out_f32) {
-                    float* c = reinterpret_cast<float*>(eC) + (size_t)n * eldc + m;
-                    if (accum) {
-                        const f32x4 o = *reinterpret_cast<const f32x4*>(c);
-                        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-                    }
-                    *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+                    const int m = em0 + wr * 128 + i * 16 + fq * 4, n = en0 + wc * 64 + j * 16 + fr;
+                    if (m < eM && n < eN) *reinterpret_cast<f32x4*>(slab + (size_t)n * eM + m) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
-                    bf16_t* c = reinterpret_cast<bf16_t*>(eC) + (size_t)n * eldc + m;
-                    if (accum) {
-                        const u32x2 o = *reinterpret_cast<const u32x2*>(c);
-                        v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
-                    }
-                    *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    store_quad_t(i, j, v);
                 }
             }
         }
@@ -1016,49 +1203,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             }
         }
     } else {
-
-    // ---- epilogue: lane owns C[m = .. + fr][n = .. + fq*4 + 0..3]
-    const bool has_bias = p.flags & MOLLY_GEMM_BIAS, has_res = p.flags & MOLLY_GEMM_RESIDUAL;
-    const bool gelu = p.flags & MOLLY_GEMM_GELU, accum = p.flags & MOLLY_GEMM_ACCUMULATE;
-    const bool out_f32 = p.flags & MOLLY_GEMM_OUT_F32;
+        // ---- general epilogue: every flag, ragged edges
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = em0 + wr * 128 + i * 16 + fr;
-        if (m >= eM) continue;
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = en0 + wc * 64 + j * 16 + fq * 4;
-            if (n >= eN) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (has_bias) {
-                const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
-                v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+            for (int j = 0; j < 4; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                store_quad(i, j, v);
             }
-            if (gelu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
-            if (has_res) {
-                const u32x2 b = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldres + n);
-                v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
-            }
-            if (out_f32) {
-                float* c = reinterpret_cast<float*>(eC) + (size_t)m * eldc + n;
-                if (accum) {
-                    const f32x4 o = *reinterpret_cast<const f32x4*>(c);
-                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-                }
-                *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                bf16_t* c = reinterpret_cast<bf16_t*>(eC) + (size_t)m * eldc + n;
-                if (accum) {
-                    const u32x2 o = *reinterpret_cast<const u32x2*>(c);
-                    v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
-                }
-                *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            }
-        }
-    }
     }   // epilogue variants
 
     if (!more) break;
@@ -1114,54 +1266,92 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-int g_group_m = 4;
-int g_schedule = -1;              // 256x256 kernel: -1 = per form, 0 = four phases per K-tile, 1 = two phases per K-tile
+// ---- launch state.  Everything a launch decision reads lives in a CONTEXT: the tuning knobs, the scratch memory and the record
+// of the last configuration.  molly_gemm_ctx_* create and edit contexts; the *_ctx entry points launch through one.  The entry
+// points without a context use the calling thread's default context (thread_local: what one host thread sets, another never
+// inherits), which is what the molly_gemm_set_* setters edit.
+struct GemmCtx {
+    int group_m = 4;
+    int schedule = -1;             // 256x256 kernel: -1 / 0 = four phases per K-tile, 1 = two phases per K-tile (A/B knob)
+    int persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile; -t = t tiles per block
+    int small_grid_tile = 128;     // with stream-K off: kernel for grids that fill the chip neither plain nor split (128 | 512)
+    int min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
+    int force_tile = 0;            // 0 heuristic | 128 | 512
+    int streamk = 1;               // 1 = stream-K where its cost model says it wins (M, N >= 256); 2 = wherever it is able (tests); 0 = off
+    int last_cfg = 0;              // 128 / 512 + 1000 * split-K factor (+ 50000: stream-K, + 100000 * problems: grouped)
+    float* ws = nullptr;           // scratch: [stream-K header: error word + flags][fp32 slabs of split-K / stream-K]
+    size_t ws_bytes = 0;
+};
+thread_local GemmCtx t_ctx;
+inline GemmCtx& ctx_of(void* h) { return h ? *static_cast<GemmCtx*>(h) : t_ctx; }
+
+constexpr int SK_MAX_BLOCKS = 2048;
+constexpr int SK_MAX_TILES = 8192;                                     // one counter line per TILE of a stream-K launch
+constexpr size_t SK_HDR_BYTES = 64 + (size_t)SK_MAX_TILES * 64;        // error word line + one 64-byte line per counter
+constexpr size_t SK_SLAB_BYTES = 2 * 262144;                           // per block: two pieces of 8 waves x 32 quads x 64 lanes x 16 B
+inline float* ws_slabs(const GemmCtx& c) { return c.ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(c.ws) + SK_HDR_BYTES) : nullptr; }
+inline size_t ws_slab_bytes(const GemmCtx& c) { return c.ws_bytes > SK_HDR_BYTES ? c.ws_bytes - SK_HDR_BYTES : 0; }
+
 // Per-form default.  Round 1 ran the k-major-B forms (dgrad, wgrad) on the two-phase schedule, measured +3-4 % — while hipcc
 // was draining the LDS-DMA pipeline in front of their transposed reads (dma16 above).  With the DMA issued from asm the
 // four-phase schedule wins on every form (same-box: gate|up dgrad 1387 vs 1320 TF/s, qkv dgrad 1296 vs 1279), so -1 now
 // means four phases everywhere; 1 still selects two.
-inline bool two_phase(bool /*b_kmajor*/) { return g_schedule == 1; }
-int g_persist_blocks = 256;      // 256x256 kernel: resident blocks (1 per CU); 0 = one block per tile; -t = t tiles per block
+inline bool two_phase(const GemmCtx& c) { return c.schedule == 1; }
 // grid of the 256x256 kernel for `nwork` work items.  n > 0: min(nwork, n) resident blocks that walk the work list (every CU
 // must be free for the whole launch, or the blocks that found none run as a second round).  0: one block per item.  -t: blocks of
 // at most t tiles each, a multiple of 256 of them (whole rounds when the chip is free; a block keeps its XCD) — the dispatcher
 // places them on whatever CUs are free (a collective running beside the GEMM owns some), and t - 1 of every t tile boundaries
 // still run under the rolling prefetch.
-inline int grid256(int nwork) {
-    if (g_persist_blocks > 0) return min(nwork, g_persist_blocks);
-    if (g_persist_blocks == 0) return nwork;
-    const int t = -g_persist_blocks;
+inline int grid256(const GemmCtx& c, int nwork) {
+    if (c.persist_blocks > 0) return min(nwork, c.persist_blocks);
+    if (c.persist_blocks == 0) return nwork;
+    const int t = -c.persist_blocks;
     return min(nwork, 256 * cdiv(nwork, 256 * t));                  // whole rounds of 256 blocks, at most t tiles per block
 }
-int g_small_grid_tile = 128;     // kernel for grids that fill the chip neither plain nor split: 128 (128x128 ring) | 512 (256x256)
-int g_min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
-int g_last_cfg = 0;          // tile configuration of the most recent launch: 128 / 256 / 512 (+ 1000 * split-K factor)
-float* g_ws = nullptr;
-size_t g_ws_bytes = 0;
+// blocks of a STREAM-K launch over `ntile` tiles of `upt` units: the same three modes — n > 0: n resident blocks; 0: as many
+// blocks as whole rounds of one tile's worth each need; -t: shares of at most t tiles — always a multiple of 8 (the XCD labels),
+// never more than one block per two units, and within what the scratch memory holds slabs for.
+inline int grid_sk(const GemmCtx& c, int ntile, int upt) {
+    int g = c.persist_blocks > 0 ? c.persist_blocks : 256 * cdiv(ntile, 256 * (c.persist_blocks == 0 ? 1 : -c.persist_blocks));
+    g = min(g, SK_MAX_BLOCKS);
+    g = min(g, (int)min((long)ntile * upt / 2, (long)(ws_slab_bytes(c) / SK_SLAB_BYTES)));
+    g = min(g, 6 * ntile);                       // a tile in at most 6 + 2 pieces: the reducer's list holds 10, and it reads them one by one
+    return g / 8 * 8;
+}
 
 __device__ bf16_t g_zero_page[64];      // zero-initialised device memory (k-rows beyond K)
 
 template <bool AT, bool BT, bool TO = false>
-int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
+int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
     // force_tile: 0 heuristic | 128 = gemm_kernel<128, 2 stages, BK 64> | 512 = gemm256_kernel
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 128, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * (128 + BN) * 64 * 2);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr_set = true;
     }
-    // heuristic: the 256x256 ping-pong kernel when its grid fills the 256 CUs without a long tail; if it does not and K
-    // is long (wgrad: K = tokens), split K so that tiles x splits does (fp32 slabs + a reduce launch); else 128x128.
+    // heuristic.  Whole rounds of the 256 CUs: the persistent 256x256 kernel, one tile after another.  Anything else with both
+    // sides at least one tile wide: the same kernel as STREAM-K (one launch, every CU an equal share of the K-tiles).  One
+    // side narrower than a tile (rank-r adapters, decode rows): a pure operand stream — K split over the chip into fp32 slabs +
+    // the reduce launch, or the 128x128 kernel.
     p.splits = 1;
     p.ws = nullptr;
-    p.group_m = g_group_m;
+    p.sk = 0;
+    p.group_m = c.group_m;
+    const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256);
+    const int nk = cdiv(p.K, 64);
+    auto eff = [](long items) { return (double)items / (double)(((items + 255) / 256) * 256); };
+    bool use_sk = false;
+    const bool sk_able = c.streamk && !two_phase(c) && p.M >= 256 && p.N >= 256 && nk >= 4 && t256 <= SK_MAX_TILES &&
+                         ws_slab_bytes(c) >= 8 * SK_SLAB_BYTES && !(p.flags & (MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD));
     if (force_tile == 0) {
-        const long t256 = (long)cdiv(p.M, 256) * cdiv(p.N, 256);
-        auto eff = [](long items) { return (double)items / (double)(((items + 255) / 256) * 256); };
         if (t256 >= 200 && eff(t256) >= 0.8) {
             force_tile = 512;
         } else {
-            const int nk = cdiv(p.K, 64);
             const bool plain_epilogue = !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_GELU | MOLLY_GEMM_RESIDUAL));
             // "skinny": one side of the output is narrower than a tile (rank-r adapter GEMMs: N = r or M = r) and the
             // 128x128 grid would leave CUs empty.  Such a problem is bound by streaming the big operand once, so what
@@ -1169,12 +1359,12 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             const long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, BN);
             // (decode GEMMs, M = batch rows: a pure weight stream — slices down to 4 K-tiles)
             const bool skinny = (p.M < 256 || p.N < 256) && t128 < 256;
-            const int min_kt = skinny ? ((p.M < 64 || p.N < 64) ? 4 : 8) : g_min_ktiles;
+            const int min_kt = skinny ? ((p.M < 64 || p.N < 64) ? 4 : 8) : c.min_ktiles;
             int best = 0;
             double best_score = 0.0;
             for (int sp : {2, 3, 4, 6, 8, 12, 16, 24, 32}) {
                 if (nk / sp < min_kt) break;                               // keep slices >= 1024 (skinny: 512) deep
-                if ((size_t)sp * p.M * p.N * sizeof(float) > g_ws_bytes) break;
+                if ((size_t)sp * p.M * p.N * sizeof(float) > ws_slab_bytes(c)) break;
                 if (t256 * sp >= 200 && eff(t256 * sp) >= 0.85) { best = sp; break; }
                 if (skinny && eff(t256 * sp) > best_score + 1e-9) { best_score = eff(t256 * sp); best = -sp; }
             }
@@ -1183,27 +1373,65 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
             if (best && (plain_epilogue || !TO) && p.N % 4 == 0 && ((p.M >= 256 && p.N >= 256) || skinny)) {
                 force_tile = 512;
                 p.splits = best;
-                p.ws = g_ws;
+                p.ws = ws_slabs(c);
             } else {
-                force_tile = TO ? 512 : g_small_grid_tile;     // transposed output exists in the 256x256 kernel only
+                force_tile = TO ? 512 : c.small_grid_tile;     // transposed output exists in the 256x256 kernel only
+            }
+        }
+        {
+            const long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, BN);
+            // ---- stream-K instead?  Its hand-off has a price on this chip: a piece's accumulators are 256 KiB written through to
+            // memory (~21 GB/s per workgroup: guide price list 'publish-large') and read back by the reducer — measured 30-36 us
+            // per launch (tools/bench_streamk.py) against ~1.4 us per K-tile of work.  So it pays where the alternatives waste more
+            // than that: long contractions on grids just past a whole round (Qwen3-8B qkv at B = 1: 384 tiles, 162 us against 197
+            // for split-K and its 200 MB of slabs; Qwen3-4B qkv: 288 tiles, 99 against 105), not on the encoders' 20-K-tile
+            // projections.  Times in us from constants fitted to those measurements; stream-K must win by 7 %.
+            if (sk_able && eff(t256) < 0.9) {
+                const double kt = 1.4, launch = 12.0, tile_fix = 6.0;
+                double t_other;
+                if (force_tile == 512 && p.splits > 1)
+                    t_other = launch + cdiv(t256 * p.splits, 256) * (tile_fix + kt * nk / p.splits) + 8.0 * p.M * p.N * p.splits / 9e6 + 4.0;
+                else if (force_tile == 512)
+                    t_other = launch + cdiv(t256, 256) * (tile_fix + kt * nk);
+                else
+                    t_other = 5.0 + (t128 > 512 ? (t128 / 512.0 + 0.35) * 1.17 : 1.25) * nk;      // 128x128 kernel, two blocks per CU
+                // (14 us: a block's slab writes; 8 us per piece the reducer reads — two when the shares are a tile or more)
+                const int g_sk = grid_sk(c, (int)t256, nk / 2);
+                const double pieces = g_sk > t256 ? (double)g_sk / t256 + 1.0 : 2.0;
+                const double t_sk = launch + tile_fix + kt * nk * (double)t256 / (g_sk > 0 ? g_sk : 1) + 14.0 + 8.0 * pieces;
+                if (c.streamk == 2 || (g_sk >= 8 && (double)nk * t256 / g_sk >= 8.0 && t_sk < 0.93 * t_other)) {
+                    force_tile = 512;
+                    p.splits = 1;
+                    p.ws = nullptr;
+                    use_sk = true;
+                }
             }
         }
     }
-    g_last_cfg = force_tile + 1000 * p.splits;
     if (force_tile == 512) {
-        static bool a2 = false;
-        if (!a2) {
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            a2 = true;
-        }
         p.tiles_m = cdiv(p.M, 256); p.tiles_n = cdiv(p.N, 256);
-
-        // persistent: at most g_persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
+        if (use_sk) {
+            const int ntile = p.tiles_m * p.tiles_n;
+            p.sk = 2;                                              // a cut falls on even K-tiles: every piece >= 2 K-tiles
+            const int upt = nk / p.sk;
+            const int grid = grid_sk(c, ntile, upt);
+            if (grid >= 8) {
+                // the 8 XCD labels own whole tiles when that costs < 3 % of balance; else their borders fall inside tiles too
+                const double per = ntile / 8.0;
+                p.sk_tile_aligned = (cdiv(ntile, 8) / per - 1.0) <= 0.03 ? 1 : 0;
+                p.sk_flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c.ws) + 64);
+                p.sk_slab = ws_slabs(c);
+                c.last_cfg = 512 + 1000 + 50000;
+                hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false, false, true>), dim3(grid), dim3(512), 163840, st, p);
+                return 0;
+            }
+            p.sk = 0;                                              // (no room for slabs: the plain launch below)
+        }
+        c.last_cfg = force_tile + 1000 * p.splits;
+        // persistent: at most persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
-        const int grid = grid256(nwork);
-        // two-phase schedule where it measured faster: a k-major B operand (dgrad, wgrad); -1 = this choice, 0 / 1 = forced
-        if (two_phase(BT)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
+        const int grid = grid256(c, nwork);
+        if (two_phase(c)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
         else hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false>), dim3(grid), dim3(512), 163840, st, p);
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
@@ -1217,6 +1445,7 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
         molly_set_error("gemm: transposed output is only built into the 256x256 kernel");
         return 1;
     } else {
+        c.last_cfg = 128 + 1000;
         p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, BN);
         hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
                            2 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
@@ -1224,11 +1453,24 @@ int launch_cfg(hipStream_t st, GemmArgs& p, int force_tile) {
     return 0;
 }
 
-int g_force_tile = 0;
+int resolve_zero_page(const bf16_t** out) {
+    static const bf16_t* zeros = nullptr;
+    if (!zeros) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) {
+            molly_set_error("gemm: cannot resolve the zero page");
+            return 3;
+        }
+        zeros = (const bf16_t*)zp;
+    }
+    *out = zeros;
+    return 0;
+}
 
-int launch_gemm(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
-                int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
+int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N,
+                int K, int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
     MOLLY_ENTER();
+    GemmCtx& c = ctx_of(ctx);
     MOLLY_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     MOLLY_CHECK((at && bt) || K % 64 == 0, "gemm: K=%d must be a multiple of %d when an operand is k-contiguous", K, 64);
     MOLLY_CHECK(N % 4 == 0 || (flags & MOLLY_GEMM_TRANS_OUT), "gemm: N=%d must be a multiple of 4", N);
@@ -1244,21 +1486,13 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
     p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)res;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres; p.flags = flags;
     p.ngroup = 0;
-    static const bf16_t* zeros = nullptr;
-    if (!zeros) {
-        void* zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) {
-            molly_set_error("gemm: cannot resolve the zero page");
-            return 3;
-        }
-        zeros = (const bf16_t*)zp;
-    }
-    p.zeros = zeros;
+    p.sk = 0; p.sk_tile_aligned = 0; p.sk_flag = nullptr; p.sk_slab = nullptr;
+    if (int rc = resolve_zero_page(&p.zeros)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (flags & MOLLY_GEMM_SWIGLU) {
         MOLLY_CHECK(!at && !bt && flags == MOLLY_GEMM_SWIGLU && res && N % 256 == 0 && ldres % 4 == 0,
                     "gemm: MOLLY_GEMM_SWIGLU is the plain NT form with N = 2*ff, ff %% 128 == 0 (N=%d), res = the activation output", N);
-        if (launch_cfg<false, false>(st, p, 512)) return 1;    // the 256x256 kernel, one pass (no split-K slabs)
+        if (launch_cfg<false, false>(st, c, p, 512)) return 1;    // the 256x256 kernel, one pass (no split-K slabs)
         MOLLY_LAUNCH_CHECK();
         return 0;
     }
@@ -1266,7 +1500,7 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
         MOLLY_CHECK(!at && bt && flags == MOLLY_GEMM_SWIGLU_BWD && res && ldres % 4 == 0 && ldres >= 2 * N && ldc >= 2 * N,
                     "gemm: MOLLY_GEMM_SWIGLU_BWD is the dgrad form (k-contiguous A, k-major B) with N = ff (N=%d), res = [gate | up] "
                     "[M][2*ff], C = d[gate | up] [M][2*ff]", N);
-        if (launch_cfg<false, true>(st, p, 512)) return 1;     // the 256x256 kernel, one pass (no split-K slabs)
+        if (launch_cfg<false, true>(st, c, p, 512)) return 1;     // the 256x256 kernel, one pass (no split-K slabs)
         MOLLY_LAUNCH_CHECK();
         return 0;
     }
@@ -1274,13 +1508,13 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
         MOLLY_CHECK(!at && bt, "gemm: MOLLY_GEMM_TRANS_OUT is built for the (k-contiguous A, k-major B) form only");
         MOLLY_CHECK(!(flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_GELU | MOLLY_GEMM_RESIDUAL)) && M % 4 == 0,
                     "gemm: MOLLY_GEMM_TRANS_OUT takes no bias/GELU/residual and needs M %% 4 == 0");
-        if (launch_cfg<false, true, true>(st, p, g_force_tile == 0 ? 0 : 512)) return 1;
+        if (launch_cfg<false, true, true>(st, c, p, c.force_tile == 0 ? 0 : 512)) return 1;
     } else if (!at && !bt) {
-        if (launch_cfg<false, false>(st, p, g_force_tile)) return 1;
+        if (launch_cfg<false, false>(st, c, p, c.force_tile)) return 1;
     } else if (!at && bt) {
-        if (launch_cfg<false, true>(st, p, g_force_tile)) return 1;
+        if (launch_cfg<false, true>(st, c, p, c.force_tile)) return 1;
     } else if (at && bt) {
-        if (launch_cfg<true, true>(st, p, g_force_tile)) return 1;
+        if (launch_cfg<true, true>(st, c, p, c.force_tile)) return 1;
     } else {
         molly_set_error("gemm: the (k-major A, k-contiguous B) form is not on the hot path and not built");
         return 1;
@@ -1289,51 +1523,14 @@ int launch_gemm(void* stream, const void* A, const void* B, void* C, const void*
     return 0;
 }
 
-}  // namespace
-
-extern "C" int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias,
-                                  const void* res, int M, int N, int K, int lda, int ldb, int ldc, int ldres,
-                                  int flags) {
-    return launch_gemm(stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, false, false);
-}
-
-extern "C" int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
-                               int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor,
-                               int b_kmajor) {
-    return launch_gemm(stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, a_kmajor != 0, b_kmajor != 0);
-}
-
-// fp32 scratch for split-K partial slabs (caller-owned device memory; NULL/0 disables split-K)
-extern "C" int molly_gemm_set_workspace(void* ptr, long bytes) {
-    MOLLY_CHECK(bytes >= 0 && ((uintptr_t)ptr % 16) == 0, "gemm_set_workspace: pointer must be 16-byte aligned");
-    g_ws = (float*)ptr;
-    g_ws_bytes = ptr ? (size_t)bytes : 0;
-    return 0;
-}
-
-// which kernel configuration the most recent molly_gemm_* call on this thread's library instance used:
-// 128 = 128x128 tile, 256 = 256x128 ring, 512 = 256x256 ping-pong kernel; + 1000 * split-K factor
-extern "C" int molly_gemm_last_config(void) { return g_last_cfg; }
-
-extern "C" int molly_gemm_set_small_grid_tile(int tile) {
-    MOLLY_CHECK(tile == 128 || tile == 512, "gemm_set_small_grid_tile: 128 or 512 (got %d)", tile);
-    g_small_grid_tile = tile;
-    return 0;
-}
-
-extern "C" int molly_gemm_set_group_m(int g) {
-    MOLLY_CHECK(g >= 1 && g <= 64, "gemm_set_group_m: %d", g);
-    g_group_m = g;
-    return 0;
-}
-
-extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {
+int launch_grouped(void* ctx, void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {
     MOLLY_ENTER();
+    GemmCtx& c = ctx_of(ctx);
     MOLLY_CHECK(problems && count >= 1 && count <= 16, "gemm_grouped: 1..16 problems (count=%d)", count);
     MOLLY_CHECK(K > 0 && !(flags & ~(MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_OUT_F32)),
                 "gemm_grouped: K=%d, flags 0x%x (accumulate / fp32 output only)", K, flags);
     GemmArgs p{};
-    p.K = K; p.flags = flags; p.splits = 1; p.ws = nullptr; p.group_m = g_group_m; p.ngroup = count;
+    p.K = K; p.flags = flags; p.splits = 1; p.ws = nullptr; p.group_m = c.group_m; p.ngroup = count;
     int work = 0;
     for (int i = 0; i < count; ++i) {
         const molly_gemm_problem& q = problems[i];
@@ -1349,14 +1546,7 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
         G.tiles_m = cdiv(q.M, 256); G.tiles_n = cdiv(q.N, 256); G.trans_out = q.trans_out; G.work0 = work;
         work += G.tiles_m * G.tiles_n;
     }
-    {
-        void* zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) {
-            molly_set_error("gemm_grouped: cannot resolve the zero page");
-            return 3;
-        }
-        p.zeros = (const bf16_t*)zp;
-    }
+    if (int rc = resolve_zero_page(&p.zeros)) return rc;
     // the single-problem fields describe problem 0 (never read by the grouped kernel beyond its initial values)
     p.A = p.grp[0].A; p.B = p.grp[0].B; p.C = p.grp[0].C; p.M = p.grp[0].M; p.N = p.grp[0].N;
     p.lda = p.grp[0].lda; p.ldb = p.grp[0].ldb; p.ldc = p.grp[0].ldc; p.tiles_m = p.grp[0].tiles_m; p.tiles_n = p.grp[0].tiles_n;
@@ -1368,9 +1558,9 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr = true;
     }
-    const int grid = grid256(work);
-    g_last_cfg = 512 + 1000 + 100000 * count;
-    if (two_phase(true))
+    const int grid = grid256(c, work);
+    c.last_cfg = 512 + 1000 + 100000 * count;
+    if (two_phase(c))
         hipLaunchKernelGGL((gemm256_kernel<false, true, false, true, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((gemm256_kernel<false, true, false, false, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
@@ -1378,28 +1568,133 @@ extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* p
     return 0;
 }
 
-extern "C" int molly_gemm_set_schedule(int mode) {
-    MOLLY_CHECK(mode >= -1 && mode <= 1, "gemm_set_schedule: %d not in {-1,0,1}", mode);
-    g_schedule = mode;
+int ctx_set(GemmCtx& c, int key, long v) {
+    switch (key) {
+    case MOLLY_GEMM_KEY_PERSISTENT_BLOCKS:
+        MOLLY_CHECK((v >= 0 && v % 8 == 0 && v <= SK_MAX_BLOCKS) || (v < 0 && v >= -64),
+                    "gemm persistent_blocks: %ld must be a non-negative multiple of 8 (<= %d), or -t (t tiles per block, t <= 64)", v,
+                    SK_MAX_BLOCKS);
+        c.persist_blocks = (int)v;
+        return 0;
+    case MOLLY_GEMM_KEY_SCHEDULE:
+        MOLLY_CHECK(v >= -1 && v <= 1, "gemm schedule: %ld not in {-1,0,1}", v);
+        c.schedule = (int)v;
+        return 0;
+    case MOLLY_GEMM_KEY_FORCE_TILE:
+        MOLLY_CHECK(v == 0 || v == 128 || v == 512, "gemm force_tile: %ld not in {0,128,512}", v);
+        c.force_tile = (int)v;
+        return 0;
+    case MOLLY_GEMM_KEY_GROUP_M:
+        MOLLY_CHECK(v >= 1 && v <= 64, "gemm group_m: %ld", v);
+        c.group_m = (int)v;
+        return 0;
+    case MOLLY_GEMM_KEY_SMALL_GRID_TILE:
+        MOLLY_CHECK(v == 128 || v == 512, "gemm small_grid_tile: 128 or 512 (got %ld)", v);
+        c.small_grid_tile = (int)v;
+        return 0;
+    case MOLLY_GEMM_KEY_MIN_KTILES:
+        MOLLY_CHECK(v >= 2 && v <= 64, "gemm min_ktiles: %ld not in 2..64", v);
+        c.min_ktiles = (int)v;
+        return 0;
+    case MOLLY_GEMM_KEY_STREAMK:
+        MOLLY_CHECK(v >= 0 && v <= 2, "gemm streamk: %ld not in {0,1,2}", v);
+        c.streamk = (int)v;
+        return 0;
+    default:
+        molly_set_error("gemm_ctx_set: unknown key %d", key);
+        return 1;
+    }
+}
+
+int ctx_set_workspace(GemmCtx& c, void* ptr, long bytes) {
+    MOLLY_CHECK(bytes >= 0 && ((uintptr_t)ptr % 256) == 0, "gemm_set_workspace: pointer must be 256-byte aligned");
+    c.ws = (float*)ptr;
+    c.ws_bytes = ptr ? (size_t)bytes : 0;
+    if (ptr && (size_t)bytes > SK_HDR_BYTES) {
+        // stream-K's flags must read zero before the first launch (afterwards every launch leaves them zero).  Not on the hot
+        // path: a synchronous clear on the null stream, once per workspace.
+        if (hipMemset(ptr, 0, SK_HDR_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            molly_set_error("gemm_set_workspace: cannot clear the stream-K header");
+            return 2;
+        }
+    }
     return 0;
 }
 
-extern "C" int molly_gemm_set_min_ktiles(int n) {
-    MOLLY_CHECK(n >= 2 && n <= 64, "gemm_set_min_ktiles: %d not in 2..64", n);
-    g_min_ktiles = n;
-    return 0;
+}  // namespace
+
+extern "C" int molly_gemm_nt_bf16(void* stream, const void* A, const void* B, void* C, const void* bias,
+                                  const void* res, int M, int N, int K, int lda, int ldb, int ldc, int ldres,
+                                  int flags) {
+    return launch_gemm(nullptr, stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, false, false);
 }
 
-extern "C" int molly_gemm_set_persistent_blocks(int n) {
-    MOLLY_CHECK((n >= 0 && n % 8 == 0) || (n < 0 && n >= -64),
-                "gemm_set_persistent_blocks: %d must be a non-negative multiple of 8, or -t (t tiles per block, t <= 64)", n);
-    g_persist_blocks = n;
-    return 0;
+extern "C" int molly_gemm_bf16(void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
+                               int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int a_kmajor,
+                               int b_kmajor) {
+    return launch_gemm(nullptr, stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, a_kmajor != 0, b_kmajor != 0);
 }
 
-// tuning/test hook: 0 = heuristic, 128 or 256 = force that BM tile configuration
-extern "C" int molly_gemm_force_tile(int bm) {
-    MOLLY_CHECK(bm == 0 || bm == 128 || bm == 512, "gemm_force_tile: %d not in {0,128,512}", bm);
-    g_force_tile = bm;
+extern "C" int molly_gemm_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias,
+                                   const void* res, int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags,
+                                   int a_kmajor, int b_kmajor) {
+    return launch_gemm(ctx, stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, a_kmajor != 0, b_kmajor != 0);
+}
+
+extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {
+    return launch_grouped(nullptr, stream, problems, count, K, flags);
+}
+
+extern "C" int molly_gemm_grouped_bf16_ctx(void* ctx, void* stream, const molly_gemm_problem* problems, int count, int K,
+                                           int flags) {
+    return launch_grouped(ctx, stream, problems, count, K, flags);
+}
+
+// ---- contexts
+extern "C" int molly_gemm_ctx_create(void** out) {
+    MOLLY_CHECK(out, "gemm_ctx_create: NULL out pointer");
+    *out = new GemmCtx();
     return 0;
 }
+extern "C" int molly_gemm_ctx_destroy(void* ctx) {
+    delete static_cast<GemmCtx*>(ctx);
+    return 0;
+}
+extern "C" int molly_gemm_ctx_set(void* ctx, int key, long value) { return ctx_set(ctx_of(ctx), key, value); }
+extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
+    const GemmCtx& c = ctx_of(ctx);
+    switch (key) {
+    case MOLLY_GEMM_KEY_PERSISTENT_BLOCKS: return c.persist_blocks;
+    case MOLLY_GEMM_KEY_SCHEDULE: return c.schedule;
+    case MOLLY_GEMM_KEY_FORCE_TILE: return c.force_tile;
+    case MOLLY_GEMM_KEY_GROUP_M: return c.group_m;
+    case MOLLY_GEMM_KEY_SMALL_GRID_TILE: return c.small_grid_tile;
+    case MOLLY_GEMM_KEY_MIN_KTILES: return c.min_ktiles;
+    case MOLLY_GEMM_KEY_STREAMK: return c.streamk;
+    case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
+    default: return -1;
+    }
+}
+extern "C" int molly_gemm_ctx_set_workspace(void* ctx, void* ptr, long bytes) { return ctx_set_workspace(ctx_of(ctx), ptr, bytes); }
+// the error word of the stream-K hand-off (a wait that gave up): a device read, for tests and diagnostics only
+extern "C" int molly_gemm_ctx_streamk_timeouts(void* ctx) {
+    const GemmCtx& c = ctx_of(ctx);
+    if (!c.ws || c.ws_bytes <= SK_HDR_BYTES) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, c.ws, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (int)v;
+}
+
+// ---- the calling thread's default context (what the entry points without a context launch through)
+// fp32 scratch for split-K partial slabs and the stream-K slabs + flags (caller-owned device memory; NULL/0 disables both)
+extern "C" int molly_gemm_set_workspace(void* ptr, long bytes) { return ctx_set_workspace(t_ctx, ptr, bytes); }
+// which kernel configuration the most recent molly_gemm_* call of this thread's default context used
+extern "C" int molly_gemm_last_config(void) { return t_ctx.last_cfg; }
+extern "C" int molly_gemm_set_small_grid_tile(int tile) { return ctx_set(t_ctx, MOLLY_GEMM_KEY_SMALL_GRID_TILE, tile); }
+extern "C" int molly_gemm_set_group_m(int g) { return ctx_set(t_ctx, MOLLY_GEMM_KEY_GROUP_M, g); }
+extern "C" int molly_gemm_set_schedule(int mode) { return ctx_set(t_ctx, MOLLY_GEMM_KEY_SCHEDULE, mode); }
+extern "C" int molly_gemm_set_min_ktiles(int n) { return ctx_set(t_ctx, MOLLY_GEMM_KEY_MIN_KTILES, n); }
+extern "C" int molly_gemm_set_persistent_blocks(int n) { return ctx_set(t_ctx, MOLLY_GEMM_KEY_PERSISTENT_BLOCKS, n); }
+extern "C" int molly_gemm_force_tile(int bm) { return ctx_set(t_ctx, MOLLY_GEMM_KEY_FORCE_TILE, bm); }
+extern "C" int molly_gemm_set_streamk(int on) { return ctx_set(t_ctx, MOLLY_GEMM_KEY_STREAMK, on); }

@@ -29,6 +29,10 @@ class GenerationSession:
     @torch.no_grad()
     def prefill(self, input_ids, attention_mask, omic_ids, omic_info_list) -> torch.Tensor:
         """Returns the logits of the last prompt position [B, V] (fp32)."""
+        with ops.use_gemm_context(self.rt.gemm_ctx):
+            return self._prefill(input_ids, attention_mask, omic_ids, omic_info_list)
+
+    def _prefill(self, input_ids, attention_mask, omic_ids, omic_info_list) -> torch.Tensor:
         m, rt, e = self.m, self.rt, self.eng
         B, T = input_ids.shape
         dev = rt.dev
@@ -160,6 +164,10 @@ class GenerationSession:
         buffer that the next step overwrites).  The first step runs eagerly (it also sizes workspaces and sets kernel
         attributes), the second is captured into a hipGraph, later steps replay it: ~340 launches become one."""
         assert self.cur_len < self.Tmax, "generation budget exhausted"
+        with ops.use_gemm_context(self.rt.gemm_ctx):
+            return self._step(token_ids)
+
+    def _step(self, token_ids: torch.Tensor) -> torch.Tensor:
         self.tok.copy_(token_ids.to(self.rt.dev), non_blocking=True)
         self.cur_len += 1
         self._steps_done += 1

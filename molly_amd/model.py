@@ -229,6 +229,17 @@ class EsmForMaskedLM(_Shell):
 
 # ---- batch assembly: molly_amd/batch.py (one host pass, one pinned H2D copy, the rest in molly_batch_assemble) ----------
 # ---- the model ---------------------------------------------------------------------------------------------------
+def _in_gemm_ctx(fn):
+    """Run a method with the model's own GEMM context current (launch knobs + scratch: ops.GemmContext)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with ops.use_gemm_context(self._runtime().gemm_ctx):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class OmicsOne(_MetaSafe):
     def __init__(self, config: OmicsModalConfig):
         super().__init__()
@@ -366,6 +377,10 @@ class OmicsOne(_MetaSafe):
                     self.model.lm_head.weight = emb.weight
         rt = type("Runtime", (), {})()
         rt.dev, rt.base, rt.enc = dev, base, enc
+        # the launch state of every GEMM this model issues (knobs + scratch): its own, so that nothing set for it (an optimizer's
+        # launch shape beside collectives) leaks into another model of the process, and nothing set elsewhere leaks in
+        rt.gemm_ctx = ops.GemmContext()
+        rt.gemm_ctx.ensure_workspace(0, dev)
         rt.full, rt.train_llm, rt.train_mlp = full, bool(train_llm), bool(train_mlp or lora is not None)
         rt.train_bio = bool(train_bio)
         if full:
@@ -435,6 +450,7 @@ class OmicsOne(_MetaSafe):
                                     {"dna_rna": self.dna_rna_project_token_num, "protein": self.protein_project_token_num},
                                     want_sort=want_sort)
 
+    @_in_gemm_ctx
     def _embed_and_inject(self, st, keep_for_backward, wait_embed=None, wait_proj=None):
         """reference: src/model/omics_one.py:164-172 — token embeddings, then encoder -> projector -> overwrite.  `st` is the
         staged batch (device-side ids, encoder ids, scatter indices).
@@ -486,12 +502,16 @@ class OmicsOne(_MetaSafe):
         """Wire a Zero2Optimizer's overlap hooks into the engines (no-ops when the optimizer does not overlap)."""
         rt = self._runtime()
         rt.opt = opt
+        mode = getattr(opt, "gemm_blocks_mode", None)
+        if mode is not None:
+            rt.gemm_ctx.set("persistent_blocks", mode)        # this model's GEMMs run beside the optimizer's collectives
         if rt.full:
             # per-layer overlap: flat offsets of the optimizer's group ARE the LLM's parameter offsets
             opt.hooked = True
             rt.llm.grads_final_hook = opt.on_grads_final
             rt.llm.wait_params_hook = opt.wait_params
 
+    @_in_gemm_ctx
     def forward_backward(self, input_ids, attention_mask, omic_ids, omic_info_list, labels, accumulate=False,
                          final_micro=True):
         """One training micro-step on the native path: forward + loss + full backward into the flat grad buffer.
@@ -556,6 +576,7 @@ class OmicsOne(_MetaSafe):
                             v.zero_()
         return rt.llm.scal[2]
 
+    @_in_gemm_ctx
     def process_omic_sequences(self, hidden_states, omic_ids_list, omic_info_list, device=None):
         """reference: src/model/omics_one.py:49-136 — in-place overwrite of `hidden_states` [B,T,h]; returns it."""
         rt = self._runtime()
@@ -575,6 +596,7 @@ class OmicsOne(_MetaSafe):
             ops.copy_rows(emb, flat, emb.shape[0], dst_idx32=dst)
         return hidden_states
 
+    @_in_gemm_ctx
     def forward(self, input_ids=None, attention_mask=None, omic_ids=None, omic_info_list=None, labels=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
                 return_dict=None, task_label=None, task_num=None, **kwargs):
@@ -598,6 +620,7 @@ class OmicsOne(_MetaSafe):
 
 
     @torch.no_grad()
+    @_in_gemm_ctx
     def generate(self, input_ids, attention_mask=None, omic_ids=None, omic_info_list=None, max_length=None, min_length=None,
                  do_sample=True, temperature=0.8, top_p=0.95, top_k=None, num_beams=None, no_repeat_ngram_size=None,
                  **generate_kwargs):

@@ -36,7 +36,7 @@ def _prof_end(prof, e0, flops, layout):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-    prof.append((e0, e1, flops, lib().query("molly_gemm_last_config"), layout))
+    prof.append((e0, e1, flops, lib().query("molly_gemm_ctx_get", _ctx(), GEMM_KEYS["last_config"]), layout))
 
 
 def _stream() -> int:
@@ -52,12 +52,84 @@ def _chk(t: torch.Tensor, dtype=None, name="tensor"):
         raise ValueError(f"molly_amd: {name} must be contiguous in its last dimension")
 
 
+# ---- GEMM launch state (include/molly_hip.h: molly_gemm_ctx_*).  A GemmContext owns the launch knobs and the scratch memory of
+# everything launched while it is current; `with use_gemm_context(ctx):` makes it current.  Outside any context the calling
+# thread's default context of the library is used (tools, kernel tests).  A model owns one (OmicsOne.prepare), so an optimizer
+# that wants another launch shape at N > 1 changes ITS model's context and nothing else in the process.
+GEMM_KEYS = {"persistent_blocks": 1, "schedule": 2, "force_tile": 3, "group_m": 4, "small_grid_tile": 5, "min_ktiles": 6,
+             "streamk": 7, "last_config": 100}
+STREAMK_SCRATCH = (64 + 8192 * 64) + 256 * 2 * 262144   # header (a counter line per tile) + two 256 KiB accumulator images per block of a 256-block launch
+
+
+class GemmContext:
+    def __init__(self):
+        import ctypes
+        h = ctypes.c_void_p()
+        lib().call("molly_gemm_ctx_create", ctypes.addressof(h))
+        self.handle = h.value
+        self.ws = None
+        import os
+        if os.environ.get("MOLLY_GEMM_STREAMK") is not None:       # A/B and bisection knob: 0 off, 1 cost model (default), 2 wherever able
+            self.set("streamk", int(os.environ["MOLLY_GEMM_STREAMK"]))
+
+    def set(self, key: str, value: int):
+        lib().call("molly_gemm_ctx_set", self.handle, GEMM_KEYS[key], int(value))
+
+    def get(self, key: str) -> int:
+        return lib().query("molly_gemm_ctx_get", self.handle, GEMM_KEYS[key])
+
+    def ensure_workspace(self, nbytes: int, device="cuda"):
+        nbytes = max(int(nbytes), 0) + STREAMK_SCRATCH
+        if self.ws is None or self.ws.numel() * 4 < nbytes:
+            self.ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+            lib().call("molly_gemm_ctx_set_workspace", self.handle, self.ws, self.ws.numel() * 4)
+        return self.ws
+
+    def streamk_timeouts(self) -> int:
+        return lib().query("molly_gemm_ctx_streamk_timeouts", self.handle)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().call("molly_gemm_ctx_destroy", self.handle)
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+        self.handle = None
+
+
+_CTX_STACK = []
+
+
+def _ctx():
+    """handle of the current GEMM context (None = the calling thread's default context)."""
+    return _CTX_STACK[-1].handle if _CTX_STACK else None
+
+
+class use_gemm_context:
+    def __init__(self, ctx: Optional[GemmContext]):
+        self.ctx = ctx
+
+    def __enter__(self):
+        if self.ctx is not None:
+            _CTX_STACK.append(self.ctx)
+        return self.ctx
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            _CTX_STACK.pop()
+        return False
+
+
 _GEMM_WS = None
 
 
 def ensure_gemm_workspace(nbytes: int = 512 << 20, device="cuda"):
-    """Register an fp32 scratch slab for split-K partials (idempotent; grows only)."""
+    """Scratch for split-K partials and the stream-K slabs (idempotent; grows only) of the CURRENT context — the model's, inside
+    `use_gemm_context`; else the thread's default context."""
     global _GEMM_WS
+    if _CTX_STACK:
+        return _CTX_STACK[-1].ensure_workspace(nbytes, device)
+    nbytes = int(nbytes) + STREAMK_SCRATCH
     if _GEMM_WS is None or _GEMM_WS.numel() * 4 < nbytes:
         _GEMM_WS = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         lib().call("molly_gemm_set_workspace", _GEMM_WS, _GEMM_WS.numel() * 4)
@@ -78,7 +150,7 @@ def gemm_gate_up_swiglu(x, w_gu, gu, act):
     assert w_gu.shape[1] == K and tuple(gu.shape) == (M, N) and tuple(act.shape) == (M, N // 2) and N % 256 == 0
     prof = GEMM_PROFILE
     e0 = _prof_begin() if prof is not None else None
-    lib().call("molly_gemm_bf16", _stream(), x, w_gu, gu, None, act, M, N, K, x.stride(0), w_gu.stride(0), gu.stride(0),
+    lib().call("molly_gemm_bf16_ctx", _ctx(), _stream(), x, w_gu, gu, None, act, M, N, K, x.stride(0), w_gu.stride(0), gu.stride(0),
                act.stride(0), GEMM_SWIGLU, 0, 0)
     if prof is not None:
         _prof_end(prof, e0, 2.0 * M * N * K, (False, False))
@@ -95,8 +167,8 @@ def gemm_down_dgrad_swiglu_bwd(dy, w_down, gu, dgu):
     assert w_down.shape[0] == K and tuple(gu.shape) == (M, 2 * ff) and tuple(dgu.shape) == (M, 2 * ff)
     prof = GEMM_PROFILE
     e0 = _prof_begin() if prof is not None else None
-    lib().call("molly_gemm_bf16", _stream(), dy, w_down, dgu, None, gu, M, ff, K, dy.stride(0), w_down.stride(0), dgu.stride(0),
-               gu.stride(0), GEMM_SWIGLU_BWD, 0, 1)
+    lib().call("molly_gemm_bf16_ctx", _ctx(), _stream(), dy, w_down, dgu, None, gu, M, ff, K, dy.stride(0), w_down.stride(0),
+               dgu.stride(0), gu.stride(0), GEMM_SWIGLU_BWD, 0, 1)
     if prof is not None:
         _prof_end(prof, e0, 2.0 * M * ff * K, (False, True))
     return dgu
@@ -130,7 +202,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
         raise TypeError("gemm_nt: out must be bf16 or fp32")
     prof = GEMM_PROFILE
     e0 = _prof_begin() if prof is not None else None
-    lib().call("molly_gemm_bf16", _stream(), a, b, out, bias, res, M, N, K, a.stride(0), b.stride(0), out.stride(0),
+    lib().call("molly_gemm_bf16_ctx", _ctx(), _stream(), a, b, out, bias, res, M, N, K, a.stride(0), b.stride(0), out.stride(0),
                res.stride(0) if res is not None else 0, flags, int(a_kmajor), int(b_kmajor))
     if prof is not None:
         _prof_end(prof, e0, 2.0 * M * N * K, (a_kmajor, b_kmajor))
@@ -158,7 +230,7 @@ def gemm_grouped(problems, accumulate: bool = False):
         flags |= GEMM_OUT_F32
     prof = GEMM_PROFILE
     e0 = _prof_begin() if prof is not None else None
-    lib().call("molly_gemm_grouped_bf16", _stream(), desc.data_ptr(), len(problems), K, flags)
+    lib().call("molly_gemm_grouped_bf16_ctx", _ctx(), _stream(), desc.data_ptr(), len(problems), K, flags)
     if prof is not None:
         _prof_end(prof, e0, sum(2.0 * a.shape[0] * b.shape[1] * K for a, b, _, _ in problems), (False, True))
 

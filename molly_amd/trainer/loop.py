@@ -87,6 +87,12 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         rt = model._runtime()
+        if optimizer is None and self.world > 1:
+            # first contact with the communication backend BEFORE the optimizer picks its collective forms: the three
+            # collectives of the step on small buffers with known answers; a wrong in-place result selects the staged forms
+            # (bench.py and smoke_dist did this; a plain `python -m molly_amd.train` run never had)
+            from .zero2 import preflight_collectives
+            self.comm_preflight = preflight_collectives(rt.dev)
         self.opt = optimizer if optimizer is not None else Zero2Optimizer(
             rt.P.flat, rt.G.flat, model.n_decay, lr=args.learning_rate, betas=(args.adam_beta1, args.adam_beta2),
             eps=args.adam_epsilon, weight_decay=args.weight_decay, max_grad_norm=args.max_grad_norm, stage=args.zero_stage)

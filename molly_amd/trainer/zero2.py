@@ -243,14 +243,13 @@ class Zero2Optimizer:
                 # CU, each owning 1/256 of the tiles: with a few CUs taken, the blocks that cannot start wait for a whole
                 # share to finish and the launch takes twice as long.  Blocks of THREE tiles (ceil(tiles / 3) of them, placed by
                 # the hardware dispatcher on whatever CUs are free) degrade by the CUs taken only and keep two of every three
-                # tile boundaries under the GEMM's rolling prefetch (one tile per block keeps none: measured on one GPU,
-                # DESIGN.md 5).  A prediction for the CU conflict, not yet a measurement on 8 GPUs: MOLLY_GEMM_PERSISTENT_MULTI
-                # = 256 keeps the one-block-per-CU launch, 0 = one block per tile, -t = t tiles per block (default -3).
-                from .. import ops
+                # tile boundaries under the GEMM's rolling prefetch (measured on one GPU with a stand-in that holds CUs:
+                # DESIGN.md 5; not yet on 8 GPUs).  MOLLY_GEMM_PERSISTENT_MULTI = 256 keeps the one-block-per-CU launch,
+                # 0 = one block per tile, -t = t tiles per block (default -3).
+                # The optimizer only RECORDS the wish: `OmicsOne.attach_optimizer` applies it to the GEMM context of the model
+                # this optimizer steps — no other model, evaluator or later test in the process inherits it.
                 mode = os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "-3")
-                mode = 256 if mode == "1" else int(mode)
-                ops.lib().call("molly_gemm_set_persistent_blocks", mode)
-                self.gemm_blocks_mode = mode
+                self.gemm_blocks_mode = 256 if mode == "1" else int(mode)
             self.cstream = torch.cuda.Stream(device=dev, priority=-1)     # collectives first whenever CUs free up
             self._rs_done = [False] * len(self.buckets)
             self._ag_events = [None] * len(self.buckets)

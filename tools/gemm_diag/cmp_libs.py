@@ -4,7 +4,12 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from molly_amd._lib import MollyLib, lib
-A, Bv = lib(), MollyLib(os.path.join(ROOT, "tools", "variants", f"libmolly_{sys.argv[1]}.so"))
+A, Bv = lib(), MollyLib(os.path.join(ROOT, "tools", "variants", f"libmolly_{sys.argv[1]}.so"), strict=False)
+# second argument 0: stream-K off in the in-tree library (then every case must be bit-identical to a build that has no stream-K);
+# default 1: the grids that take the stream-K launch are allowed the fp32 reordering of their K-range sums and are reported apart
+SK = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if "molly_gemm_set_streamk" in A.fn:
+    A.call("molly_gemm_set_streamk", SK)
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
@@ -36,8 +41,11 @@ for (M, N, K, form, flags) in cases:
     torch.cuda.synchronize()
     if not torch.equal(outs[0], outs[1]):
         d = (outs[0].float() - outs[1].float()).abs()
+        if A.fn['molly_gemm_last_config']() // 1000 >= 50 and d.max().item() <= 2 ** -7 * outs[1].float().abs().max().item():
+            nsk = globals().get("nsk", 0) + 1
+            continue
         rows = (d.max(dim=1).values > 0).nonzero().flatten()
         cols = (d.max(dim=0).values > 0).nonzero().flatten()
         print(f"MISMATCH M={M} N={N} K={K} {form} flags={flags}: max {d.max().item():.3g}, rows {rows[:4].tolist()}..{rows[-1].item()} ({len(rows)}), cols {cols[:4].tolist()}..{cols[-1].item()} ({len(cols)}), cfg {A.fn['molly_gemm_last_config']()}")
         bad += 1
-print("cases", len(cases), "mismatches", bad)
+print("cases", len(cases), "mismatches", bad, "stream-K cases within one bf16 step of the one-pass result:", globals().get("nsk", 0))
