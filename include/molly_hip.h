@@ -100,7 +100,10 @@ enum {
                                              order: deterministic) WHERE that beats split-K slabs + reduce launch / the 128x128
                                              kernel by the launcher's cost model (long contractions just past a whole round);
                                              2: wherever stream-K is able to run (tests, tools); 0: never */
-    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
+    MOLLY_GEMM_KEY_SKINNY = 8,            /* 1 (default): forward GEMMs with M <= 64 rows (the decode step of `generate`) run on the
+                                             weight-streaming kernel — one launch, W read once straight into registers; 0: K split over
+                                             the chip through the tile kernel + fp32 slabs + reduce launch (round 2's path; A/B) */
+    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
 int molly_gemm_ctx_create(void** out);

@@ -1221,6 +1221,143 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #undef SEG_BARRIER
 }
 
+// ================================================================================================
+// Decode rows: y[M <= 64, N] = x[M, K] W[N, K]^T — the q_len = 1 projections of `generate` (HF:models/qwen3/modeling_qwen3.py:
+// 76-83, 225-236 with one token per sample; reference src/model/omics_one.py:220-232).  A pure WEIGHT STREAM: every byte of W is
+// read once, x (M x K, a few hundred KB) stays in L2, the arithmetic is free.  So no tiles, no LDS staging, no slabs:
+//   * one workgroup = 16 rows of W (one MFMA tile of outputs), its 4 waves split K in four; a wave streams its quarter of the 16
+//     rows straight into registers with 16-byte non-temporal loads — W is the A operand of mfma_16x16x32 (lane (n = lane & 15,
+//     g = lane >> 4) holds W[n][k0 + 8g .. +7]), the two k-steps of a 128-byte line issued back to back, U line-pairs
+//     (8 loads per lane) in flight before the first is used (guide 5 'glds vs register staging', GEMV row);
+//   * x is the B operand (lane (m = lane & 15, g) holds x[m][k0 + 8g .. +7]): plain loads that hit L1 / L2;
+//   * the four partial 16 x M tiles meet in 4 KB of LDS, wave 0..MT-1 apply the epilogue (bias -> GELU -> residual ->
+//     accumulate; bf16 or fp32) and store 4 consecutive n per lane.
+// N / 16 workgroups of 4 waves, up to 8 per CU: 256 KB of loads in flight per CU.  Replaces, for M <= 64, the 256x256 kernel
+// split 8-32 ways over K + fp32 slabs + the reduce launch (2.3-3.1 TB/s on Qwen3-8B's matrices; two launches per projection).
+// ================================================================================================
+struct SkinnyArgs {
+    const bf16_t* X; const bf16_t* W; void* C; const bf16_t* bias; const bf16_t* res;
+    int M, N, K, ldx, ldw, ldc, ldres, flags;
+};
+
+// MT = 16-row tiles of x (M <= 16 MT), NT = 16-row tiles of W per wave, KW = waves per workgroup = ways K is split.
+// What bounds it is the vector-memory path, not HBM: every byte — W from HBM, x from L2 — enters through 64-byte requests at
+// ~17 B/clk per CU (measured: 9 TB/s of loads chip-wide whatever the mix).  With NT = 1 a wave loads 2 x-bytes per W-byte at
+// M = 32 (2.9 TB/s of W); NT = 4 reuses each x fragment for four W fragments: 0.5 x-bytes per W-byte.
+template <int MT, int NT, int KW>
+__global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs p) {
+    __shared__ float red[KW - 1][NT][MT][256];                  // [waves 1..][n-tile][m-tile][64 lanes x 4 floats]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16 * NT;
+    const int fr = lane & 15, g = lane >> 4;
+    const int kq = p.K / KW;                                    // K per wave (a multiple of 64: host check)
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int wrow = n0 + 16 * j + fr;
+        wrow = wrow < p.N ? wrow : p.N - 1;                     // ragged last tile: re-read the last row, masked at the store
+        wp[j] = p.W + (size_t)wrow * p.ldw + wave * kq + 8 * g;
+    }
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        int m = t * 16 + fr;
+        m = m < p.M ? m : p.M - 1;
+        xp[t] = p.X + (size_t)m * p.ldx + wave * kq + 8 * g;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = NT * MT <= 2 ? 4 : 2;                     // line pairs (64 k each) in flight per wave
+    const int npair = kq >> 6;
+    // W AND x of a pair are issued U pairs ahead (x is an L2 round trip too: M x K does not stay in a 32 KB L1 beside 32 streams)
+    bf16x8 wa[U][NT], wb[U][NT], xa[U][MT], xb[U][MT];
+    auto issue = [&](int slot, int pair) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            wa[slot][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + pair * 64));
+            wb[slot][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[j] + pair * 64 + 32));
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            xa[slot][t] = *reinterpret_cast<const bf16x8*>(xp[t] + pair * 64);
+            xb[slot][t] = *reinterpret_cast<const bf16x8*>(xp[t] + pair * 64 + 32);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (u < npair) issue(u, u);
+    for (int pr = 0; pr < npair; pr += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pr + u >= npair) break;
+            bf16x8 a[NT], b[NT], ya[MT], yb[MT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { a[j] = wa[u][j]; b[j] = wb[u][j]; }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { ya[t] = xa[u][t]; yb[t] = xb[u][t]; }
+            if (pr + u + U < npair) issue(u, pr + u + U);      // refill the slot: U pairs stay in flight
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], ya[t], acc[j][t], 0, 0, 0);
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], yb[t], acc[j][t], 0, 0, 0);
+                }
+        }
+    }
+    // ---- the K parts meet in LDS; lane (m = fr, g) of wave 0 holds y[m][n0 + 16 j + 4g .. +3] of m-tile t
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4*>(&red[wave - 1][j][t][lane * 4]) = acc[j][t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        f32x4 v = acc[j][t];
+#pragma unroll
+        for (int w = 0; w < KW - 1; ++w) v += *reinterpret_cast<const f32x4*>(&red[w][j][t][lane * 4]);
+        const int m = t * 16 + fr, n = n0 + 16 * j + 4 * g;
+        if (m >= p.M || n >= p.N) continue;                     // N % 4 == 0 (host check)
+        float o[4] = {v[0], v[1], v[2], v[3]};
+        if (p.flags & MOLLY_GEMM_BIAS) {
+            const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
+            o[0] += bflo(bb[0]); o[1] += bfhi(bb[0]); o[2] += bflo(bb[1]); o[3] += bfhi(bb[1]);
+        }
+        if (p.flags & MOLLY_GEMM_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+        }
+        if (p.flags & MOLLY_GEMM_RESIDUAL) {
+            const u32x2 bb = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldres + n);
+            o[0] += bflo(bb[0]); o[1] += bfhi(bb[0]); o[2] += bflo(bb[1]); o[3] += bfhi(bb[1]);
+        }
+        if (p.flags & MOLLY_GEMM_OUT_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+            if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                const f32x4 old = *reinterpret_cast<const f32x4*>(c);
+                o[0] += old[0]; o[1] += old[1]; o[2] += old[2]; o[3] += old[3];
+            }
+            *reinterpret_cast<f32x4*>(c) = f32x4{o[0], o[1], o[2], o[3]};
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+            if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                const u32x2 old = *reinterpret_cast<const u32x2*>(c);
+                o[0] += bflo(old[0]); o[1] += bfhi(old[0]); o[2] += bflo(old[1]); o[3] += bfhi(old[1]);
+            }
+            *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        }
+    }
+}
+
 // out[m,n] (+)= sum_s slab[s][m][n]   (split-K combine; 4 elements per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long MN, int M, int N,
                                                             void* C, int ldc, int out_f32, int accumulate,
@@ -1277,6 +1414,7 @@ struct GemmCtx {
     int small_grid_tile = 128;     // with stream-K off: kernel for grids that fill the chip neither plain nor split (128 | 512)
     int min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
     int force_tile = 0;            // 0 heuristic | 128 | 512
+    int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
     int streamk = 1;               // 1 = stream-K where its cost model says it wins (M, N >= 256); 2 = wherever it is able (tests); 0 = off
     int last_cfg = 0;              // 128 / 512 + 1000 * split-K factor (+ 50000: stream-K, + 100000 * problems: grouped)
     float* ws = nullptr;           // scratch: [stream-K header: error word + flags][fp32 slabs of split-K / stream-K]
@@ -1489,6 +1627,37 @@ int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, 
     p.sk = 0; p.sk_tile_aligned = 0; p.sk_flag = nullptr; p.sk_slab = nullptr;
     if (int rc = resolve_zero_page(&p.zeros)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // decode rows (M <= 64, the plain forward form): the weight-streaming kernel, one launch
+    // Where it is used (tools/bench_decode_gemm.py, M = 32 / 8, same box): it wins wherever launches, not bytes, set the time —
+    // matrices up to ~64 MB (every projection of the 1.7B model: 8.7 against 15.6 us for qkv; Qwen3-8B qkv / o: 19.5 / 14.2 against
+    // 21.7 / 18.8) and any matrix at M <= 16 (8B gate|up at M = 8: 4.5 against 4.0 TB/s).  The 100-200 MB matrices at M = 32 stay on
+    // the tile kernel (3.1-3.6 TB/s there, 5.0 on the 1.2 GB lm_head): x enters through the same 64-byte request path as W, and
+    // at 32 rows it is the larger stream unless a wave keeps 64 rows of W — which leaves too few waves for the 4096-row matrices.
+    if (!at && !bt && M <= 64 && c.skinny && c.force_tile == 0 && K % 256 == 0 && N % 4 == 0 && N >= 256 &&
+        (M <= 16 || (long)N * K <= (32L << 20)) && !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) {
+        SkinnyArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, M, N, K, lda, ldb, ldc, ldres, flags};
+        // W rows per wave (16 NT) and K parts per workgroup (KW): as much reuse of x as still leaves >= ~1000 waves on the chip
+        const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4;
+        int nt = 4, kw = 4;
+        auto waves = [&](int nt_, int kw_) { return (long)cdiv(N, 16 * nt_) * kw_; };
+        if (waves(4, 4) < 1000) { nt = 2; kw = K % 512 == 0 ? 8 : 4; }
+        if (mt == 4) nt = min(nt, 2);                        // (registers: 4 x 4 accumulator tiles + the fragments in flight)
+        if (N <= 4096 || waves(nt, kw) < 600) { nt = 1; kw = 4; }   // (a 4096-row matrix: 256 workgroups of 4 waves measured best)
+#define MOLLY_SKINNY(MT_, NT_, KW_) \
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT_, NT_, KW_>), dim3(cdiv(N, 16 * NT_)), dim3(64 * KW_), 0, st, q)
+#define MOLLY_SKINNY_M(NT_, KW_) \
+        do { if (mt == 1) MOLLY_SKINNY(1, NT_, KW_); else if (mt == 2) MOLLY_SKINNY(2, NT_, KW_); else MOLLY_SKINNY(4, NT_, KW_); } while (0)
+        if (nt == 4) { if (mt == 1) MOLLY_SKINNY(1, 4, 4); else MOLLY_SKINNY(2, 4, 4); }
+        else if (nt == 2 && kw == 8) MOLLY_SKINNY_M(2, 8);
+        else if (nt == 2) MOLLY_SKINNY_M(2, 4);
+        else if (kw == 8) MOLLY_SKINNY_M(1, 8);
+        else MOLLY_SKINNY_M(1, 4);
+#undef MOLLY_SKINNY_M
+#undef MOLLY_SKINNY
+        c.last_cfg = 16 + 1000;
+        MOLLY_LAUNCH_CHECK();
+        return 0;
+    }
     if (flags & MOLLY_GEMM_SWIGLU) {
         MOLLY_CHECK(!at && !bt && flags == MOLLY_GEMM_SWIGLU && res && N % 256 == 0 && ldres % 4 == 0,
                     "gemm: MOLLY_GEMM_SWIGLU is the plain NT form with N = 2*ff, ff %% 128 == 0 (N=%d), res = the activation output", N);
@@ -1596,6 +1765,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v >= 2 && v <= 64, "gemm min_ktiles: %ld not in 2..64", v);
         c.min_ktiles = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_SKINNY:
+        MOLLY_CHECK(v == 0 || v == 1, "gemm skinny: %ld not in {0,1}", v);
+        c.skinny = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_STREAMK:
         MOLLY_CHECK(v >= 0 && v <= 2, "gemm streamk: %ld not in {0,1,2}", v);
         c.streamk = (int)v;
@@ -1672,6 +1845,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_SMALL_GRID_TILE: return c.small_grid_tile;
     case MOLLY_GEMM_KEY_MIN_KTILES: return c.min_ktiles;
     case MOLLY_GEMM_KEY_STREAMK: return c.streamk;
+    case MOLLY_GEMM_KEY_SKINNY: return c.skinny;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

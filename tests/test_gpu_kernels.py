@@ -540,6 +540,7 @@ def test_gemm_decode_rows_splitk_with_epilogue(M, N, K):
     from molly_amd import ops
     from molly_amd._lib import lib
     ops.ensure_gemm_workspace(64 << 20)
+    lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["skinny"], 0)      # round 2's path (the decode-row kernel has its own test)
     g = torch.Generator(device="cuda").manual_seed(M + N)
     a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
@@ -556,6 +557,7 @@ def test_gemm_decode_rows_splitk_with_epilogue(M, N, K):
         assert (out.float() - ref.float()).abs().max().item() <= 2e-2 * max(ref.float().abs().max().item(), 1.0), kw.keys()
     r32 = a.float() @ w.float().t()
     assert (ops.gemm_nt(a, w).float() - r32).abs().max().item() <= 2e-2 * r32.abs().max().item()
+    lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["skinny"], 1)
 
 
 def test_gelu_epilogue_erf_accuracy_over_the_whole_range():
@@ -704,3 +706,39 @@ def test_gemm_launch_shapes_are_bit_identical(form, M, N, K, res):
     if res:
         ref = ref + r.float()
     _close(outs[0], ref, 2e-2, 2e-2, "gemm vs fp32")
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1000, 1280), (256, 256), (6144, 2560), (12288, 2048)])
+def test_gemm_decode_row_kernel(M, N, K):
+    """M <= 64 forward GEMMs (the decode step's projections, HF:models/qwen3/modeling_qwen3.py:76-83 with one token per sample) on the
+    weight-streaming kernel: exact on small integers (every epilogue), fp32 accumulation error only on random data, and the
+    same numbers as round 2's split-K path up to the order of the K-quarter sums."""
+    g = torch.Generator(device="cuda").manual_seed(M * 131 + N + K)
+    ints = lambda *s: torch.randint(-3, 4, s, device="cuda", generator=g).to(BF)
+    x, w, bias, res = ints(M, K), ints(N, K), ints(N), ints(M, N)
+    ref = x.float() @ w.float().t()
+    c = ops.GemmContext()
+    c.ensure_workspace(64 << 20)
+    with ops.use_gemm_context(c):
+        out = ops.gemm_nt(x, w, out_dtype=torch.float32)
+        assert c.get("last_config") == 1016                      # the decode-row kernel
+        assert torch.equal(out, ref)
+        assert torch.equal(ops.gemm_nt(x, w, bias=bias, res=res, out_dtype=torch.float32), ref + bias.float() + res.float())
+        acc = ints(M, N).float()
+        want = acc + ref
+        ops.gemm_nt(x, w, out=acc, accumulate=True)
+        assert torch.equal(acc, want)
+        got = ops.gemm_nt(x, w, bias=bias, gelu=True)
+        wg = torch.nn.functional.gelu(ref + bias.float())
+        assert (got.float() - wg).abs().max().item() <= 2 ** -7 * wg.abs().max().item()
+        xr, wr = _rand(M, K, seed=5).to(BF), _rand(N, K, seed=6).to(BF)
+        o1 = ops.gemm_nt(xr, wr, out_dtype=torch.float32)
+    _close(o1, xr.float() @ wr.float().t(), atol=2e-3 * math.sqrt(K), rtol=1e-4, what="decode-row kernel fp32")
+    off = ops.GemmContext()
+    off.ensure_workspace(64 << 20)
+    off.set("skinny", 0)
+    with ops.use_gemm_context(off):
+        o0 = ops.gemm_nt(xr, wr, out_dtype=torch.float32)
+        assert off.get("last_config") != 1016
+    _close(o1, o0, atol=2e-3 * math.sqrt(K), rtol=1e-4, what="decode-row kernel vs split-K path")
