@@ -103,6 +103,7 @@ enum {
     MOLLY_GEMM_KEY_SKINNY = 8,            /* 1 (default): forward GEMMs with M <= 64 rows (the decode step of `generate`) run on the
                                              weight-streaming kernel — one launch, W read once straight into registers; 0: K split over
                                              the chip through the tile kernel + fp32 slabs + reduce launch (round 2's path; A/B) */
+    MOLLY_GEMM_KEY_SMALL3 = 9,            /* A/B knob: 1 = 128x128 grids of at most one tile per CU run a 3-stage ring; 0 (default) = the 2-stage loop */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };

@@ -11,6 +11,7 @@
 // converted to bf16 is directly the B operand of O^T = V^T·P^T; V^T fragments come from the row-major V tile through
 // ds_read_b64_tr_b16 (guide T10).  Q lives in registers for the whole kernel.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "molly_hip.h"
@@ -190,6 +191,19 @@ __device__ __forceinline__ void store_rows(bf16_t* slab, const f32x16 (&acc)[ND]
 #endif
 }
 
+// max over the two half-waves' copies of a row statistic without an LDS round trip: after the swap `a` holds the lower half's
+// value in both halves and `b` the upper half's.  (asm with two registers: chained on one value the builtin is folded away by
+// hipcc — the note in stage_kv; MOLLY_ATTN_XHALF_LDS=1 at compile time restores the ds_bpermute form for an A/B)
+__device__ __forceinline__ float xhalf_max(float v) {
+#if defined(MOLLY_ATTN_XHALF_LDS) && MOLLY_ATTN_XHALF_LDS
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+#else
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+#endif
+}
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[e]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
+        mx = xhalf_max(mx) * p.scale_log2;
         // deferred rescale (guide T13): keep the old reference max unless some row's max grew by > RESCALE_THR.  The
         // decision precedes every exponentiation of this half (textbook order), so nothing is ever half-scaled.
         if (!__all(mx - m_run <= RESCALE_THR)) {
@@ -729,10 +743,13 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
         return 0;
     }
     dim3 grid(n_heads * B, cdiv(T, BQ));
-    const size_t lds = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
+    // MOLLY_ATTN_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, e.g. 40960 leaves room for ONE workgroup per CU — what the
+    // second wave of every SIMD is worth is then the ratio of the two run times
+    static const size_t pad = [] { const char* e = getenv("MOLLY_ATTN_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    const size_t lds = 2 * 2 * BKV * head_dim * sizeof(bf16_t) + pad;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 65536);
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
         attr_set = true;
     }

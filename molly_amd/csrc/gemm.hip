@@ -253,11 +253,14 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
+    // (the 3-stage ring names every wait itself: its LDS-DMA is issued from asm, invisible to hipcc — dma16's note; the 2-stage
+    // loop relies on the vmcnt(0) hipcc puts in front of __syncthreads while an LDS-DMA is in flight)
+    constexpr bool HIDE = NSTAGE != 2;
     auto stage = [&](int t, bf16_t* dst) {
-        if (AT) stage_km<BM, NW, BK>(p.A, p.lda, m0, p.M, t * BK, p.K, p.zeros, dst, wave, lane);
-        else stage_kc<BM, NW, BK>(p.A, p.lda, m0, p.M, t * BK, dst, wave, lane);
-        if (BT) stage_km<BN, NW, BK>(p.B, p.ldb, n0, p.N, t * BK, p.K, p.zeros, dst + A_ELEMS, wave, lane);
-        else stage_kc<BN, NW, BK>(p.B, p.ldb, n0, p.N, t * BK, dst + A_ELEMS, wave, lane);
+        if (AT) stage_km<BM, NW, BK, HIDE>(p.A, p.lda, m0, p.M, t * BK, p.K, p.zeros, dst, wave, lane);
+        else stage_kc<BM, NW, BK, HIDE>(p.A, p.lda, m0, p.M, t * BK, dst, wave, lane);
+        if (BT) stage_km<BN, NW, BK, HIDE>(p.B, p.ldb, n0, p.N, t * BK, p.K, p.zeros, dst + A_ELEMS, wave, lane);
+        else stage_kc<BN, NW, BK, HIDE>(p.B, p.ldb, n0, p.N, t * BK, dst + A_ELEMS, wave, lane);
     };
     const int fr = lane & 15, fq = lane >> 4;
     auto read_frags = [&](const bf16_t* sA, int kk, bf16x8 (&af)[4], bf16x8 (&bfr)[4]) {
@@ -295,13 +298,29 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
         // 3-stage LDS ring (tiles t+1, t+2 in flight behind a COUNTED vmcnt, raw barrier: guide §5 "Pipelining across
         // barriers") + register double-buffering of the MFMA fragments: the reads of the next 32-deep sub-step are
         // issued before the MFMAs of the current one, so the matrix pipe only idles across the one barrier per K-step.
-        static_assert(NLOAD == 6 && BK == 64, "vmcnt immediates below assume 6 LDS-DMA instructions per wave per stage");
+        static_assert((NLOAD == 6 || NLOAD == 8) && BK == 64, "vmcnt immediates below: 6 or 8 LDS-DMA instructions per wave per stage");
+        // s_waitcnt vmcnt(k * NLOAD) (+ lgkmcnt(0)): all but the k youngest stages' pieces have landed
+        auto wait_stages = [&](auto k_tag, bool lgkm) {
+            constexpr int N = decltype(k_tag)::value * NLOAD;
+            if (lgkm) {
+                if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            } else {
+                if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
+        };
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
         stage(0, smem);
         if (nk > 1) stage(1, smem + STAGE);
         if (nk > 2) stage(2, smem + 2 * STAGE);
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nk > 2) wait_stages(K2{}, false);
+        else if (nk > 1) wait_stages(K1{}, false);
+        else wait_stages(K0{}, false);
         __builtin_amdgcn_s_barrier();
         bf16x8 a0[4], b0[4], a1[4], b1[4];
         read_frags(smem, 0, a0, b0);
@@ -313,8 +332,8 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
             mma(a0, b0);
             if (t + 1 < nk) {
                 // every read of tile t must have returned before any wave may overwrite its stage (tile t+3)
-                if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (t + 2 < nk) wait_stages(K1{}, true);
+                else wait_stages(K0{}, true);
                 __builtin_amdgcn_s_barrier();
                 if (t + 3 < nk) stage(t + 3, smem + s_cur * STAGE);
                 read_frags(smem + s_nxt * STAGE, 0, a0, b0);
@@ -1414,6 +1433,9 @@ struct GemmCtx {
     int small_grid_tile = 128;     // with stream-K off: kernel for grids that fill the chip neither plain nor split (128 | 512)
     int min_ktiles = 16;           // split-K: shortest K-slice (in 64-wide K-tiles) of a grid that is not skinny
     int force_tile = 0;            // 0 heuristic | 128 | 512
+    int small3 = 0;                // 1 = 128x128 grids of at most one tile per CU on the 3-stage ring; 0 (default): the 2-stage loop — measured equal
+                                   // (tools/bench_esm_gemm.py: 22.4 / 24.4 / 27.5 us against 21.8 / 22.7 / 27.5 at M = 1024): these launches are not
+                                   // bound by the LDS-DMA drain
     int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
     int streamk = 1;               // 1 = stream-K where its cost model says it wins (M, N >= 256); 2 = wherever it is able (tests); 0 = off
     int last_cfg = 0;              // 128 / 512 + 1000 * split-K factor (+ 50000: stream-K, + 100000 * problems: grouped)
@@ -1466,6 +1488,8 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 128, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * (128 + BN) * 64 * 2);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 128, 3, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * (128 + BN) * 64 * 2);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false, false, true>,
@@ -1585,8 +1609,14 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
     } else {
         c.last_cfg = 128 + 1000;
         p.tiles_m = cdiv(p.M, 128); p.tiles_n = cdiv(p.N, BN);
-        hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
-                           2 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
+        // (knob, off by default: grids of at most one tile per CU on the 3-stage ring — tiles t+1, t+2 in flight behind a counted
+        // vmcnt, fragments double-buffered in registers — instead of the 2-stage loop; measured equal, see GemmCtx::small3)
+        if (c.small3 && nk >= 3 && p.tiles_m * p.tiles_n <= 256)
+            hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 3, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
+                               3 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
+        else
+            hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
+                               2 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
     }
     return 0;
 }
@@ -1765,6 +1795,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v >= 2 && v <= 64, "gemm min_ktiles: %ld not in 2..64", v);
         c.min_ktiles = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_SMALL3:
+        MOLLY_CHECK(v == 0 || v == 1, "gemm small3: %ld not in {0,1}", v);
+        c.small3 = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_SKINNY:
         MOLLY_CHECK(v == 0 || v == 1, "gemm skinny: %ld not in {0,1}", v);
         c.skinny = (int)v;
@@ -1846,6 +1880,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_MIN_KTILES: return c.min_ktiles;
     case MOLLY_GEMM_KEY_STREAMK: return c.streamk;
     case MOLLY_GEMM_KEY_SKINNY: return c.skinny;
+    case MOLLY_GEMM_KEY_SMALL3: return c.small3;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

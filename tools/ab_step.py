@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """In-process A/B of the whole Molly-1.7B training step under two settings of one library knob (boxes differ by +-2 %, so
 variants are only ever compared inside one process, alternating).
-    python tools/ab_step.py --knob molly_gemm_set_schedule --a -1 --b 0
-    python tools/ab_step.py --knob molly_gemm_set_persistent_blocks --a 256 --b 0"""
+    python tools/ab_step.py --knob schedule --a -1 --b 0
+    python tools/ab_step.py --knob persistent_blocks --a 256 --b -3        (keys of ops.GEMM_KEYS: the model's own GEMM context)"""
 import argparse
 import os
 import sys
@@ -44,7 +44,7 @@ def main():
     res = {args.a: [], args.b: []}
     for _ in range(args.rounds):
         for v in (args.a, args.b):
-            lib().call(args.knob, v)
+            m._rt.gemm_ctx.set(args.knob.replace('molly_gemm_set_', ''), v)
             step()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -24,7 +24,8 @@ def timeit(fn, n=5):
 
 
 def main():
-    B, T, nh, nkv, hd = 8, 2048, 16, 8, 128
+    import os
+    B, T, nh, nkv, hd = (int(x) for x in os.environ.get("ATTN_SHAPE", "8,2048,16,8,128").split(","))   # e.g. 16,2048,64,8,128 (the guide's)
     M = B * T
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn(M, (nh + 2 * nkv) * hd, device="cuda", generator=g).bfloat16()

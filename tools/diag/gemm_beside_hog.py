@@ -23,10 +23,10 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
     shapes = [("qkv fwd", "nt", 16384, 4096, 2048), ("gate|up fwd", "nt", 16384, 12288, 2048), ("down dgrad", "nn", 16384, 6144, 2048),
-              ("gate|up dgrad", "nn", 16384, 2048, 12288)]
+              ("gate|up dgrad", "nn", 16384, 2048, 12288), ("8b qkv B=1 (stream-K)", "nt", 4096, 6144, 4096)]
     side = torch.cuda.Stream()
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
-    print(f"{'shape':14s} {'CUs held':>8s} " + " ".join(f"{('mode ' + str(m)):>10s}" for m in a.modes) + "   (TF/s)")
+    print(f"{'shape':22s} {'CUs held':>8s} " + " ".join(f"{('mode ' + str(m)):>10s}" for m in a.modes) + "   (TF/s)")
     for name, form, M, N, K in shapes:
         x = rnd(M, K)
         w = rnd(N, K) if form == "nt" else rnd(K, N)
@@ -53,7 +53,7 @@ def main():
                     best = min(best, e0.elapsed_time(e1) / 5)
                     torch.cuda.synchronize()
                 row.append(2.0 * M * N * K / best / 1e9)
-            print(f"{name:14s} {cus:8d} " + " ".join(f"{v:10.0f}" for v in row))
+            print(f"{name:22s} {cus:8d} " + " ".join(f"{v:10.0f}" for v in row))
     lib().call("molly_gemm_set_persistent_blocks", 256)
 
 
