@@ -525,7 +525,7 @@ def main(argv=None):
                  (True, True): "TN gemm256_kernel<true,true>"}
         def klass(kcfg, lay):
             # cfg = 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems of a grouped launch)
-            key = names[lay] if kcfg % 1000 == 512 else "gemm_kernel<...,128,2,64> (a side narrower than a tile)"
+            key = names[lay] if kcfg % 1000 in (512, 513) else "gemm_kernel<...,128,2,64> (a side narrower than a tile)"
             if kcfg >= 100000:
                 key += f" grouped x{kcfg // 100000} (a layer's weight gradients in one launch)"
             elif kcfg // 1000 >= 50:
@@ -547,7 +547,7 @@ def main(argv=None):
         # passes of this same workload (tools/pmc_hbm_traffic.py; corrected as MI355X_MICROARCH.md §HBM prescribes)
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        tj = next((os.path.join(prof_dir, f) for f in ("r02b_hbm_traffic.json", "r02_hbm_traffic.json", "r01b_hbm_traffic.json")
+        tj = next((os.path.join(prof_dir, f) for f in ("r03_hbm_traffic.json", "r02b_hbm_traffic.json", "r02_hbm_traffic.json", "r01b_hbm_traffic.json")
                    if os.path.exists(os.path.join(prof_dir, f))), None)
         if args.train_mode == "full" and (B, T, K, args.model) == (8, 2048, 512, "1.7b") and args.micro is None and tj:
             with open(tj) as f:

@@ -104,7 +104,11 @@ enum {
                                              weight-streaming kernel — one launch, W read once straight into registers; 0: K split over
                                              the chip through the tile kernel + fp32 slabs + reduce launch (round 2's path; A/B) */
     MOLLY_GEMM_KEY_SMALL3 = 9,            /* A/B knob: 1 = 128x128 grids of at most one tile per CU run a 3-stage ring; 0 (default) = the 2-stage loop */
-    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
+    MOLLY_GEMM_KEY_DYNAMIC = 10,          /* 1: plain 256x256 launches of more than one round run as 256 resident blocks that DRAW their tiles
+                                             (one ticket counter per XCD label in the workspace header; the next ticket fetched five
+                                             K-tiles ahead, so the rolling prefetch never waits for it) — for GEMMs that share the chip
+                                             with a collective's kernels; same results as the static walk.  0 (default): static walk */
+    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
 int molly_gemm_ctx_create(void** out);
@@ -112,7 +116,7 @@ int molly_gemm_ctx_destroy(void* ctx);
 int molly_gemm_ctx_set(void* ctx, int key, long value);
 int molly_gemm_ctx_get(void* ctx, int key);                 /* the value (an answer, not a status); -1 = unknown key */
 /* scratch of a context: device memory the caller owns, 256-byte aligned, valid until replaced; NULL / 0 = none (no split-K, no
- * stream-K).  Layout: a 512 KiB + 64 B header (stream-K's error word and one counter line per tile; cleared here, synchronously,
+ * stream-K).  Layout: a 512 KiB + 576 B header (stream-K's error word, one counter line per tile, the dynamic fetch's 8 ticket lines; cleared here, synchronously,
  * once) followed by fp32 slabs: split-K partial sums [splits][M][N], or stream-K's two 256 KiB accumulator images per block.
  * 129 MiB serve every stream-K launch of 256 blocks. */
 int molly_gemm_ctx_set_workspace(void* ctx, void* ptr, long bytes);

@@ -23,7 +23,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + CSRC, "-I
 
 
 # per-file extra flags
-EXTRA = {}      # (tried for attention.hip: -fno-slp-vectorize — hipcc packs the softmax's scalar adds into v_pk_add_f32 behind v_mov
+# gemm.hip: the ticket of the dynamic tile fetch is ONE lane's returning atomic add whose result must stay in flight for a whole
+# K-tile; hipcc's atomic optimizer rewrites it into a wave reduction + readfirstlane that waits for the result on the spot
+EXTRA = {"gemm.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+                # (tried for attention.hip: -fno-slp-vectorize — hipcc packs the softmax's scalar adds into v_pk_add_f32 behind v_mov
                 # shuffles — 168-170 us either way at B8 T2048 H16 D128: not kept)
 
 

@@ -41,6 +41,8 @@ struct GemmArgs {
     int sk_tile_aligned;      // 1: the 8 XCD labels own whole tiles each (no piece of a tile crosses from one label to the next)
     unsigned* sk_flag;        // [tiles] units of the tile whose pieces have been written, 64 bytes apart, zero between launches
     float* sk_slab;           // [grid][2][8 waves][32 quads][64 lanes] f32x4: the accumulators of the block's (at most two) pieces
+    // dynamic tile fetch (gemm256_kernel<..., DYN = true>): one ticket counter per XCD label, 64 bytes apart, zero between launches
+    unsigned* dyn_cnt;
     // grouped launch (gemm256_kernel<..., GRP>): up to 16 problems sharing K, layouts and epilogue flags; one work list
     int ngroup;
     struct Group {
@@ -61,6 +63,10 @@ struct GemmArgs {
 #ifndef MOLLY_GEMM_ASM_DMA
 #define MOLLY_GEMM_ASM_DMA 1
 #endif
+// one word through LDS (ds_write_b32 / ds_read_b32: a generic pointer would make these flat instructions, which count on vmcnt too)
+__device__ __forceinline__ void lds_put(void* p, unsigned v) { *reinterpret_cast<volatile __attribute__((address_space(3))) unsigned*>(LDS_PTR(p)) = v; }
+__device__ __forceinline__ unsigned lds_get(void* p) { return *reinterpret_cast<volatile __attribute__((address_space(3))) unsigned*>(LDS_PTR(p)); }
+
 template <bool HIDE>
 __device__ __forceinline__ void dma16(const char* base, unsigned off, bf16_t* lds_dst) {
     if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
@@ -420,20 +426,31 @@ __device__ __forceinline__ void regroup_rows(unsigned& x0, unsigned& x1) {
 // (nontemporal epilogue stores, tried on the 8-byte pieces before the regrouping: 3x the fixed cost per tile — written through
 // as partial lines)
 //
-// SKM: STREAM-K.  A grid whose tiles do not fill the 256 CUs in whole rounds (the encoders' 80 / 320-tile projections, the
-// decoder GEMMs of a B = 1 micro-batch: 288 tiles = 1.125 rounds, 120 tiles = 0.47) is cut by WORK instead of by tile: all
-// tiles' K-tiles form one sequence (tile-major), every block takes an equal contiguous share of it, so a block's share is
-// [the tail of one tile][whole tiles][the head of another].  A piece that ends its tile OWNS the tile: it adds the other
-// pieces' accumulators to its own and runs the epilogue.  A piece that does not end its tile (a head or a middle) writes its
-// accumulators to the block's slab (fp32, register order, write-through) and raises the block's flag.  Order inside a block:
-// the head piece FIRST, whole tiles, the owned tail LAST — so every slab a block waits for was written by a block of lower
-// index as the first thing it did, long before it is needed; nothing waits on a higher block (dispatch order can only help).
-// Same numbers on every run: the cut and the order of the additions are functions of the grid alone.  Blocks with the same
-// XCD label (blockIdx & 7) take neighbouring shares, so a tile's pieces and its operand panels meet in one L2.
-// Replaces split-K slabs + the reduce launch and the 128x128 kernel for every grid with M, N >= 256.
-template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false>
+// SKM: STREAM-K.  A grid whose tiles do not fill the 256 CUs in whole rounds (the decoder GEMMs of a B = 1 micro-batch: 288 tiles
+// = 1.125 rounds, 384 = 1.5) is cut by WORK instead of by tile: all tiles' K-tiles form one sequence (tile-major), every block
+// takes an equal contiguous share of it, so a block's share is [the tail of one tile][whole tiles][the head of another].  A
+// whole tile runs the ordinary epilogue.  A PIECE writes its accumulators to one of the block's two slabs (fp32, register order,
+// write-through) and adds its length to the tile's counter; the piece whose addition completes the tile — the last arriver,
+// whichever that is: nobody ever waits — sums the slabs of all the tile's pieces in ascending-K order and runs the epilogue (see
+// the block at 'stream-K: a PIECE of a tile' below).  Same numbers on every run: the cut and the order of the additions are
+// functions of the grid alone.  Blocks with the same XCD label (blockIdx & 7) take neighbouring shares, so a tile's pieces and
+// its operand panels meet in one L2.  The hand-off costs 30-36 us per launch on this chip, so the launcher (launch_cfg) takes
+// stream-K only where its cost model says the alternatives waste more: long contractions on grids just past a whole round.
+//
+// DYN: DYNAMIC TILE FETCH.  The static walk (block b runs items b, b + G, ...) assumes that all G blocks start together and run
+// at one speed.  Beside a collective that is false: RCCL's kernels hold CUs, the blocks that found none start a round late and
+// the launch takes two rounds for what fits in 1.07 (tools/diag/gemm_beside_hog.py: -40 % with 16 CUs held).  Here a block
+// DRAWS its items: one returning atomic add on the counter of its XCD label (8 counters: a label's blocks keep walking their
+// own chunk of the tile order, so the L2 sharing of the static walk stays), issued by one lane five K-tiles before the
+// current tile ends and handed to the other waves through LDS, so that the next tile is known when the rolling prefetch needs it
+// (two K-tiles before the end).  The first item is drawn too (one exposed round trip per launch, ~2 us): a block that starts late
+// takes what is left instead of finding its share untouched.  Every block of a label draws exactly one ticket past the end; the
+// block that draws the LAST one (n + blocks - 1) puts the counter back to zero — after it, nobody in this launch reads it again.
+// Results are identical to the static walk's (a tile is computed the same way whoever computes it).
+template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false, bool DYN = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     static_assert(!SKM || (!P2 && !GRP), "stream-K exists on the four-phase, single-problem kernel");
+    static_assert(!DYN || (!P2 && !GRP && !SKM), "the dynamic tile fetch exists on the four-phase, single-problem kernel");
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
     constexpr int NWI = P2 ? 4 : 8;                   // waves that stage one operand
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -474,9 +491,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     int sk_u0 = 0, sk_u1 = 0;
     if constexpr (SKM) sk_range(blockIdx.x, sk_u0, sk_u1);
     // this block's work items: stream-K — its pieces, highest tile first; otherwise the virtual ids b, b + G, b + 2G, ...
+    // (dynamic fetch: the items of this block's XCD label, indices 0 .. nitems - 1 of its chunk, drawn one at a time)
     const int nitems = SKM ? (sk_u1 > sk_u0 ? (sk_u1 - 1) / sk_upt - sk_u0 / sk_upt + 1 : 0)
+                     : DYN ? (nwork >> 3) + ((int)(blockIdx.x & 7) < (nwork & 7) ? 1 : 0)
                            : (nwork - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     if (nitems <= 0) return;                                       // (block-uniform: more blocks than pieces of work)
+    unsigned* const dcnt = DYN ? p.dyn_cnt + (blockIdx.x & 7) * 16 : nullptr;
+    const int dyn_last = nitems + (int)(gridDim.x >> 3) - 1;       // the last ticket any block of this label can draw
     auto decode = [&](int it) -> Tile {
         Tile t;
         t.gi = 0;
@@ -485,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         if constexpr (SKM) {
             work = (sk_u1 - 1) / sk_upt - it;                      // tile index (in the XCD-chunked order the labels already give)
         } else {
-            const int v = blockIdx.x + it * gridDim.x;
+            const int v = DYN ? (int)(blockIdx.x & 7) + 8 * it : (int)(blockIdx.x + it * gridDim.x);
             const int q = nwork >> 3, r = nwork & 7, xcd = v & 7;
             work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
         }
@@ -525,6 +546,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         return t;
     };
     int vcur = 0;                                                  // index of the current item in this block's list
+    if constexpr (DYN) {
+        // the first ticket, through LDS (A slot 2: the prologue stages slots 0 and 1 only)
+        if (tid == 0) lds_put(smem + 4 * HT, __hip_atomic_fetch_add(dcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        vcur = __builtin_amdgcn_readfirstlane((int)lds_get(smem + 4 * HT));
+        if (vcur >= nitems) {
+            if (tid == 0 && vcur == dyn_last) __hip_atomic_store(dcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     Tile cur = decode(vcur);
 
     f32x4 acc[8][4];
@@ -667,11 +698,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     bool landed0 = false;                     // K-tile 0 of the tile about to start has already been waited for
     int abuf = 0, bbuf = 0;                   // LDS slots of the current K-tile (A: 0..2, B: 0..1)
 
+    unsigned tk = 0, tk_here = 0;             // dynamic fetch: the ticket in flight (lane 0 of wave 0) and its copy once it has arrived
     for (;;) {
-    const int vnext = vcur + 1;
-    const bool more = vnext < nitems;
+    // (dynamic fetch: unknown until the ticket arrives at K-tile nk - 3 — both are only read from K-tile nk - 2 on)
+    int vnext = vcur + 1;
+    bool more = DYN ? false : vnext < nitems;
     const int nk = cur.nk;
-    const int t_stage_end = (roll && more) ? nk : nk - 2;       // loop iterations T < t_stage_end stage a K-tile (T + 2)
+    int t_stage_end = (roll && more) ? nk : nk - 2;             // loop iterations T < t_stage_end stage a K-tile (T + 2)
     const bool cto = tto(cur);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -756,13 +789,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         // ---- P0: quadrant (m0,n0)
         readB(bbuf, 0, b0);
         readA(abuf, 0, af);
+        unsigned mailv = 0;
+        if constexpr (DYN) {
+            // the ticket wave 0 left in the A1 half of the slot K-tile T-1 lived in (dead from its last read, group 1's P2(T-1),
+            // until P2(T) restages it)
+            if (T == nk - 3)
+                mailv = lds_get(smem + ((abuf == 0 ? 2 : abuf - 1) * 2 + 1) * HT);
+        }
         SEG_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DYN) {
+            if (T == nk - 3) {
+                vnext = __builtin_amdgcn_readfirstlane((int)mailv);
+                more = vnext < nitems;
+                if (more) t_stage_end = nk;
+            }
+        }
         MMA_QUAD(0, 0, af, b0);
         SEG_BARRIER();
         // ---- P1: quadrant (m0,n1)
         readB(bbuf, 1, b1);
+        if constexpr (DYN) {
+            // the ticket's wait, placed where nothing younger than it is in flight (hipcc waits vmcnt(0) for an ordinary result: it
+            // does not count the LDS-DMA issued from asm) — K-tile T+1's pieces, the only things older, are due a phase later anyway
+            // (copied by an asm move: a register hipcc never sees a load pending on — at the later store it would otherwise wait
+            // again, for the path that did not come through here)
+            if (T == nk - 4 && tid == 0) asm volatile("v_mov_b32 %0, %1" : "=v"(tk_here) : "v"(tk));
+        }
         stage2(T, 0);
         SEG_BARRIER();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -785,8 +839,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if constexpr (DYN) {
+            // draw the next ticket: the youngest vector-memory operation, behind the counted wait
+            if (T == nk - 5 && tid == 0) tk = __hip_atomic_fetch_add(dcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         SEG_BARRIER();
         MMA_QUAD(1, 0, af, b0);
+        if constexpr (DYN) {
+            if (T == nk - 4) {
+                // into the A1 half of THIS K-tile's slot: group 1's reads of it returned before its P2 compute segment, one barrier ago
+                if (tid == 0) lds_put(smem + (abuf * 2 + 1) * HT, tk_here);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
         SEG_BARRIER();
         abuf = abuf == 2 ? 0 : abuf + 1;
         bbuf ^= 1;
@@ -1232,7 +1297,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             }
     }   // epilogue variants
 
-    if (!more) break;
+    if (!more) {
+        if constexpr (DYN) {
+            if (tid == 0 && vnext == dyn_last) __hip_atomic_store(dcnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        break;
+    }
     vcur = vnext;
     cur = nxt;
     }   // persistent tile loop
@@ -1437,6 +1507,8 @@ struct GemmCtx {
                                    // (tools/bench_esm_gemm.py: 22.4 / 24.4 / 27.5 us against 21.8 / 22.7 / 27.5 at M = 1024): these launches are not
                                    // bound by the LDS-DMA drain
     int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
+    int dynamic = 0;               // 1 = plain 256x256 launches of more than one round draw their tiles (gemm256_kernel<DYN>): for GEMMs that
+                                   // run beside a collective's kernels (ranks of a multi-GPU job)
     int streamk = 1;               // 1 = stream-K where its cost model says it wins (M, N >= 256); 2 = wherever it is able (tests); 0 = off
     int last_cfg = 0;              // 128 / 512 + 1000 * split-K factor (+ 50000: stream-K, + 100000 * problems: grouped)
     float* ws = nullptr;           // scratch: [stream-K header: error word + flags][fp32 slabs of split-K / stream-K]
@@ -1447,7 +1519,8 @@ inline GemmCtx& ctx_of(void* h) { return h ? *static_cast<GemmCtx*>(h) : t_ctx; 
 
 constexpr int SK_MAX_BLOCKS = 2048;
 constexpr int SK_MAX_TILES = 8192;                                     // one counter line per TILE of a stream-K launch
-constexpr size_t SK_HDR_BYTES = 64 + (size_t)SK_MAX_TILES * 64;        // error word line + one 64-byte line per counter
+constexpr size_t DYN_CNT_OFF = 64 + (size_t)SK_MAX_TILES * 64;         // the dynamic fetch's 8 ticket counters, one line each
+constexpr size_t SK_HDR_BYTES = DYN_CNT_OFF + 8 * 64;                  // error word line + one 64-byte line per counter
 constexpr size_t SK_SLAB_BYTES = 2 * 262144;                           // per block: two pieces of 8 waves x 32 quads x 64 lanes x 16 B
 inline float* ws_slabs(const GemmCtx& c) { return c.ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(c.ws) + SK_HDR_BYTES) : nullptr; }
 inline size_t ws_slab_bytes(const GemmCtx& c) { return c.ws_bytes > SK_HDR_BYTES ? c.ws_bytes - SK_HDR_BYTES : 0; }
@@ -1493,6 +1566,8 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false, false, false, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr_set = true;
     }
@@ -1593,7 +1668,12 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
         // persistent: at most persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
         const int grid = grid256(c, nwork);
-        if (two_phase(c)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
+        if (c.dynamic && !two_phase(c) && c.ws && nwork > 256 && nk / p.splits >= 8) {
+            // 256 resident blocks (32 per XCD label) that draw their tiles
+            p.dyn_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c.ws) + DYN_CNT_OFF);
+            c.last_cfg += 1;                                       // 513: the 256x256 kernel drawing its tiles
+            hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false, false, false, true>), dim3(256), dim3(512), 163840, st, p);
+        } else if (two_phase(c)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
         else hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false>), dim3(grid), dim3(512), 163840, st, p);
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
@@ -1799,6 +1879,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v == 0 || v == 1, "gemm small3: %ld not in {0,1}", v);
         c.small3 = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_DYNAMIC:
+        MOLLY_CHECK(v == 0 || v == 1, "gemm dynamic: %ld not in {0,1}", v);
+        c.dynamic = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_SKINNY:
         MOLLY_CHECK(v == 0 || v == 1, "gemm skinny: %ld not in {0,1}", v);
         c.skinny = (int)v;
@@ -1881,6 +1965,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_STREAMK: return c.streamk;
     case MOLLY_GEMM_KEY_SKINNY: return c.skinny;
     case MOLLY_GEMM_KEY_SMALL3: return c.small3;
+    case MOLLY_GEMM_KEY_DYNAMIC: return c.dynamic;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

@@ -503,8 +503,9 @@ class OmicsOne(_MetaSafe):
         rt = self._runtime()
         rt.opt = opt
         mode = getattr(opt, "gemm_blocks_mode", None)
-        if mode is not None:
-            rt.gemm_ctx.set("persistent_blocks", mode)        # this model's GEMMs run beside the optimizer's collectives
+        if mode is not None:                                   # this model's GEMMs run beside the optimizer's collectives
+            rt.gemm_ctx.set("persistent_blocks", 256 if mode == "dyn" else mode)
+            rt.gemm_ctx.set("dynamic", 1 if mode == "dyn" else 0)
         if rt.full:
             # per-layer overlap: flat offsets of the optimizer's group ARE the LLM's parameter offsets
             opt.hooked = True

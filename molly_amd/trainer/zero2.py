@@ -241,15 +241,17 @@ class Zero2Optimizer:
             if self.world > 1 and flat_params.is_cuda:
                 # RCCL's collective kernels hold CUs for milliseconds.  The persistent GEMM launches exactly one block per
                 # CU, each owning 1/256 of the tiles: with a few CUs taken, the blocks that cannot start wait for a whole
-                # share to finish and the launch takes twice as long.  Blocks of THREE tiles (ceil(tiles / 3) of them, placed by
-                # the hardware dispatcher on whatever CUs are free) degrade by the CUs taken only and keep two of every three
-                # tile boundaries under the GEMM's rolling prefetch (measured on one GPU with a stand-in that holds CUs:
-                # DESIGN.md 5; not yet on 8 GPUs).  MOLLY_GEMM_PERSISTENT_MULTI = 256 keeps the one-block-per-CU launch,
-                # 0 = one block per tile, -t = t tiles per block (default -3).
+                # share to finish and the launch takes twice as long (-40 % with 16 CUs held).  Default at N > 1: the same 256
+                # resident blocks DRAW their tiles (MOLLY_GEMM_KEY_DYNAMIC; gemm.hip 'DYN'): a block that starts late takes
+                # what is left, so held CUs cost their share of the chip plus tile quantisation (-13 % / -24 % with 16 / 64 held;
+                # measured on one GPU with a stand-in that holds CUs: tools/diag/gemm_beside_hog.py; not yet
+                # on 8 GPUs).  It costs one exposed ticket per launch, +1.4 % of the N = 1 step, which is why one rank keeps the
+                # static walk.  MOLLY_GEMM_PERSISTENT_MULTI = dyn (default) | 256 static, one block per CU | 0 one block per
+                # tile | -t static blocks of t tiles (round 2's -3).
                 # The optimizer only RECORDS the wish: `OmicsOne.attach_optimizer` applies it to the GEMM context of the model
                 # this optimizer steps — no other model, evaluator or later test in the process inherits it.
-                mode = os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "-3")
-                self.gemm_blocks_mode = 256 if mode == "1" else int(mode)
+                mode = os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "dyn")
+                self.gemm_blocks_mode = "dyn" if mode == "dyn" else 256 if mode == "1" else int(mode)
             self.cstream = torch.cuda.Stream(device=dev, priority=-1)     # collectives first whenever CUs free up
             self._rs_done = [False] * len(self.buckets)
             self._ag_events = [None] * len(self.buckets)

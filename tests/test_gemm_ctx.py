@@ -79,4 +79,6 @@ def test_two_optimizers_in_one_process_do_not_leak_a_launch_mode(monkeypatch):
         ctx.set("persistent_blocks", o.gemm_blocks_mode)
     assert (c1.get("persistent_blocks"), c2.get("persistent_blocks")) == (-3, 0)
     assert L.query("molly_gemm_ctx_get", None, ops.GEMM_KEYS["persistent_blocks"]) == 256
+    c1.set("dynamic", 1)                                           # 'dyn', the N > 1 default: 256 resident blocks that draw their tiles
+    assert (c1.get("dynamic"), c2.get("dynamic"), L.query("molly_gemm_ctx_get", None, ops.GEMM_KEYS["dynamic"])) == (1, 0, 0)
     assert not hasattr(Z, "_GEMM_MODE_GLOBAL")

@@ -1,5 +1,23 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_prof_v3 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/r02_prof_v3.log 2>&1
-tail -1 gpurun_out/r02_prof_v3.log | cut -c1-200
-bash tools/collect_pmc.sh > gpurun_out/r02b_pmc.log 2>&1
-tail -45 gpurun_out/r02b_pmc.log | head -16
+# Round-3 profile collection (run on the GPU box through gpurun).  Kernel-trace statistics of the headline step, of BASELINE
+# config 3 (Molly-4B, B = 1, GA = 2) and of config 5 (8B prefill + decode); then the counter passes of the headline step, each
+# `--pmc` set in a run of its own with --kernel-trace only.  Summaries are written to profiles/r03_* and copied to gpurun_out/r03/.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="--no-cpu-baseline --no-secondary"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_step -- python3 $R/bench.py --steps 4 --warmup 2 $B > $O/prof_step.log 2>&1
+cp /tmp/p_step/*/*kernel_stats.csv $R/profiles/r03_bench_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3 -- python3 $R/bench.py --steps 3 --warmup 2 $B --model 4b --batch 1 --seq 3072 --micro "dna:512,rna:512,protein:512;dna:512,rna:512,protein:512" > $O/prof_c3.log 2>&1
+cp /tmp/p_c3/*/*kernel_stats.csv $R/profiles/r03_c3_4b_b1_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -- python3 $R/bench.py --secondary-worker c5 > $O/prof_c5.log 2>&1
+cp /tmp/p_c5/*/*kernel_stats.csv $R/profiles/r03_c5_8b_generate_kernel_stats.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_sq_a -- python3 $R/bench.py --steps 1 --warmup 1 $B > $O/pmc_sq_a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d /tmp/p_sq_b -- python3 $R/bench.py --steps 1 --warmup 1 $B > $O/pmc_sq_b.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -- python3 $R/bench.py --steps 1 --warmup 1 $B > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -- python3 $R/bench.py --steps 1 --warmup 1 $B > $O/pmc_w.log 2>&1
+cd $R
+python tools/pmc_sq_summary.py r03 "round 3: GEMM contexts, stream-K where its cost model wins, decode-row kernel" /tmp/p_sq_a /tmp/p_sq_b | head -30
+python tools/pmc_hbm_traffic.py /tmp/p_f /tmp/p_w r03 | head -30
+cp profiles/r03_* $O/ 2>/dev/null
+ls -la $O | head -40

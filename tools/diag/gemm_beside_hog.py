@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The 256x256 GEMM's launch shapes beside a kernel that holds some CUs (what a collective's kernel does at N > 1): one block per
-CU (persistent, 256), one block per tile (0), blocks of at most t tiles in whole rounds (-t).  The hog (molly_probe_hog) owns
+CU walking a static list (persistent, 256), one block per tile (0), blocks of at most t tiles in whole rounds (-t), and 256 blocks
+that DRAW their tiles (dyn: MOLLY_GEMM_KEY_DYNAMIC).  The hog (molly_probe_hog) owns
 `--cus` CUs for the whole measurement on a second stream; the GEMM is timed on the main stream.
     python tools/diag/gemm_beside_hog.py [--cus 0 16 32 64]"""
 import argparse
@@ -17,44 +18,47 @@ from molly_amd._lib import lib  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cus", type=int, nargs="+", default=[0, 16, 32, 64])
-    ap.add_argument("--modes", type=int, nargs="+", default=[256, 0, -2, -3, -4])
+    ap.add_argument("--modes", nargs="+", default=["256", "0", "-3", "dyn"])
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
     shapes = [("qkv fwd", "nt", 16384, 4096, 2048), ("gate|up fwd", "nt", 16384, 12288, 2048), ("down dgrad", "nn", 16384, 6144, 2048),
               ("gate|up dgrad", "nn", 16384, 2048, 12288), ("8b qkv B=1 (stream-K)", "nt", 4096, 6144, 4096)]
+    ctx = ops.GemmContext()
+    ctx.ensure_workspace(1 << 28)
     side = torch.cuda.Stream()
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
     print(f"{'shape':22s} {'CUs held':>8s} " + " ".join(f"{('mode ' + str(m)):>10s}" for m in a.modes) + "   (TF/s)")
-    for name, form, M, N, K in shapes:
-        x = rnd(M, K)
-        w = rnd(N, K) if form == "nt" else rnd(K, N)
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-        run = (lambda: ops.gemm_nt(x, w, out=out)) if form == "nt" else (lambda: ops.gemm(x, w, out=out, b_kmajor=True))
-        for cus in a.cus:
-            row = []
-            for mode in a.modes:
-                lib().call("molly_gemm_set_persistent_blocks", mode)
-                best = 1e9
-                for _ in range(3):
-                    run()
-                    torch.cuda.synchronize()
-                    if cus:
-                        with torch.cuda.stream(side):
-                            lib().call("molly_probe_hog", side.cuda_stream, cus, 20000, sink)      # 20 ms: outlives the timed launches
-                        torch.cuda._sleep(200000)                                                # let the hog's blocks land first
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(5):
-                        run()
-                    e1.record()
-                    e1.synchronize()
-                    best = min(best, e0.elapsed_time(e1) / 5)
-                    torch.cuda.synchronize()
-                row.append(2.0 * M * N * K / best / 1e9)
-            print(f"{name:22s} {cus:8d} " + " ".join(f"{v:10.0f}" for v in row))
-    lib().call("molly_gemm_set_persistent_blocks", 256)
+    with ops.use_gemm_context(ctx):
+      for name, form, M, N, K in shapes:
+          x = rnd(M, K)
+          w = rnd(N, K) if form == "nt" else rnd(K, N)
+          out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+          run = (lambda: ops.gemm_nt(x, w, out=out)) if form == "nt" else (lambda: ops.gemm(x, w, out=out, b_kmajor=True))
+          for cus in a.cus:
+              row = []
+              for mode in a.modes:
+                  ctx.set("persistent_blocks", 256 if mode == "dyn" else int(mode))
+                  ctx.set("dynamic", 1 if mode == "dyn" else 0)
+                  best = 1e9
+                  for _ in range(3):
+                      run()
+                      torch.cuda.synchronize()
+                      if cus:
+                          with torch.cuda.stream(side):
+                              lib().call("molly_probe_hog", side.cuda_stream, cus, 20000, sink)      # 20 ms: outlives the timed launches
+                          torch.cuda._sleep(200000)                                                # let the hog's blocks land first
+                      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                      e0.record()
+                      for _ in range(5):
+                          run()
+                      e1.record()
+                      e1.synchronize()
+                      best = min(best, e0.elapsed_time(e1) / 5)
+                      torch.cuda.synchronize()
+                  row.append(2.0 * M * N * K / best / 1e9)
+              print(f"{name:22s} {cus:8d} " + " ".join(f"{v:10.0f}" for v in row))
 
 
 if __name__ == "__main__":
