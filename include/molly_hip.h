@@ -108,6 +108,8 @@ enum {
                                              (one ticket counter per XCD label in the workspace header; the next ticket fetched five
                                              K-tiles ahead, so the rolling prefetch never waits for it) — for GEMMs that share the chip
                                              with a collective's kernels; same results as the static walk.  0 (default): static walk */
+    MOLLY_GEMM_KEY_SMALL_SPLIT = 11,      /* 1 (default): a grid of at most 256 128x128 blocks with a long contraction (encoder ffn2 at one sample
+                                             per GPU) is priced for split-K with slices down to 4 K-tiles; 0: round 2's rule (A/B) */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
@@ -293,6 +295,16 @@ int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, co
                    const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo, const int* kv_hi,
                    int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv, int ldo, int lddo,
                    int lddq, int lddk, int lddv, float scale, int causal);
+/* the same with scratch: when the dK / dV grid over (kv head, key block) does not fill the chip (one sample per GPU: B = 1 of
+ * scripts/train/examples/run_train_4B_z2_b1.sh:29 — 8 kv heads x T/128 key blocks = 192 blocks for 512 slots) the two passes run one
+ * block per QUERY head, leave fp32 accumulator images in `workspace`, and a third launch adds a group's images in head order and
+ * writes the rows: still no atomics, still bitwise reproducible.  molly_attn_bwd_workspace: the floats that takes (0 = the split
+ * does not apply to these sizes); a smaller or NULL workspace runs the unsplit passes. */
+int molly_attn_bwd_workspace(int B, int T, int n_heads, int n_kv_heads, int head_dim);
+int molly_attn_bwd_ws(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                      const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo, const int* kv_hi,
+                      int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv, int ldo, int lddo,
+                      int lddq, int lddk, int lddv, float scale, int causal, float* workspace, long workspace_floats);
 
 /* single-query attention over a KV cache — the decode step of HF `generate` with DynamicCache that the reference runs
  * for inference (reference src/model/omics_one.py:220-232).  q [B, ldq] (heads at column h*hd), out [B, n_heads*hd]; k/v

@@ -442,6 +442,7 @@ struct AttnBwdArgs {
     int T, nh, nkv, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float scale, scale_log2;
     int causal;
+    float* part;               // head-split dK/dV pass: per-(block, query head) accumulator images, register order (see SPLIT)
 };
 
 template <int HD>
@@ -569,7 +570,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 // MODE 0: dK and dV in one pass (256 accumulator registers -> one wave per SIMD); MODE 1: dV only (S -> P -> dV);
 // MODE 2: dK only (S, dP -> dS -> dK).  The two single-output passes recompute S (+25 % MFMAs in total) but fit two
 // waves per SIMD, which is what the matrix-pipe / VALU overlap needs — measured faster than MODE 0 at hd 128.
-template <int HD, int MODE>
+// SPLIT: one block per QUERY head of the group instead of one per kv head.  At one sample per GPU (BASELINE configs 3 / 4:
+// B = 1, 8 kv heads, T = 3072 / 4096) the grid over (kv head, key block) is 192-256 blocks for 512 slots, and the block of key
+// block 0 walks group x T/64 = 192-256 query tiles alone: the launch is as long as that one block (346 us against 98 for the
+// forward).  Split, there are group x as many blocks, each 1/group as long; a block leaves its accumulators, unscaled fp32 in
+// register order (16 bytes per lane, coalesced), in `part`, and attn_dkv_reduce_kernel adds the group's images in head order
+// (fixed: bitwise reproducible, no atomics) and writes the bf16 rows.
+template <int HD, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -581,8 +588,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // causal: key block 0 sees every query tile (heaviest) -> slot order = key-block order already is heaviest-first
-    const int kb = blockIdx.y, kvh = blockIdx.x % p.nkv, b = blockIdx.x / p.nkv;
     const int group = p.nh / p.nkv;
+    const int bx = SPLIT ? blockIdx.x / group : blockIdx.x, g0 = SPLIT ? blockIdx.x % group : 0;
+    const int kb = blockIdx.y, kvh = bx % p.nkv, b = bx / p.nkv;
     const int T = p.T;
     const int lo = p.kv_lo ? p.kv_lo[b] : 0;
     const int hi = p.kv_hi ? p.kv_hi[b] : T;
@@ -613,10 +621,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     const int nqt = (T + BKV - 1) / BKV;
     const int qt_first = p.causal ? (kb * 128) / BKV : 0;
     const int n_tiles = nqt > qt_first ? nqt - qt_first : 0;
-    const int total = n_tiles * group;                           // iteration it -> (head g, tile qt_first + j)
+    const int total = SPLIT ? n_tiles : n_tiles * group;         // iteration it -> (head g, tile qt_first + j)
 
     auto stage = [&](int it, int stg) {
-        const int g = it / n_tiles, qt = qt_first + it % n_tiles;
+        const int g = SPLIT ? g0 : it / n_tiles, qt = qt_first + it % n_tiles;
         const int head = kvh * group + g;
         const bf16_t* Qb = p.Q + (size_t)b * T * p.ldq + head * HD;
         const bf16_t* Db = p.dO + (size_t)b * T * p.ldo + head * HD;
@@ -710,11 +718,59 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
         __syncthreads();
         cur ^= 1;
     }
-    {
+    if constexpr (SPLIT) {
+        // image [(b, kvh, kb)][g][wave][d][g4][lane] f32x4; the dV pass owns the first half of `part`, the dK pass the second
+        const size_t nimg = (size_t)gridDim.x * gridDim.y;
+        const size_t img = ((size_t)bx * gridDim.y + kb) * group + g0 + (DO_DK ? nimg : 0);
+        float* dst = p.part + img * (4 * ND * 16 * 64) + (size_t)wave * (ND * 16 * 64) + lane * 4;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x16& a = DO_DK ? dk[d] : dv[d];
+                *reinterpret_cast<f32x4*>(dst + (d * 4 + g4) * 256) = f32x4{a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]};
+            }
+    } else {
         bf16_t* slab = reinterpret_cast<bf16_t*>(smem_raw) + wave * 32 * (HD + 8);
         const int key0w = key - (lane & 31);                                           // the wave's first key
         if (DO_DK) store_rows<HD, ND>(slab, dk, p.scale, p.dK + ((size_t)b * T + key0w) * p.lddk + kvh * HD, p.lddk, T - key0w, lane);
         if (DO_DV) store_rows<HD, ND>(slab, dv, 1.0f, p.dV + ((size_t)b * T + key0w) * p.lddv + kvh * HD, p.lddv, T - key0w, lane);
+    }
+}
+
+// the head-split pass's second half: block = (batch, kv head, key block) like the unsplit dK/dV kernel, wave = its 32 keys; adds the
+// group's images in head order, then the same row store (dK scaled, dV not)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
+    constexpr int ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) bf16_t slab_all[4 * 32 * (HD + 8)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = blockIdx.y, kvh = blockIdx.x % p.nkv, b = blockIdx.x / p.nkv;
+    const int group = p.nh / p.nkv;
+    const size_t nimg = (size_t)gridDim.x * group * gridDim.y;
+    const int key0w = kb * 128 + wave * 32;
+    if (key0w >= p.T) return;
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {                    // 0: dV, 1: dK
+        const float* src = p.part + (((size_t)blockIdx.x * gridDim.y + kb) * group + (which ? nimg : 0)) * (4 * ND * 16 * 64) +
+                           (size_t)wave * (ND * 16 * 64) + lane * 4;
+        f32x16 acc[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(src + (d * 4 + g4) * 256);
+                for (int g = 1; g < group; ++g) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(src + (size_t)g * (4 * ND * 16 * 64) + (d * 4 + g4) * 256);
+                    v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+                }
+                acc[d][4 * g4] = v[0]; acc[d][4 * g4 + 1] = v[1]; acc[d][4 * g4 + 2] = v[2]; acc[d][4 * g4 + 3] = v[3];
+            }
+        bf16_t* slab = slab_all + wave * 32 * (HD + 8);
+        if (which) store_rows<HD, ND>(slab, acc, p.scale, p.dK + ((size_t)b * p.T + key0w) * p.lddk + kvh * HD, p.lddk, p.T - key0w, lane);
+        else store_rows<HD, ND>(slab, acc, 1.0f, p.dV + ((size_t)b * p.T + key0w) * p.lddv + kvh * HD, p.lddv, p.T - key0w, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the slab is the wave's own: its reads are done before the next round's writes
     }
 }
 
@@ -761,10 +817,23 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     return 0;
 }
 
-extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+// floats of scratch with which molly_attn_bwd_ws runs the dK / dV passes split by query head (0: the split does not apply —
+// the grid over (kv head, key block) already fills the chip, or there is one query head per kv head, or head_dim != 128)
+extern "C" int molly_attn_bwd_workspace(int B, int T, int n_heads, int n_kv_heads, int head_dim) {
+    if (head_dim != 128 || n_kv_heads <= 0 || n_heads % n_kv_heads != 0 || n_heads == n_kv_heads || n_heads / n_kv_heads > 8) return 0;
+    const long nkb = cdiv(T, 128);
+    // (two blocks per CU: the split pays up to one round of the 512 slots — B = 2 x T = 4096: 1,373 -> 1,162 us; at 768 blocks it loses;
+    // MOLLY_ATTN_SPLIT_MAX moves the bound for measurements: tools/bench_attn_b1.py)
+    static const long max_blocks = [] { const char* e = getenv("MOLLY_ATTN_SPLIT_MAX"); return e ? atol(e) : 513L; }();
+    if ((long)n_kv_heads * B * nkb >= max_blocks) return 0;
+    return (int)(2L * n_heads * B * nkb * (4 * 4 * 16 * 64));          // dV and dK images: one per (query head, key block); < 2^28
+}
+
+static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
                               const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo,
                               const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk,
-                              int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal) {
+                              int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal,
+                              float* workspace, long workspace_floats) {
     MOLLY_ENTER();
     MOLLY_CHECK(head_dim == 128 || head_dim == 64, "attn_bwd: head_dim=%d not built (64 and 128 are)", head_dim);
     MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_bwd: n_heads %% n_kv_heads != 0");
@@ -775,7 +844,7 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
     hipStream_t st = (hipStream_t)stream;
     AttnBwdArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, (const bf16_t*)O, lse2, delta_ws,
                   (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, kv_lo, kv_hi, T, n_heads, n_kv_heads, ldq, ldk, ldv, ldo,
-                  lddq, lddk, lddv, scale, scale * LOG2E, causal};
+                  lddq, lddk, lddv, scale, scale * LOG2E, causal, nullptr};
     const size_t lds_dq = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
     const size_t lds_dkv = lds_dq + 2 * 128 * sizeof(float);
     static bool attr_set = false;
@@ -786,6 +855,8 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         attr_set = true;
     }
     dim3 gq(n_heads * B, cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));
@@ -794,7 +865,14 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
     static const bool one_pass = [] { const char* e = getenv("MOLLY_ATTN_DKV_ONE_PASS"); return e && atoi(e) != 0; }();
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
-        if (one_pass) {
+        const long need = molly_attn_bwd_workspace(B, T, n_heads, n_kv_heads, head_dim);
+        if (!one_pass && need > 0 && workspace && workspace_floats >= need) {
+            p.part = workspace;
+            const dim3 gs(n_heads * B, cdiv(T, 128));
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, p);
+            hipLaunchKernelGGL(attn_dkv_reduce_kernel<128>, gk, dim3(256), 0, st, p);
+        } else if (one_pass) {
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk, dim3(256), lds_dkv, st, p);
         } else {
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk, dim3(256), lds_dkv, st, p);
@@ -806,4 +884,20 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
     }
     MOLLY_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                              const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo,
+                              const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk,
+                              int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal) {
+    return attn_bwd_impl(stream, Q, K, V, O, dO, lse2, delta_ws, dQ, dK, dV, kv_lo, kv_hi, B, T, n_heads, n_kv_heads, head_dim, ldq, ldk,
+                         ldv, ldo, lddo, lddq, lddk, lddv, scale, causal, nullptr, 0);
+}
+extern "C" int molly_attn_bwd_ws(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                 const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo,
+                                 const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk,
+                                 int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal,
+                                 float* workspace, long workspace_floats) {
+    return attn_bwd_impl(stream, Q, K, V, O, dO, lse2, delta_ws, dQ, dK, dV, kv_lo, kv_hi, B, T, n_heads, n_kv_heads, head_dim, ldq, ldk,
+                         ldv, ldo, lddo, lddq, lddk, lddv, scale, causal, workspace, workspace_floats);
 }

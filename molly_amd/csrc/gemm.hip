@@ -1507,6 +1507,7 @@ struct GemmCtx {
                                    // (tools/bench_esm_gemm.py: 22.4 / 24.4 / 27.5 us against 21.8 / 22.7 / 27.5 at M = 1024): these launches are not
                                    // bound by the LDS-DMA drain
     int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
+    int small_split = 1;           // 1 = small grids with long contractions priced for split-K (see launch_cfg); 0 = round 2's rule (A/B)
     int dynamic = 0;               // 1 = plain 256x256 launches of more than one round draw their tiles (gemm256_kernel<DYN>): for GEMMs that
                                    // run beside a collective's kernels (ranks of a multi-GPU job)
     int streamk = 1;               // 1 = stream-K where its cost model says it wins (M, N >= 256); 2 = wherever it is able (tests); 0 = off
@@ -1606,6 +1607,19 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
                 if (skinny && eff(t256 * sp) > best_score + 1e-9) { best_score = eff(t256 * sp); best = -sp; }
             }
             if (best < 0) best = skinny && best_score > eff(t128) ? -best : 0;   // nothing fills the chip: the fullest
+            // A SMALL grid with a long contraction (the encoders' ffn2 at one sample per GPU: 512 x 1280 x 5120 = 40 blocks of
+            // 128x128 walking 80 K-tiles each: 105 us for 6.7 GFLOP): no slice count reaches the 200 work items the rule above
+            // wants, so it fell through to the 128x128 kernel.  Priced instead, with the constants of the stream-K model below
+            // (conservative for split-K: they overestimate it by ~15 % on the shapes measured): slices down to 4 K-tiles.
+            if (best == 0 && !skinny && c.small_split && p.M >= 256 && p.N >= 256 && t128 <= 256) {
+                double best_t = 0.9 * (5.0 + 1.25 * nk);
+                for (int sp : {2, 3, 4, 6, 8, 12, 16, 24, 32}) {
+                    if (nk / sp < 4) break;
+                    if ((size_t)sp * p.M * p.N * sizeof(float) > ws_slab_bytes(c)) break;
+                    const double t = 12.0 + cdiv(t256 * sp, 256) * (6.0 + 1.4 * nk / sp) + 4.0 + 8.0 * p.M * p.N * sp / 9e6;
+                    if (t < best_t) { best_t = t; best = sp; }
+                }
+            }
             // the slab path applies bias/GELU/residual in its reduce kernel (not for the transposed-output form)
             if (best && (plain_epilogue || !TO) && p.N % 4 == 0 && ((p.M >= 256 && p.N >= 256) || skinny)) {
                 force_tile = 512;
@@ -1883,6 +1897,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v == 0 || v == 1, "gemm dynamic: %ld not in {0,1}", v);
         c.dynamic = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_SMALL_SPLIT:
+        MOLLY_CHECK(v == 0 || v == 1, "gemm small_split: %ld not in {0,1}", v);
+        c.small_split = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_SKINNY:
         MOLLY_CHECK(v == 0 || v == 1, "gemm skinny: %ld not in {0,1}", v);
         c.skinny = (int)v;
@@ -1966,6 +1984,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_SKINNY: return c.skinny;
     case MOLLY_GEMM_KEY_SMALL3: return c.small3;
     case MOLLY_GEMM_KEY_DYNAMIC: return c.dynamic;
+    case MOLLY_GEMM_KEY_SMALL_SPLIT: return c.small_split;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

@@ -57,7 +57,7 @@ def _chk(t: torch.Tensor, dtype=None, name="tensor"):
 # thread's default context of the library is used (tools, kernel tests).  A model owns one (OmicsOne.prepare), so an optimizer
 # that wants another launch shape at N > 1 changes ITS model's context and nothing else in the process.
 GEMM_KEYS = {"persistent_blocks": 1, "schedule": 2, "force_tile": 3, "group_m": 4, "small_grid_tile": 5, "min_ktiles": 6,
-             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "last_config": 100}
+             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "small_split": 11, "last_config": 100}
 STREAMK_SCRATCH = (64 + 8192 * 64 + 8 * 64) + 256 * 2 * 262144   # header (a counter line per tile) + two 256 KiB accumulator images per block of a 256-block launch
 
 
@@ -377,12 +377,17 @@ def attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, kv_lo=None, kv_hi=None, 
     return out, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, causal, dq, dk, dv, kv_lo=None, kv_hi=None, delta_ws=None):
+def attn_bwd_workspace(B, T, nh, nkv, hd) -> int:
+    """fp32 elements of scratch with which `attn_bwd(ws=...)` splits the dK / dV passes by query head (0: not at these sizes)."""
+    return lib().query("molly_attn_bwd_workspace", B, T, nh, nkv, hd)
+
+
+def attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, causal, dq, dk, dv, kv_lo=None, kv_hi=None, delta_ws=None, ws=None):
     if delta_ws is None:
         delta_ws = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
-    lib().call("molly_attn_bwd", _stream(), q, k, v, o, do, lse, delta_ws, dq, dk, dv, kv_lo, kv_hi, B, T, nh, nkv, hd,
+    lib().call("molly_attn_bwd_ws", _stream(), q, k, v, o, do, lse, delta_ws, dq, dk, dv, kv_lo, kv_hi, B, T, nh, nkv, hd,
                q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0),
-               float(scale), int(causal))
+               float(scale), int(causal), ws, ws.numel() if ws is not None else 0)
     return dq, dk, dv
 
 

@@ -141,6 +141,9 @@ class Qwen3Engine:
             self.d_act = e(M, ff); self.d_gu = e(M, 2 * ff)
             self.d_attn = e(M, self.nh * self.hd); self.d_qkv = e(M, self.nqkv); self.d_qk = e(M, self.nqk)
             self.delta = e(B, self.nh, T, dt=torch.float32)
+            # one sample per GPU: the dK / dV passes of the attention backward split by query head (attention.hip SPLIT)
+            n_ws = ops.attn_bwd_workspace(B, T, self.nh, self.nkv, self.hd) if os.environ.get("MOLLY_ATTN_DKV_SPLIT", "1") != "0" else 0
+            self.attn_ws = e(n_ws, dt=torch.float32) if n_ws else None
             self.hn_s = e(M, h); self.dh_s = e(M, h)                       # compacted scored rows (head GEMMs)
             self.tT = e(max(h, self.nh * self.hd) * M)                     # transposed narrow operand of the wgrad GEMMs
             # the four weight-gradient GEMMs of a layer as ONE grouped launch (no split-K, no reduce launches) when their
@@ -441,7 +444,7 @@ class Qwen3Engine:
                 self._wgrad_layer(1, dx2, a["attn"], g["o"], accumulate)
             ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
-                         self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta)
+                         self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta, ws=self.attn_ws)
             ops.norm_rope_bwd(a["qkv"], self.d_qk, self.d_qkv, self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos,
                               self.sin, None if defer else gw(g, "qn"), None if defer else gw(g, "kn"), eps=cfg.rms_norm_eps,
                               dw_accumulate=acc_n, workspace=self.ws_qk[i] if defer else self.ws)

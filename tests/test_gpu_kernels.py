@@ -297,6 +297,46 @@ def test_attn_bwd(hd, nh, nkv, T, causal, ragged):
         _close(dv, g(vr), 4e-2, 2e-2, "dV")
 
 
+@pytest.mark.parametrize("nh,nkv,T,ragged", [(32, 8, 1024, False), (16, 8, 2048, True), (8, 2, 1000, True), (32, 8, 3072, False)])
+def test_attn_bwd_split_by_query_head(nh, nkv, T, ragged):
+    """One sample per GPU (BASELINE configs 3 / 4, scripts/train/examples/run_train_4B_z2_b1.sh:29): the dK / dV passes run one block
+    per QUERY head and a third launch adds the group's fp32 images in head order.  Against the unsplit passes (same products, another
+    order of the fp32 sums over heads: equal to bf16 rounding of near-ties), against the fp32 reference, and twice (bitwise equal)."""
+    B, hd = 1, 128
+    M = B * T
+    n_ws = ops.attn_bwd_workspace(B, T, nh, nkv, hd)
+    assert n_ws == 2 * nh * B * ((T + 127) // 128) * 16384
+    assert ops.attn_bwd_workspace(8, 2048, 16, 8, hd) == 0          # the headline's grid fills the chip: no split
+    assert ops.attn_bwd_workspace(1, 512, 20, 20, 64) == 0          # one query head per kv head / hd 64: nothing to split
+    qkv = _rand(M, (nh + 2 * nkv) * hd, seed=40, scale=0.7).to(BF)
+    q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+    lo = hi = None
+    if ragged:
+        lo = torch.tensor([3], device=DEV, dtype=torch.int32)
+        hi = torch.tensor([T - 41], device=DEV, dtype=torch.int32)
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, True, lo, hi)
+    do = _rand(M, nh * hd, seed=41).to(BF)
+    outs = []
+    for ws in (None, torch.empty(n_ws, dtype=torch.float32, device=DEV), torch.full((n_ws,), float("nan"), dtype=torch.float32, device=DEV)):
+        dqkv = torch.zeros_like(qkv)
+        dq, dk, dv = dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd], dqkv[:, (nh + nkv) * hd:]
+        ops.attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, True, dq, dk, dv, lo, hi, ws=ws)
+        outs.append(dqkv)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], outs[2])                            # reproducible, and every image it reads it wrote (NaN-filled scratch)
+    assert torch.equal(outs[0][:, :nh * hd], outs[1][:, :nh * hd])  # dQ is not touched by the split
+    d = (outs[0].float() - outs[1].float()).abs().max().item()
+    ref = outs[0].float().abs().max().item()
+    assert d <= 2e-2 * ref, (d, ref)
+    if not ragged and T <= 1024:
+        qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+        ro, rl = _attn_ref(qr, kr, vr, B, T, nh, nkv, hd, scale, True, None, None)
+        (ro * do.float()).sum().backward()
+        _close(outs[1][:, nh * hd:(nh + nkv) * hd], kr.grad, 4e-2, 2e-2, "dK (split)")
+        _close(outs[1][:, (nh + nkv) * hd:], vr.grad, 4e-2, 2e-2, "dV (split)")
+
+
 def test_ce_fwd_bwd_matches_torch():
     rows, V = 96, 1024
     logits = _rand(rows, V, seed=32, scale=2.0).to(BF)
