@@ -110,7 +110,11 @@ enum {
                                              with a collective's kernels; same results as the static walk.  0 (default): static walk */
     MOLLY_GEMM_KEY_SMALL_SPLIT = 11,      /* 1 (default): a grid of at most 256 128x128 blocks with a long contraction (encoder ffn2 at one sample
                                              per GPU) is priced for split-K with slices down to 4 K-tiles; 0: round 2's rule (A/B) */
-    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
+    MOLLY_GEMM_KEY_ROWS_TILED = 12,       /* 1 (default): forward GEMMs with M <= 64 rows that the weight-streaming kernel does not take (M > 16 on
+                                             matrices beyond 64 MB: Qwen3-8B gate|up / down at batch 32) run on the tiled decode-row kernel —
+                                             x and W through LDS-DMA in whole lines, x once per workgroup and K-tile, K split over the chip;
+                                             0: split-K through the 256x256 kernel (round 2's path; A/B) */
+    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
 int molly_gemm_ctx_create(void** out);

@@ -1447,6 +1447,133 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs p) {
     }
 }
 
+// ================================================================================================
+// Decode rows, tiled: y[M <= 64, N] = x W^T for the 100-200 MB matrices at M = 17..64 (Qwen3-8B gate|up / down at the batch 32 of
+// BASELINE config 5), where the register-streaming kernel above loses: its x fragments enter through the same 64-byte request
+// path as W (2 x-bytes per W-byte at M = 32, NT = 1).  Here both operands go HBM / L2 -> LDS by LDS-DMA in whole 128-byte lines
+// (8 rows x 128 B per wave-instruction), x ONCE per workgroup and K-tile: a tile is [16 MT rows of x | 128 rows of W] x 64 k =
+// 4 + 16 KB (MT = 2), so x adds a quarter to the bytes the memory path carries instead of doubling them — the 128x128 kernel
+// reaches 5 TB/s on the 1.2 GB lm_head this way while staging 128 rows of x per tile, 96 of them padding.
+//   * 4 waves; wave w owns 32 of the tile's 128 output columns for all 16 MT rows (MT x 2 accumulator tiles);
+//   * NSTAGE-deep LDS ring (20 KB per stage at MT = 2: 4 stages, two workgroups per CU = 120 KB in flight per CU), ONE barrier
+//     per K-tile, counted vmcnt: the stage issued at K-tile t lands in the slot K-tile t-1 was read from;
+//   * K split over `splits` workgroups per column tile so that >= 2 workgroups per CU exist whatever N is; partial tiles go to
+//     fp32 slabs [split][M][N] and splitk_reduce_kernel applies the epilogue; splits == 1 stores directly.  (Stream-K's hand-off
+//     inside the launch — images in register order, a ticket per column tile, the last slice adds them in slice order — was
+//     built and measured 1-3 us SLOWER per launch than the reduce launch it saves: 19.7 / 16.9 / 29.1 against 17.8 / 14.2 / 28.0 us
+//     on Qwen3-8B qkv / o / down at M = 32; a dependent launch in the same stream overlaps the tail the hand-off serialises.)
+// ================================================================================================
+struct RowsArgs {
+    const bf16_t* X; const bf16_t* W; void* C; const bf16_t* bias; const bf16_t* res; float* ws;
+    int M, N, K, ldx, ldw, ldc, ldres, flags, tiles_n, splits;
+};
+
+template <int MT, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
+    constexpr int BM = 16 * MT, BK = 64, A_ELEMS = BM * BK, B_ELEMS = 128 * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int NLOAD = 4 + BM * BK * 2 / 1024 / 4;          // LDS-DMA instructions per wave per stage: 4 of W, 1-2 of x
+    static_assert(MT == 2 || MT == 4, "16 MT rows: 32 or 64");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);          // [stage][x tile | W tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = blockIdx.x % p.tiles_n, sp = blockIdx.x / p.tiles_n;
+    const int n0 = tn * 128;
+    const int nk_all = p.K / BK;
+    const int kt0 = (int)((long)nk_all * sp / p.splits), nk = (int)((long)nk_all * (sp + 1) / p.splits) - kt0;
+
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int t, int slot) {
+        bf16_t* dst = smem + slot * STAGE;
+        stage_kc<BM, 4, BK, true>(p.X, p.ldx, 0, p.M, (kt0 + t) * BK, dst, wave, lane);
+        stage_kc<128, 4, BK, true>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane);
+    };
+    // s_waitcnt vmcnt(k * NLOAD): everything but the k youngest stages has landed (k = 0 .. NSTAGE - 2)
+    auto wait_younger = [&](int k) {
+        if (k >= 2 && NSTAGE >= 4) { if constexpr (NLOAD == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        else if (k == 1) { if constexpr (NLOAD == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) stage(s, s);
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+        wait_younger(min(NSTAGE - 2, nk - 1 - t));
+        __builtin_amdgcn_s_barrier();
+        // slot of K-tile t-1: every wave has passed the barrier, so its reads (consumed before that wave's MFMAs) are over
+        if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
+        const bf16_t* sA = smem + slot * STAGE;
+        const bf16_t* sB = sA + A_ELEMS;
+        bf16x8 xf[2][MT], wf[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[kk][i] = frag_kc<BK>(sA, i * 16 + fr, kk * 4 + fq);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[kk][j] = frag_kc<BK>(sB, wave * 32 + j * 16 + fr, kk * 4 + fq);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
+        slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+    }
+    // ---- lane owns C[m = 16 i + fr][n = n0 + 32 wave + 16 j + 4 fq + 0..3]
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wave * 32 + j * 16 + fq * 4;
+            if (n >= p.N) continue;                       // N % 4 == 0 (host check)
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.splits > 1) {
+                *reinterpret_cast<f32x4*>(p.ws + ((size_t)sp * p.M + m) * p.N + n) = f32x4{v[0], v[1], v[2], v[3]};
+                continue;
+            }
+            if (p.flags & MOLLY_GEMM_BIAS) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+                v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+            }
+            if (p.flags & MOLLY_GEMM_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (p.flags & MOLLY_GEMM_RESIDUAL) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(p.res + (size_t)m * p.ldres + n);
+                v[0] += bflo(b[0]); v[1] += bfhi(b[0]); v[2] += bflo(b[1]); v[3] += bfhi(b[1]);
+            }
+            if (p.flags & MOLLY_GEMM_OUT_F32) {
+                float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+                if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(c);
+                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                }
+                *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+                if (p.flags & MOLLY_GEMM_ACCUMULATE) {
+                    const u32x2 o = *reinterpret_cast<const u32x2*>(c);
+                    v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+                }
+                *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            }
+        }
+    }
+}
+
 // out[m,n] (+)= sum_s slab[s][m][n]   (split-K combine; 4 elements per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long MN, int M, int N,
                                                             void* C, int ldc, int out_f32, int accumulate,
@@ -1506,6 +1633,8 @@ struct GemmCtx {
     int small3 = 0;                // 1 = 128x128 grids of at most one tile per CU on the 3-stage ring; 0 (default): the 2-stage loop — measured equal
                                    // (tools/bench_esm_gemm.py: 22.4 / 24.4 / 27.5 us against 21.8 / 22.7 / 27.5 at M = 1024): these launches are not
                                    // bound by the LDS-DMA drain
+    int rows_tiled = 1;            // 1 = M <= 64 forward GEMMs the weight-streaming kernel does not take run on the tiled decode-row kernel; 0 = split-K
+                                   // through the 256x256 kernel (round 2's path; A/B)
     int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
     int small_split = 1;           // 1 = small grids with long contractions priced for split-K (see launch_cfg); 0 = round 2's rule (A/B)
     int dynamic = 0;               // 1 = plain 256x256 launches of more than one round draw their tiles (gemm256_kernel<DYN>): for GEMMs that
@@ -1758,6 +1887,7 @@ int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, 
     // the tile kernel (3.1-3.6 TB/s there, 5.0 on the 1.2 GB lm_head): x enters through the same 64-byte request path as W, and
     // at 32 rows it is the larger stream unless a wave keeps 64 rows of W — which leaves too few waves for the 4096-row matrices.
     if (!at && !bt && M <= 64 && c.skinny && c.force_tile == 0 && K % 256 == 0 && N % 4 == 0 && N >= 256 &&
+        ((long)N * K <= (9L << 20) || (M <= 16 && N <= 4096) || !c.rows_tiled || K % 64 != 0 || N < 128) &&
         (M <= 16 || (long)N * K <= (32L << 20)) && !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) {
         SkinnyArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, M, N, K, lda, ldb, ldc, ldres, flags};
         // W rows per wave (16 NT) and K parts per workgroup (KW): as much reuse of x as still leaves >= ~1000 waves on the chip
@@ -1779,6 +1909,44 @@ int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, 
 #undef MOLLY_SKINNY_M
 #undef MOLLY_SKINNY
         c.last_cfg = 16 + 1000;
+        MOLLY_LAUNCH_CHECK();
+        return 0;
+    }
+    // decode rows the streaming kernel left: the tiled decode-row kernel (x and W through LDS-DMA, x once per workgroup and K-tile)
+    // (not the lm_head: with >= 512 column tiles the 128x128 kernel streams it at 5.0 TB/s, this one at 4.8)
+    if (!at && !bt && M <= 64 && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < 65536 &&
+        !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) {
+        RowsArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, nullptr,
+                   M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1};
+        // K slices, priced in K-tile times of one workgroup (~0.75 us with two workgroups per CU): whole rounds of the 512 slots x
+        // (slice length + ring fill) + the reduce launch and its slab traffic; slices of >= 4 K-tiles, within the scratch
+        const int nk = K / 64;
+        int splits = 1;
+        double best_cost = 1e30;
+        for (int sp = 1; sp <= 32 && nk / sp >= 4; ++sp) {
+            if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_slab_bytes(c)) break;
+            const double cost = cdiv(q.tiles_n * sp, 512) * ((double)nk / sp + 3.0) +
+                                (sp > 1 ? (5.0 + 8.0 * sp * M * N / 5e6) / 0.75 : 0.0);
+            if (cost < best_cost) { best_cost = cost; splits = sp; }
+        }
+        q.splits = splits;
+        q.ws = splits > 1 ? ws_slabs(c) : nullptr;
+        static bool rows_attr = false;
+        if (!rows_attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32 + 128) * 64 * 2);
+            (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * 64 * 2);
+            rows_attr = true;
+        }
+        if (M <= 32) hipLaunchKernelGGL((gemm_rows_kernel<2, 4>), dim3(q.tiles_n * splits), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
+        else hipLaunchKernelGGL((gemm_rows_kernel<4, 3>), dim3(q.tiles_n * splits), dim3(256), 3 * (64 + 128) * 64 * 2, st, q);
+        if (splits > 1) {
+            const long MN = (long)M * N;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, q.ws,
+                               splits, MN, M, N, C, ldc, (flags & MOLLY_GEMM_OUT_F32) ? 1 : 0, (flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0,
+                               (flags & MOLLY_GEMM_BIAS) ? (const bf16_t*)bias : nullptr, (flags & MOLLY_GEMM_RESIDUAL) ? (const bf16_t*)res : nullptr,
+                               ldres, (flags & MOLLY_GEMM_GELU) ? 1 : 0);
+        }
+        c.last_cfg = 32 + 1000 * splits;
         MOLLY_LAUNCH_CHECK();
         return 0;
     }
@@ -1901,6 +2069,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v == 0 || v == 1, "gemm small_split: %ld not in {0,1}", v);
         c.small_split = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_ROWS_TILED:
+        MOLLY_CHECK(v == 0 || v == 1, "gemm rows_tiled: %ld not in {0,1}", v);
+        c.rows_tiled = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_SKINNY:
         MOLLY_CHECK(v == 0 || v == 1, "gemm skinny: %ld not in {0,1}", v);
         c.skinny = (int)v;
@@ -1985,6 +2157,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_SMALL3: return c.small3;
     case MOLLY_GEMM_KEY_DYNAMIC: return c.dynamic;
     case MOLLY_GEMM_KEY_SMALL_SPLIT: return c.small_split;
+    case MOLLY_GEMM_KEY_ROWS_TILED: return c.rows_tiled;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

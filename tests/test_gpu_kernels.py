@@ -580,7 +580,8 @@ def test_gemm_decode_rows_splitk_with_epilogue(M, N, K):
     from molly_amd import ops
     from molly_amd._lib import lib
     ops.ensure_gemm_workspace(64 << 20)
-    lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["skinny"], 0)      # round 2's path (the decode-row kernel has its own test)
+    lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["skinny"], 0)      # round 2's path (the decode-row kernels have their own tests)
+    lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["rows_tiled"], 0)
     g = torch.Generator(device="cuda").manual_seed(M + N)
     a = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
@@ -598,6 +599,43 @@ def test_gemm_decode_rows_splitk_with_epilogue(M, N, K):
     r32 = a.float() @ w.float().t()
     assert (ops.gemm_nt(a, w).float() - r32).abs().max().item() <= 2e-2 * r32.abs().max().item()
     lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["skinny"], 1)
+    lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["rows_tiled"], 1)
+
+
+@pytest.mark.parametrize("M", [1, 17, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(24576, 4096), (4096, 12288), (1000, 1280), (128, 256), (40000, 512), (6144, 2560)])
+def test_gemm_decode_rows_tiled_kernel(M, N, K):
+    """The tiled decode-row kernel (gemm.hip gemm_rows_kernel: the M = 17..64 projections of BASELINE config 5's batch-32 decode,
+    HF:models/qwen3/modeling_qwen3.py:76-83, 225-236 with one token per sample): exact on small integers with every epilogue, through
+    the K-sliced path (fp32 slabs + reduce) and the direct one (many column tiles), ragged N, K-tile counts that do not divide."""
+    g = torch.Generator(device="cuda").manual_seed(M * 131 + N + K)
+    ints = lambda *s: torch.randint(-3, 4, s, device="cuda", generator=g).to(BF)
+    x, w, bias, res = ints(M, K), ints(N, K), ints(N), ints(M, N)
+    ref = x.float() @ w.float().t()
+    c = ops.GemmContext()
+    c.ensure_workspace(64 << 20)
+    c.set("skinny", 0)
+    with ops.use_gemm_context(c):
+        out = ops.gemm_nt(x, w, out_dtype=torch.float32)
+        cfg = c.get("last_config")
+        assert cfg % 1000 == 32, cfg
+        assert (cfg // 1000 == 1) == (N == 40000 or K == 256), cfg           # one slice only where the column tiles alone fill the chip
+        out_again = ops.gemm_nt(x, w, out_dtype=torch.float32)               # the tile counters were left at zero
+        assert torch.equal(out_again, ref)
+        assert torch.equal(out, ref)
+        assert torch.equal(ops.gemm_nt(x, w, bias=bias, res=res, out_dtype=torch.float32), ref + bias.float() + res.float())
+        acc = ints(M, N).float()
+        want = acc + ref
+        ops.gemm_nt(x, w, out=acc, accumulate=True)
+        assert torch.equal(acc, want)
+        got = ops.gemm_nt(x, w, bias=bias, gelu=True)
+        wg = torch.nn.functional.gelu(ref + bias.float())
+        assert (got.float() - wg).abs().max().item() <= 2 ** -7 * wg.abs().max().item()
+        # a strided x (rows of a wider buffer) and a strided output
+        wide = ints(M, K + 64)
+        outw = torch.zeros(M, N + 8, dtype=torch.float32, device="cuda")
+        ops.gemm_nt(wide[:, 64:], w, out=outw[:, :N])
+        assert torch.equal(outw[:, :N], wide[:, 64:].float() @ w.float().t()) and outw[:, N:].abs().max().item() == 0
 
 
 def test_gelu_epilogue_erf_accuracy_over_the_whole_range():
@@ -760,6 +798,7 @@ def test_gemm_decode_row_kernel(M, N, K):
     ref = x.float() @ w.float().t()
     c = ops.GemmContext()
     c.ensure_workspace(64 << 20)
+    c.set("rows_tiled", 0)                                      # (the tiled decode-row kernel takes the larger matrices: its own test)
     with ops.use_gemm_context(c):
         out = ops.gemm_nt(x, w, out_dtype=torch.float32)
         assert c.get("last_config") == 1016                      # the decode-row kernel

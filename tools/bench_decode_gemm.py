@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Decode-step GEMMs (M = batch rows against whole weight matrices, six copies rotated so they stream from HBM): effective weight
-bandwidth of the decode-row kernel (default) against round 2's path (K split over the chip through the 256x256 kernel + fp32
-slabs + reduce launch).  python tools/bench_decode_gemm.py [--batch 32]"""
+bandwidth of the launcher's default (streaming decode-row kernel, cfg 1016, or the tiled one, cfg 32 + 1000 x slices), the tiled
+kernel alone (streaming kernel off), and round 2's path (K split over the chip through the 256x256 kernel + fp32 slabs + reduce
+launch).  python tools/bench_decode_gemm.py [--batch 32]"""
 import argparse
 import os
 import sys
@@ -17,10 +18,11 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[32])
     args = ap.parse_args()
     dev = "cuda"
-    new, old = ops.GemmContext(), ops.GemmContext()
-    for c in (new, old):
+    new, tiled, old = ops.GemmContext(), ops.GemmContext(), ops.GemmContext()
+    for c in (new, tiled, old):
         c.ensure_workspace(256 << 20)
-    old.set("skinny", 0)
+    tiled.set("skinny", 0)
+    old.set("skinny", 0); old.set("rows_tiled", 0)
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
     for m in args.batch:
@@ -31,7 +33,7 @@ def main():
             ws = [rnd(n, k) for _ in range(2 if n > 100000 else 6)]
             out = torch.empty(m, n, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
             res = {}
-            for tag, c in (("decode-row kernel", new), ("split-K 256x256", old)):
+            for tag, c in (("default", new), ("tiled", tiled), ("r02 split-K", old)):
                 with ops.use_gemm_context(c):
                     for w in ws:
                         ops.gemm_nt(a, w, out=out)
