@@ -7,11 +7,28 @@
 //    processed together, so K/V rows are read ONCE (GQA), 16 B per lane, whole rows coalesced (hd*2 B contiguous);
 //  * split-KV ("flash-decoding"): the key range of a sample is cut into `splits` chunks so B * n_kv_heads * splits blocks
 //    fill the chip; each writes an un-normalised partial (m, l, acc) and a small second kernel merges them;
-//  * 8 independent 16-B loads in flight per lane (4 keys x {K, V}) and online softmax with one rescale per 4 keys.
+//  * 8 independent 16-B loads in flight per lane (4 keys x {K, V}) and online softmax with one rescale per 4 keys;
+//  * the arithmetic per key and query head is what bounds a group of 4 heads (Qwen3-8B: 3.45 TB/s against 5.0 for the groups of
+//    2 of Qwen3-1.7B with the first form of this kernel), so it is cut to the bone: q . k as four v_dot2_f32_bf16 on the raw
+//    bf16 pairs (no conversions, scale applied to the sum), the sum over the 8 / 16 lanes of a key row by DPP adds (quad_perm,
+//    row_half_mirror, row_mirror: one VALU instruction each, no LDS permute), p . v as packed fp32 FMAs on V converted once per key.
 #include "common.h"
 #include "molly_hip.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// sum over the LPR (8 | 16) lanes that hold one key row, result in every one of them
+template <int LPR>
+__device__ __forceinline__ float row_sum(float d) {
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xf, 0xf, true));       // quad_perm [2,3,0,1]
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xf, 0xf, true));      // row_half_mirror
+    if (LPR == 16) d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x140, 0xf, 0xf, true));   // row_mirror
+    return d;
+}
 
 constexpr float NEG_BIG = -1e30f;       // finite "-inf": exp2(NEG_BIG - x) == 0 and NEG_BIG - NEG_BIG == 0 (no NaN)
 constexpr int MAX_SPLITS = 16;
@@ -46,18 +63,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
     const bf16_t* kb = p.kc + (size_t)b * p.Tmax * ldc + kvh * HD + sub * 8;
     const bf16_t* vb = p.vc + (size_t)b * p.Tmax * ldc + kvh * HD + sub * 8;
 
-    float qf[G][8], acc[G][8], m[G], l[G];
+    static_assert(LPR == 8 || LPR == 16, "row_sum: a key row lives in 8 or 16 lanes");
+    u32x4 qv[G];                                     // the lane's 8 q values of every head of the group, raw bf16 pairs
+    f32x2 acc[G][4];
+    float m[G], l[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const u32x4 qv = *reinterpret_cast<const u32x4*>(p.q + (size_t)b * p.ldq + (kvh * G + g) * HD + sub * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            qf[g][2 * e] = bflo(qv[e]) * p.qscale;
-            qf[g][2 * e + 1] = bfhi(qv[e]) * p.qscale;
-        }
+        qv[g] = *reinterpret_cast<const u32x4*>(p.q + (size_t)b * p.ldq + (kvh * G + g) * HD + sub * 8);
         m[g] = NEG_BIG; l[g] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+        for (int e = 0; e < 4; ++e) acc[g][e] = f32x2{0.f, 0.f};
     }
 
     for (int key = k0 + wave * RPW + rg; key < k1; key += STEP * U) {
@@ -71,6 +86,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
             kv[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc_ * ldc);
             vv[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc_ * ldc);
         }
+        f32x2 vf[U][4];                              // V converted once per key, used by every head of the group
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vf[u][e] = f32x2{bflo(vv[u][e]), bfhi(vv[u][e])};
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float sc[U];
@@ -79,26 +99,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
             for (int u = 0; u < U; ++u) {
                 float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d += bflo(kv[u][e]) * qf[g][2 * e] + bfhi(kv[u][e]) * qf[g][2 * e + 1];
-#pragma unroll
-                for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-                sc[u] = ok[u] ? d : NEG_BIG;
+                for (int e = 0; e < 4; ++e) {
+                    // (through named scalars: __builtin_bit_cast applied to a vector ELEMENT reads element 0 for every e — the hipcc
+                    // fold recorded in gemm.hip's residual epilogue; here it turned the 16-byte loads into 4-byte ones)
+                    const unsigned kx = kv[u][e], qx = qv[g][e];
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, kx), __builtin_bit_cast(bf16x2_t, qx), d, false);
+                }
+                d = row_sum<LPR>(d);
+                sc[u] = ok[u] ? d * p.qscale : NEG_BIG;
                 mx = fmaxf(mx, sc[u]);
             }
             const float c = __builtin_amdgcn_exp2f(m[g] - mx);
             m[g] = mx;
             float lsum = l[g] * c;
+            const f32x2 c2 = f32x2{c, c};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[g][e] *= c;
+            for (int e = 0; e < 4; ++e) acc[g][e] *= c2;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float pe = __builtin_amdgcn_exp2f(sc[u] - mx);
                 lsum += pe;
+                const f32x2 pe2 = f32x2{pe, pe};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[g][2 * e] += pe * bflo(vv[u][e]);
-                    acc[g][2 * e + 1] += pe * bfhi(vv[u][e]);
-                }
+                for (int e = 0; e < 4; ++e) acc[g][e] = __builtin_elementwise_fma(pe2, vf[u][e], acc[g][e]);
             }
             l[g] = lsum;
         }
@@ -114,12 +137,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
             const float c1 = __builtin_amdgcn_exp2f(m[g] - mn), c2 = __builtin_amdgcn_exp2f(mo - mn);
             l[g] = l[g] * c1 + lo_ * c2;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * c1 + __shfl_xor(acc[g][e], o, 64) * c2;
+            for (int e = 0; e < 4; ++e) {
+                acc[g][e][0] = acc[g][e][0] * c1 + __shfl_xor(acc[g][e][0], o, 64) * c2;
+                acc[g][e][1] = acc[g][e][1] * c1 + __shfl_xor(acc[g][e][1], o, 64) * c2;
+            }
             m[g] = mn;
         }
         if (rg == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sm[wave][g][sub * 8 + e] = acc[g][e];
+            for (int e = 0; e < 4; ++e) { sm[wave][g][sub * 8 + 2 * e] = acc[g][e][0]; sm[wave][g][sub * 8 + 2 * e + 1] = acc[g][e][1]; }
             if (sub == 0) { sm[wave][g][HD] = m[g]; sm[wave][g][HD + 1] = l[g]; }
         }
     }
@@ -193,9 +219,11 @@ extern "C" int molly_attn_decode(void* stream, const void* q, const void* kcache
     p.qscale = scale * 1.44269504088896341f;
     // enough blocks for ~4 per CU, but keep >= 256 keys per split (kv_len_hint = upper bound of the valid length, 0 = Tmax)
     const int len = kv_len_hint > 0 ? kv_len_hint : Tmax;
-    int splits = (1024 + B * n_kv_heads - 1) / (B * n_kv_heads);
+    static const int target = [] { const char* e = getenv("MOLLY_DECODE_BLOCKS"); return e ? atoi(e) : 1024; }();
+    static const int min_keys = [] { const char* e = getenv("MOLLY_DECODE_MIN_KEYS"); return e ? atoi(e) : 256; }();
+    int splits = (target + B * n_kv_heads - 1) / (B * n_kv_heads);
     splits = splits < 1 ? 1 : splits;
-    if (splits > len / 256) splits = len / 256 > 0 ? len / 256 : 1;
+    if (splits > len / min_keys) splits = len / min_keys > 0 ? len / min_keys : 1;
     if (splits > MAX_SPLITS) splits = MAX_SPLITS;
     if (splits > 1 && (workspace == nullptr || workspace_floats < (long)B * n_heads * splits * (head_dim + 2))) splits = 1;
     p.splits = splits;
