@@ -117,6 +117,15 @@ enum {
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
+/* decode rows (M <= 64, the plain forward form) on the tiled decode-row kernel, with the kernel the decode step would launch next
+ * folded into the launch that combines the K slices.  tail 1: C = A B^T (+ bias) (+ res) [M][N] and tail_out = RMSNorm(C) * gain
+ * [M][N] (the next block's input norm, HF:models/qwen3/modeling_qwen3.py:50-63, 262-276); tail 2: C = [gate | up] [M][N] and
+ * tail_out = silu(gate) * up [M][N / 2] (HF:models/qwen3/modeling_qwen3.py:76-83).  Same roundings as the separate kernels.
+ * molly_gemm_rows_tail_supported: 1 when this context would run M x N x K that way (else use the GEMM and the kernel). */
+int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, int tail);
+int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
+                                  int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int tail, const void* gain,
+                                  float eps, void* tail_out, int ld_tail);
 int molly_gemm_ctx_create(void** out);
 int molly_gemm_ctx_destroy(void* ctx);
 int molly_gemm_ctx_set(void* ctx, int key, long value);
@@ -167,6 +176,13 @@ int molly_colsum_batched(void* stream, const void* items_dev, int n_items, int m
 int molly_norm_rope_fwd(void* stream, const void* src, void* dst, const void* q_norm_w, const void* k_norm_w,
                         const float* cos, const float* sin, const int* positions, int M, int T, int n_q_heads,
                         int n_k_heads, int head_dim, int ld_src, int ld_dst, float eps, float q_scale);
+/* the same for one decode step (T = 1 row per sample), together with the KV-cache append HF's DynamicCache.update does behind it
+ * (reference src/model/omics_one.py:220-232): src rows hold q | k | v heads; the k heads after norm + rotary and the v heads as they are
+ * are also written to row slot[m] of kcache / vcache ([rows][ld_cache], n_k_heads * head_dim wide). */
+int molly_norm_rope_cache_fwd(void* stream, const void* src, void* dst, const void* q_norm_w, const void* k_norm_w,
+                              const float* cos, const float* sin, const int* positions, int M, int T, int n_q_heads,
+                              int n_k_heads, int head_dim, int ld_src, int ld_dst, float eps, float q_scale,
+                              void* kcache, void* vcache, const int* slot, int ld_cache);
 int molly_norm_rope_bwd_blocks(void);
 int molly_norm_rope_bwd(void* stream, const void* src, const void* g, void* dsrc, const void* q_norm_w,
                         const void* k_norm_w, const float* cos, const float* sin, const int* positions, void* dq_w,

@@ -239,6 +239,8 @@ struct RopeArgs {
     const int* pos;                          // nullable: position = m % T
     int M, T, nq, nk, hd, ld_src, ld_dst;
     float eps, q_scale;
+    // decode step: the k heads (after norm + rotary) and the v heads (as they are) of row m also go to row slot[m] of the KV caches
+    bf16_t* kc; bf16_t* vc; const int* slot; int ld_cache, nv;
 };
 
 // each thread owns 4 consecutive (i, i+hd/2) pairs -> 8-byte loads/stores; hd/8 threads per head
@@ -248,11 +250,19 @@ __global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
     const int heads_per_blk = 256 / tph;
     const int i = (threadIdx.x % tph) * 4;
     const long item = (long)blockIdx.x * heads_per_blk + threadIdx.x / tph;
-    const int nh = p.nq + p.nk;
+    const int nh = p.nq + p.nk + p.nv;                  // (nv > 0: the decode step's cache append; v heads follow the k heads in src)
     const long total = (long)p.M * nh;
     const bool live = item < total;
     const int m = live ? (int)(item / nh) : 0, head = live ? (int)(item % nh) : 0;
     const bf16_t* s = p.src + (size_t)m * p.ld_src + head * p.hd;
+    if (head >= p.nq + p.nk) {                          // a v head: copied as it is (whole groups of tph lanes take this branch)
+        if (live) {
+            bf16_t* d = p.vc + (size_t)p.slot[m] * p.ld_cache + (head - p.nq - p.nk) * p.hd;
+            *reinterpret_cast<u32x2*>(d + i) = *reinterpret_cast<const u32x2*>(s + i);
+            *reinterpret_cast<u32x2*>(d + i + half) = *reinterpret_cast<const u32x2*>(s + i + half);
+        }
+        return;
+    }
     float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
     if (live) {
         const u32x2 a = ld_stream<u32x2>(s + i), b = ld_stream<u32x2>(s + i + half);
@@ -298,8 +308,14 @@ __global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
     }
     if (live) {
         bf16_t* d = p.dst + (size_t)m * p.ld_dst + head * p.hd;
-        st_stream<u32x2>(d + i, u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])});
-        st_stream<u32x2>(d + i + half, u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])});
+        const u32x2 o1 = u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])}, o2 = u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
+        st_stream<u32x2>(d + i, o1);
+        st_stream<u32x2>(d + i + half, o2);
+        if (p.kc && !isq) {
+            bf16_t* c = p.kc + (size_t)p.slot[m] * p.ld_cache + (head - p.nq) * p.hd;
+            *reinterpret_cast<u32x2*>(c + i) = o1;
+            *reinterpret_cast<u32x2*>(c + i + half) = o2;
+        }
     }
 }
 
@@ -1206,8 +1222,29 @@ extern "C" int molly_norm_rope_fwd(void* stream, const void* src, void* dst, con
     MOLLY_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr), "norm_rope: give both norm gains or neither");
     MOLLY_CHECK((cos == nullptr) == (sin == nullptr), "norm_rope: give both cos and sin or neither");
     RopeArgs p{(const bf16_t*)src, (bf16_t*)dst, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, cos, sin, positions,
-               M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_dst, eps, q_scale};
+               M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_dst, eps, q_scale, nullptr, nullptr, nullptr, 0, 0};
     const long items = (long)M * (n_q_heads + n_k_heads);
+    const int hpb = 256 / (head_dim / 8);
+    hipLaunchKernelGGL(norm_rope_fwd_kernel, dim3((unsigned)((items + hpb - 1) / hpb)), dim3(256), 0, ST, p);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_norm_rope_cache_fwd(void* stream, const void* src, void* dst, const void* q_norm_w, const void* k_norm_w,
+                                         const float* cos, const float* sin, const int* positions, int M, int T, int n_q_heads,
+                                         int n_k_heads, int head_dim, int ld_src, int ld_dst, float eps, float q_scale,
+                                         void* kcache, void* vcache, const int* slot, int ld_cache) {
+    MOLLY_ENTER();
+    MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0, "norm_rope_cache: head_dim=%d", head_dim);
+    MOLLY_CHECK(ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_cache % 4 == 0 && ((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 8) == 0 &&
+                    ((uintptr_t)kcache % 8) == 0 && ((uintptr_t)vcache % 8) == 0, "norm_rope_cache: 8-byte alignment required");
+    MOLLY_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr), "norm_rope_cache: give both norm gains or neither");
+    MOLLY_CHECK((cos == nullptr) == (sin == nullptr), "norm_rope_cache: give both cos and sin or neither");
+    MOLLY_CHECK(kcache && vcache && slot && ld_src >= (n_q_heads + 2 * n_k_heads) * head_dim,
+                "norm_rope_cache: caches, slots and a src row of q | k | v heads are required");
+    RopeArgs p{(const bf16_t*)src, (bf16_t*)dst, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, cos, sin, positions,
+               M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_dst, eps, q_scale, (bf16_t*)kcache, (bf16_t*)vcache, slot, ld_cache, n_k_heads};
+    const long items = (long)M * (n_q_heads + 2 * n_k_heads);
     const int hpb = 256 / (head_dim / 8);
     hipLaunchKernelGGL(norm_rope_fwd_kernel, dim3((unsigned)((items + hpb - 1) / hpb)), dim3(256), 0, ST, p);
     MOLLY_LAUNCH_CHECK();

@@ -1619,6 +1619,100 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// ---- tails of a K-sliced decode-row GEMM (molly_gemm_rows_tail_bf16_ctx): the slab combine together with what the decode step
+// launches right behind the projection, so that one launch replaces two or three of the ~16 per layer.
+// RMSNorm tail: one workgroup of 1024 threads per output row (N <= 8192).  y = sum of the slices (+ bias) (+ residual), rounded to
+// bf16 and stored — the row the unfused path would hand to the norm kernel — then yn = bf16(bf16(y * rstd) * gain), the roundings of
+// rmsnorm_fwd_kernel (HF:models/qwen3/modeling_qwen3.py:50-63).
+__global__ __launch_bounds__(1024) void rows_tail_norm_kernel(const float* __restrict__ ws, int splits, int M, int N, bf16_t* C, int ldc,
+                                                              const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, int ldres,
+                                                              const bf16_t* __restrict__ gain, float eps, bf16_t* out, int ldo) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const long MN = (long)M * N;
+    float v[2][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = (c * 1024 + tid) * 4;
+        if (n >= N) continue;
+        const float* src = ws + (size_t)m * N + n;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        int s2 = 0;
+        for (; s2 + 4 <= splits; s2 += 4) {                       // four slices' loads in flight, added in slice order
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (size_t)s2 * MN);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (size_t)(s2 + 1) * MN);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (size_t)(s2 + 2) * MN);
+            const f32x4 a3 = *reinterpret_cast<const f32x4*>(src + (size_t)(s2 + 3) * MN);
+            a += a0; a += a1; a += a2; a += a3;
+        }
+        for (; s2 < splits; ++s2) a += *reinterpret_cast<const f32x4*>(src + (size_t)s2 * MN);
+        if (bias) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(bias + n);
+            a[0] += bflo(b[0]); a[1] += bfhi(b[0]); a[2] += bflo(b[1]); a[3] += bfhi(b[1]);
+        }
+        if (res) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(res + (size_t)m * ldres + n);
+            a[0] += bflo(b[0]); a[1] += bfhi(b[0]); a[2] += bflo(b[1]); a[3] += bfhi(b[1]);
+        }
+        const u32x2 y = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+        *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + n) = y;
+        v[c][0] = bflo(y[0]); v[c][1] = bfhi(y[0]); v[c][2] = bflo(y[1]); v[c][3] = bfhi(y[1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += v[c][e] * v[c][e];
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];                   // (every thread adds the 16 wave sums in the same order)
+    const float rstd = rsqrtf(tot / (float)N + eps);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = (c * 1024 + tid) * 4;
+        if (n >= N) continue;
+        const u32x2 g = *reinterpret_cast<const u32x2*>(gain + n);
+        const uint32_t t0 = pack_bf2(v[c][0] * rstd, v[c][1] * rstd), t1 = pack_bf2(v[c][2] * rstd, v[c][3] * rstd);
+        *reinterpret_cast<u32x2*>(out + (size_t)m * ldo + n) =
+            u32x2{pack_bf2(bflo(t0) * bflo(g[0]), bfhi(t0) * bfhi(g[0])), pack_bf2(bflo(t1) * bflo(g[1]), bfhi(t1) * bfhi(g[1]))};
+    }
+}
+
+// SwiGLU tail: C = [gate | up] [M][2 ff] (the GEMM's output, bf16), out = silu(gate) * up [M][ff] with swiglu_fwd_kernel's roundings
+// (silu rounded to bf16, then the product: HF:models/qwen3/modeling_qwen3.py:76-83); 4 activation columns per thread.
+__global__ __launch_bounds__(256) void rows_tail_swiglu_kernel(const float* __restrict__ ws, int splits, int M, int N, bf16_t* C, int ldc,
+                                                               const bf16_t* __restrict__ bias, bf16_t* out, int ldo) {
+    const int ff = N >> 1;
+    const long MN = (long)M * N;
+    const long total = (long)M * (ff >> 2);
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int m = (int)(t / (ff >> 2)), n = (int)(t % (ff >> 2)) * 4;
+        const float* src = ws + (size_t)m * N + n;
+        f32x4 g = *reinterpret_cast<const f32x4*>(src), u = *reinterpret_cast<const f32x4*>(src + ff);
+        for (int s2 = 1; s2 < splits; ++s2) {
+            g += *reinterpret_cast<const f32x4*>(src + (size_t)s2 * MN);
+            u += *reinterpret_cast<const f32x4*>(src + (size_t)s2 * MN + ff);
+        }
+        if (bias) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(bias + n), b2 = *reinterpret_cast<const u32x2*>(bias + ff + n);
+            g[0] += bflo(b[0]); g[1] += bfhi(b[0]); g[2] += bflo(b[1]); g[3] += bfhi(b[1]);
+            u[0] += bflo(b2[0]); u[1] += bfhi(b2[0]); u[2] += bflo(b2[1]); u[3] += bfhi(b2[1]);
+        }
+        const u32x2 gq = u32x2{pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3])}, uq = u32x2{pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3])};
+        *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + n) = gq;
+        *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + ff + n) = uq;
+        u32x2 o;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float ga = bflo(gq[e]), gb = bfhi(gq[e]);
+            const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+            o[e] = pack_bf2(sa * bflo(uq[e]), sb * bfhi(uq[e]));
+        }
+        *reinterpret_cast<u32x2*>(out + (size_t)m * ldo + n) = o;
+    }
+}
+
 // ---- launch state.  Everything a launch decision reads lives in a CONTEXT: the tuning knobs, the scratch memory and the record
 // of the last configuration.  molly_gemm_ctx_* create and edit contexts; the *_ctx entry points launch through one.  The entry
 // points without a context use the calling thread's default context (thread_local: what one host thread sets, another never
@@ -1858,6 +1952,62 @@ int resolve_zero_page(const bf16_t** out) {
     return 0;
 }
 
+
+// ---- the tiled decode-row kernel's launcher.  tail: 0 none | 1 RMSNorm of the output rows (gain, eps -> tail_out [M][N]) | 2 SwiGLU
+// of an output that is [gate | up] (-> tail_out [M][N / 2]); a tail runs inside the slab combine, so it forces >= 2 K slices.
+// (not the lm_head: with >= 512 column tiles the 128x128 kernel streams it at 5.0 TB/s, this one at 4.8)
+inline bool rows_applicable(const GemmCtx& c, int M, int N, int K, int flags) {
+    return M <= 64 && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < 65536 &&
+           !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD));
+}
+int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
+                int lda, int ldb, int ldc, int ldres, int flags, int tail, const void* gain, float eps, void* tail_out, int ld_tail) {
+    RowsArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, nullptr,
+               M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1};
+    // K slices, priced in K-tile times of one workgroup (~0.75 us with two workgroups per CU): whole rounds of the 512 slots x
+    // (slice length + ring fill) + the reduce launch and its slab traffic; slices of >= 4 K-tiles, within the scratch
+    const int nk = K / 64;
+    int splits = 1;
+    double best_cost = 1e30;
+    for (int sp = tail ? 2 : 1; sp <= 32 && (nk / sp >= 4 || (tail && sp == 2)); ++sp) {
+        if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_slab_bytes(c)) break;
+        const double cost = cdiv(q.tiles_n * sp, 512) * ((double)nk / sp + 3.0) +
+                            (sp > 1 ? (5.0 + 8.0 * sp * M * N / 5e6) / 0.75 : 0.0);
+        if (cost < best_cost) { best_cost = cost; splits = sp; }
+    }
+    if (tail && (splits < 2 || (size_t)splits * M * N * sizeof(float) > ws_slab_bytes(c))) {
+        molly_set_error("gemm rows tail: the context has no scratch for %d x %d x %d slabs", splits, M, N);
+        return 1;
+    }
+    q.splits = splits;
+    q.ws = splits > 1 ? ws_slabs(c) : nullptr;
+    static bool rows_attr = false;
+    if (!rows_attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32 + 128) * 64 * 2);
+        (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * 64 * 2);
+        rows_attr = true;
+    }
+    if (M <= 32) hipLaunchKernelGGL((gemm_rows_kernel<2, 4>), dim3(q.tiles_n * splits), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
+    else hipLaunchKernelGGL((gemm_rows_kernel<4, 3>), dim3(q.tiles_n * splits), dim3(256), 3 * (64 + 128) * 64 * 2, st, q);
+    const bf16_t* bp = (flags & MOLLY_GEMM_BIAS) ? (const bf16_t*)bias : nullptr;
+    const bf16_t* rp = (flags & MOLLY_GEMM_RESIDUAL) ? (const bf16_t*)res : nullptr;
+    if (tail == 1) {
+        hipLaunchKernelGGL(rows_tail_norm_kernel, dim3(M), dim3(1024), 0, st, q.ws, splits, M, N, (bf16_t*)C, ldc, bp, rp, ldres,
+                           (const bf16_t*)gain, eps, (bf16_t*)tail_out, ld_tail);
+    } else if (tail == 2) {
+        const long total = (long)M * (N / 8);
+        hipLaunchKernelGGL(rows_tail_swiglu_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, st, q.ws, splits, M, N,
+                           (bf16_t*)C, ldc, bp, (bf16_t*)tail_out, ld_tail);
+    } else if (splits > 1) {
+        const long MN = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, q.ws,
+                           splits, MN, M, N, C, ldc, (flags & MOLLY_GEMM_OUT_F32) ? 1 : 0, (flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0,
+                           bp, rp, ldres, (flags & MOLLY_GEMM_GELU) ? 1 : 0);
+    }
+    c.last_cfg = 32 + 1000 * splits;
+    return 0;
+}
+
 int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N,
                 int K, int lda, int ldb, int ldc, int ldres, int flags, bool at, bool bt) {
     MOLLY_ENTER();
@@ -1913,40 +2063,9 @@ int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, 
         return 0;
     }
     // decode rows the streaming kernel left: the tiled decode-row kernel (x and W through LDS-DMA, x once per workgroup and K-tile)
-    // (not the lm_head: with >= 512 column tiles the 128x128 kernel streams it at 5.0 TB/s, this one at 4.8)
-    if (!at && !bt && M <= 64 && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < 65536 &&
-        !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) {
-        RowsArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, nullptr,
-                   M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1};
-        // K slices, priced in K-tile times of one workgroup (~0.75 us with two workgroups per CU): whole rounds of the 512 slots x
-        // (slice length + ring fill) + the reduce launch and its slab traffic; slices of >= 4 K-tiles, within the scratch
-        const int nk = K / 64;
-        int splits = 1;
-        double best_cost = 1e30;
-        for (int sp = 1; sp <= 32 && nk / sp >= 4; ++sp) {
-            if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_slab_bytes(c)) break;
-            const double cost = cdiv(q.tiles_n * sp, 512) * ((double)nk / sp + 3.0) +
-                                (sp > 1 ? (5.0 + 8.0 * sp * M * N / 5e6) / 0.75 : 0.0);
-            if (cost < best_cost) { best_cost = cost; splits = sp; }
-        }
-        q.splits = splits;
-        q.ws = splits > 1 ? ws_slabs(c) : nullptr;
-        static bool rows_attr = false;
-        if (!rows_attr) {
-            (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32 + 128) * 64 * 2);
-            (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * 64 * 2);
-            rows_attr = true;
-        }
-        if (M <= 32) hipLaunchKernelGGL((gemm_rows_kernel<2, 4>), dim3(q.tiles_n * splits), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
-        else hipLaunchKernelGGL((gemm_rows_kernel<4, 3>), dim3(q.tiles_n * splits), dim3(256), 3 * (64 + 128) * 64 * 2, st, q);
-        if (splits > 1) {
-            const long MN = (long)M * N;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, q.ws,
-                               splits, MN, M, N, C, ldc, (flags & MOLLY_GEMM_OUT_F32) ? 1 : 0, (flags & MOLLY_GEMM_ACCUMULATE) ? 1 : 0,
-                               (flags & MOLLY_GEMM_BIAS) ? (const bf16_t*)bias : nullptr, (flags & MOLLY_GEMM_RESIDUAL) ? (const bf16_t*)res : nullptr,
-                               ldres, (flags & MOLLY_GEMM_GELU) ? 1 : 0);
-        }
-        c.last_cfg = 32 + 1000 * splits;
+    if (!at && !bt && rows_applicable(c, M, N, K, flags)) {
+        const int rc = launch_rows(c, st, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, 0, nullptr, 0.f, nullptr, 0);
+        if (rc) return rc;
         MOLLY_LAUNCH_CHECK();
         return 0;
     }
@@ -2121,6 +2240,37 @@ extern "C" int molly_gemm_bf16_ctx(void* ctx, void* stream, const void* A, const
                                    const void* res, int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags,
                                    int a_kmajor, int b_kmajor) {
     return launch_gemm(ctx, stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, a_kmajor != 0, b_kmajor != 0);
+}
+
+// ---- decode-row GEMM + the kernel the decode step launches behind it (tail 1: RMSNorm of the output rows, the next block's input
+// norm; tail 2: SwiGLU of a gate|up output), in the launch that combines the K slices
+extern "C" int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, int tail) {
+    const GemmCtx& c = ctx_of(ctx);
+    if (!(tail == 1 || tail == 2) || !rows_applicable(c, M, N, K, 0) || !c.ws) return 0;
+    if (tail == 1 && N > 8192) return 0;
+    if (tail == 2 && N % 8 != 0) return 0;
+    // a streaming-kernel shape stays there (its one launch is cheaper than slices + tail): the same rule as launch_gemm
+    if (c.skinny && K % 256 == 0 && N >= 256 && ((long)N * K <= (9L << 20) || (M <= 16 && N <= 4096)) &&
+        (M <= 16 || (long)N * K <= (32L << 20))) return 0;
+    return (size_t)2 * M * N * sizeof(float) <= ws_slab_bytes(c) ? 1 : 0;
+}
+extern "C" int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias,
+                                             const void* res, int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags,
+                                             int tail, const void* gain, float eps, void* tail_out, int ld_tail) {
+    MOLLY_ENTER();
+    GemmCtx& c = ctx_of(ctx);
+    MOLLY_CHECK(molly_gemm_rows_tail_supported(ctx, M, N, K, tail), "gemm rows tail: M=%d N=%d K=%d tail=%d is not a shape of the tiled "
+                "decode-row kernel (ask molly_gemm_rows_tail_supported first)", M, N, K, tail);
+    MOLLY_CHECK(!(flags & ~(MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL)) && (tail == 1 || !(flags & MOLLY_GEMM_RESIDUAL)),
+                "gemm rows tail: flags %d (bias, and a residual in front of the norm, are what a tail takes)", flags);
+    MOLLY_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ld_tail % 4 == 0 && tail_out && C && (tail == 2 || gain),
+                "gemm rows tail: strides / pointers");
+    MOLLY_CHECK(!(flags & MOLLY_GEMM_BIAS) || bias, "gemm rows tail: MOLLY_GEMM_BIAS without bias pointer");
+    MOLLY_CHECK(!(flags & MOLLY_GEMM_RESIDUAL) || (res && ldres % 4 == 0), "gemm rows tail: bad residual");
+    const int rc = launch_rows(c, (hipStream_t)stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, tail, gain, eps, tail_out, ld_tail);
+    if (rc) return rc;
+    MOLLY_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int molly_gemm_grouped_bf16(void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {

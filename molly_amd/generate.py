@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -127,30 +129,57 @@ class GenerationSession:
         nq, nkvd = e.nh * e.hd, e.nkv * e.hd
         ops.copy_rows(e.embed, s["x"], B, src_idx64=self.tok)
         x = s["x"]
+        eps = e.cfg.rms_norm_eps
+        # merged or no adapters: the launches behind a projection fold into it where the decode-row GEMM takes the shape (batch 17..64 on
+        # the larger matrices) — residual + next RMSNorm behind o / down, SwiGLU behind gate|up — and the cache appends into norm + rope
+        fuse = e.lora is None and os.environ.get("MOLLY_DECODE_FUSE", "1") != "0"
+        H = x.shape[1]
+        f_o = fuse and ops.gemm_rows_tail_supported(B, H, nq, "norm")
+        f_gu = fuse and ops.gemm_rows_tail_supported(B, 2 * e.ff, H, "swiglu")
+        f_dn = fuse and ops.gemm_rows_tail_supported(B, H, e.ff, "norm")
+        normed = False                                  # s["xn"] already holds ln1(x) of the layer about to run
         for i in range(e.L):
             w = e.W[i]
-            ops.rmsnorm_fwd(x, w["ln1"], e.cfg.rms_norm_eps, out=s["xn"])
+            if not normed:
+                ops.rmsnorm_fwd(x, w["ln1"], eps, out=s["xn"])
             ops.gemm_nt(s["xn"], w["qkv"], out=s["qkv"])
             self._lora(i, "q_proj", s["xn"], s["qkv"][:, :nq])
             self._lora(i, "k_proj", s["xn"], s["qkv"][:, nq:nq + nkvd])
             self._lora(i, "v_proj", s["xn"], s["qkv"][:, nq + nkvd:])
-            ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin,
-                              positions=self.pos, eps=e.cfg.rms_norm_eps)
-            ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
-            ops.copy_rows(s["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
+            if fuse:
+                ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin, positions=self.pos, eps=eps,
+                                  kcache=self.kc[i].view(B * self.Tmax, nkvd), vcache=self.vc[i].view(B * self.Tmax, nkvd), slot=self.slot)
+            else:
+                ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin,
+                                  positions=self.pos, eps=eps)
+                ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
+                ops.copy_rows(s["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
             ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
                             e.hd ** -0.5, kv_len_hint=self.Tmax, workspace=self.dec_ws)
-            ops.gemm_nt(s["attn"], w["o"], out=s["x2"], res=x)
-            self._lora(i, "o_proj", s["attn"], s["x2"])
-            ops.rmsnorm_fwd(s["x2"], w["ln2"], e.cfg.rms_norm_eps, out=s["xn2"])
-            ops.gemm_nt(s["xn2"], w["gu"], out=s["gu"])
-            self._lora(i, "gate_proj", s["xn2"], s["gu"][:, :e.ff])
-            self._lora(i, "up_proj", s["xn2"], s["gu"][:, e.ff:])
-            ops.swiglu_fwd(s["gu"], out=s["act"])
-            ops.gemm_nt(s["act"], w["down"], out=s["x"], res=s["x2"])
-            self._lora(i, "down_proj", s["act"], s["x"])
+            if f_o:
+                ops.gemm_rows_norm(s["attn"], w["o"], s["x2"], w["ln2"], eps, s["xn2"], res=x)
+            else:
+                ops.gemm_nt(s["attn"], w["o"], out=s["x2"], res=x)
+                self._lora(i, "o_proj", s["attn"], s["x2"])
+                ops.rmsnorm_fwd(s["x2"], w["ln2"], eps, out=s["xn2"])
+            if f_gu:
+                ops.gemm_rows_swiglu(s["xn2"], w["gu"], s["gu"], s["act"])
+            else:
+                ops.gemm_nt(s["xn2"], w["gu"], out=s["gu"])
+                self._lora(i, "gate_proj", s["xn2"], s["gu"][:, :e.ff])
+                self._lora(i, "up_proj", s["xn2"], s["gu"][:, e.ff:])
+                ops.swiglu_fwd(s["gu"], out=s["act"])
+            if f_dn:                                    # ... + the NEXT block's input norm (the final norm behind the last block)
+                last = i + 1 == e.L
+                ops.gemm_rows_norm(s["act"], w["down"], s["x"], e.norm_w if last else e.W[i + 1]["ln1"], eps,
+                                   s["hn"] if last else s["xn"], res=s["x2"])
+                normed = True
+            else:
+                ops.gemm_nt(s["act"], w["down"], out=s["x"], res=s["x2"])
+                self._lora(i, "down_proj", s["act"], s["x"])
             x = s["x"]
-        ops.rmsnorm_fwd(x, e.norm_w, e.cfg.rms_norm_eps, out=s["hn"])
+        if not normed:
+            ops.rmsnorm_fwd(x, e.norm_w, eps, out=s["hn"])
         ops.gemm_nt(s["hn"], e.head, out=self.logits)
         # advance the per-sample position / cache slot / visible-key bound for the next step (device-side, graph-replayable)
         self.pos += 1

@@ -136,6 +136,30 @@ def ensure_gemm_workspace(nbytes: int = 512 << 20, device="cuda"):
     return _GEMM_WS
 
 
+def gemm_rows_tail_supported(M: int, N: int, K: int, tail: str) -> bool:
+    """Would the current context run the decode-row GEMM M x N x K with `tail` ('norm' | 'swiglu') folded into its slab combine?"""
+    return bool(lib().query("molly_gemm_rows_tail_supported", _ctx(), M, N, K, {"norm": 1, "swiglu": 2}[tail]))
+
+
+def gemm_rows_norm(x, w, out, norm_w, eps, norm_out, res=None, bias=None):
+    """out[M,N] = x w^T (+bias) (+res) and norm_out = RMSNorm(out) * norm_w in the launch that combines the K slices (decode rows)."""
+    M, K = x.shape
+    N = w.shape[0]
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_RESIDUAL if res is not None else 0)
+    lib().call("molly_gemm_rows_tail_bf16_ctx", _ctx(), _stream(), x, w, out, bias, res, M, N, K, x.stride(0), w.stride(0), out.stride(0),
+               res.stride(0) if res is not None else 0, flags, 1, norm_w, float(eps), norm_out, norm_out.stride(0))
+    return out, norm_out
+
+
+def gemm_rows_swiglu(x, w, gu, act, bias=None):
+    """gu[M, 2ff] = x w^T (+bias) and act[M, ff] = silu(gate) * up in the launch that combines the K slices (decode rows)."""
+    M, K = x.shape
+    N = w.shape[0]
+    lib().call("molly_gemm_rows_tail_bf16_ctx", _ctx(), _stream(), x, w, gu, bias, None, M, N, K, x.stride(0), w.stride(0), gu.stride(0),
+               0, GEMM_BIAS if bias is not None else 0, 2, None, 0.0, act, act.stride(0))
+    return gu, act
+
+
 def gemm_nt(a, b, out=None, bias=None, res=None, gelu=False, accumulate=False, out_dtype=BF16):
     """out[M,N] = a[M,K] @ b[N,K]^T (+bias) (gelu) (+res) (+= out).  2-D views with arbitrary row stride."""
     return gemm(a, b, out, bias, res, gelu, accumulate, out_dtype, False, False)
@@ -268,8 +292,15 @@ def rmsnorm_bwd(x, w, g, dw, eps, dres=None, dx=None, dw_accumulate=True, worksp
     return dx
 
 
-def norm_rope_fwd(src, dst, nq, nk, hd, T, qw=None, kw=None, cos=None, sin=None, positions=None, eps=1e-6, q_scale=1.0):
+def norm_rope_fwd(src, dst, nq, nk, hd, T, qw=None, kw=None, cos=None, sin=None, positions=None, eps=1e-6, q_scale=1.0,
+                  kcache=None, vcache=None, slot=None):
+    """kcache / vcache ([rows, nk * hd]) + slot (int32 [M]): the decode step's cache append in the same launch — the k heads after
+    norm + rotary and the v heads of src row m go to cache row slot[m]."""
     M = src.shape[0]
+    if kcache is not None:
+        lib().call("molly_norm_rope_cache_fwd", _stream(), src, dst, qw, kw, cos, sin, positions, M, T, nq, nk, hd,
+                   src.stride(0), dst.stride(0), float(eps), float(q_scale), kcache, vcache, slot, kcache.stride(0))
+        return dst
     lib().call("molly_norm_rope_fwd", _stream(), src, dst, qw, kw, cos, sin, positions, M, T, nq, nk, hd,
                src.stride(0), dst.stride(0), float(eps), float(q_scale))
     return dst

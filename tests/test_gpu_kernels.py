@@ -638,6 +638,65 @@ def test_gemm_decode_rows_tiled_kernel(M, N, K):
         assert torch.equal(outw[:, :N], wide[:, 64:].float() @ w.float().t()) and outw[:, N:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("M", [17, 32, 64])
+def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
+    """The decode step's launches folded into the decode-row GEMM's slab combine (molly_gemm_rows_tail_bf16_ctx): residual + RMSNorm
+    behind o_proj / down_proj, SwiGLU behind gate|up (HF:models/qwen3/modeling_qwen3.py:50-63, 76-83, 262-276 with one token per
+    sample) — bit-identical to the GEMM followed by the separate kernel, except where the fp32 order of the row's sum of squares
+    moves rstd by an ulp (allowed: one bf16 ulp on a few elements)."""
+    g = torch.Generator(device="cuda").manual_seed(M)
+    H, FF = 4096, 12288
+    c = ops.GemmContext()
+    c.ensure_workspace(64 << 20)
+    rnd = lambda *s, sc=1.0: ((torch.rand(*s, device="cuda", generator=g) * 2 - 1) * sc).to(BF)
+    with ops.use_gemm_context(c):
+        # residual + norm behind a [H x FF] projection
+        x, w, res, gain = rnd(M, FF), rnd(H, FF, sc=FF ** -0.5), rnd(M, H), rnd(H)
+        assert ops.gemm_rows_tail_supported(M, H, FF, "norm")
+        y0 = ops.gemm_nt(x, w, res=res)
+        n0 = ops.rmsnorm_fwd(y0, gain, 1e-6)
+        y1, n1 = torch.empty_like(y0), torch.empty_like(y0)
+        ops.gemm_rows_norm(x, w, y1, gain, 1e-6, n1, res=res)
+        assert torch.equal(y0, y1)
+        d = (n0.float() - n1.float()).abs()
+        assert d.max().item() <= 2 ** -7 * n0.float().abs().max().item() and (d > 0).float().mean().item() < 0.02
+        # SwiGLU behind a [2 FF' x H] projection
+        x2, w2 = rnd(M, H), rnd(2 * 6144, H, sc=H ** -0.5)
+        assert ops.gemm_rows_tail_supported(M, 2 * 6144, H, "swiglu")
+        gu0 = ops.gemm_nt(x2, w2)
+        a0 = ops.swiglu_fwd(gu0)
+        gu1, a1 = torch.empty_like(gu0), torch.empty_like(a0)
+        ops.gemm_rows_swiglu(x2, w2, gu1, a1)
+        assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+        assert not ops.gemm_rows_tail_supported(8, 4096, 4096, "norm")        # a streaming-kernel shape keeps its one launch
+        assert not ops.gemm_rows_tail_supported(M, 151936, 4096, "norm")      # the lm_head is not a decode-row-kernel shape
+
+
+def test_norm_rope_with_cache_append_equals_the_three_launches():
+    """Decode step: q/k norm + rotary and the KV-cache append (HF DynamicCache.update, reference src/model/omics_one.py:220-232) in
+    one launch — same q | k rows and the same cache rows as norm_rope_fwd + two copy_rows."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, nh, nkv, hd, Tmax = 5, 8, 2, 128, 40
+    qkv = ((torch.rand(B, (nh + 2 * nkv) * hd, device="cuda", generator=g) * 2 - 1)).to(BF)
+    qn, kn = (torch.rand(hd, device="cuda", generator=g) + 0.5).to(BF), (torch.rand(hd, device="cuda", generator=g) + 0.5).to(BF)
+    cos = torch.rand(64, hd // 2, device="cuda", generator=g)
+    sin = torch.rand(64, hd // 2, device="cuda", generator=g)
+    pos = torch.tensor([3, 9, 0, 33, 17], dtype=torch.int32, device="cuda")
+    slot = torch.tensor([b * Tmax + int(p) for b, p in enumerate(pos.tolist())], dtype=torch.int32, device="cuda")
+    nq, nkvd = nh * hd, nkv * hd
+    qk0 = torch.empty(B, nq + nkvd, dtype=BF, device="cuda")
+    kc0 = torch.zeros(B * Tmax, nkvd, dtype=BF, device="cuda"); vc0 = torch.zeros_like(kc0)
+    ops.norm_rope_fwd(qkv, qk0, nh, nkv, hd, 1, qn, kn, cos, sin, positions=pos)
+    ops.copy_rows(qk0[:, nq:], kc0, B, dst_idx32=slot)
+    ops.copy_rows(qkv[:, nq + nkvd:], vc0, B, dst_idx32=slot)
+    qk1 = torch.empty_like(qk0)
+    kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+    ops.norm_rope_fwd(qkv, qk1, nh, nkv, hd, 1, qn, kn, cos, sin, positions=pos, kcache=kc1, vcache=vc1, slot=slot)
+    torch.cuda.synchronize()
+    assert torch.equal(qk0, qk1) and torch.equal(kc0, kc1) and torch.equal(vc0, vc1)
+    assert kc1.abs().sum().item() > 0 and vc1.abs().sum().item() > 0
+
+
 def test_gelu_epilogue_erf_accuracy_over_the_whole_range():
     """The GELU epilogue / kernels use a 1.5e-7-accurate erf (A&S 7.1.26): against torch's erf-GELU on a dense sweep of
     pre-activations (exact zeros, tiny, moderate, saturated tails, both signs) the bf16 results differ by at most one ulp."""
