@@ -114,6 +114,8 @@ enum {
                                              matrices beyond 64 MB: Qwen3-8B gate|up / down at batch 32) run on the tiled decode-row kernel —
                                              x and W through LDS-DMA in whole lines, x once per workgroup and K-tile, K split over the chip;
                                              0: split-K through the 256x256 kernel (round 2's path; A/B) */
+    MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK = 13, /* with DYNAMIC = 1: only launches of at least this many work items draw their tiles (default 257: every
+                                             launch of more than one round) */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };

@@ -1730,6 +1730,7 @@ struct GemmCtx {
     int rows_tiled = 1;            // 1 = M <= 64 forward GEMMs the weight-streaming kernel does not take run on the tiled decode-row kernel; 0 = split-K
                                    // through the 256x256 kernel (round 2's path; A/B)
     int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
+    int dynamic_min_work = 257;    // the dynamic fetch applies to launches of at least this many work items (default: more than one round)
     int small_split = 1;           // 1 = small grids with long contractions priced for split-K (see launch_cfg); 0 = round 2's rule (A/B)
     int dynamic = 0;               // 1 = plain 256x256 launches of more than one round draw their tiles (gemm256_kernel<DYN>): for GEMMs that
                                    // run beside a collective's kernels (ranks of a multi-GPU job)
@@ -1905,7 +1906,7 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
         // persistent: at most persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
         const int grid = grid256(c, nwork);
-        if (c.dynamic && !two_phase(c) && c.ws && nwork > 256 && nk / p.splits >= 8) {
+        if (c.dynamic && !two_phase(c) && c.ws && nwork > 256 && nwork >= c.dynamic_min_work && nk / p.splits >= 8) {
             // 256 resident blocks (32 per XCD label) that draw their tiles
             p.dyn_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c.ws) + DYN_CNT_OFF);
             c.last_cfg += 1;                                       // 513: the 256x256 kernel drawing its tiles
@@ -2192,6 +2193,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v == 0 || v == 1, "gemm rows_tiled: %ld not in {0,1}", v);
         c.rows_tiled = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK:
+        MOLLY_CHECK(v >= 257 && v <= (1 << 30), "gemm dynamic_min_work: %ld < 257", v);
+        c.dynamic_min_work = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_SKINNY:
         MOLLY_CHECK(v == 0 || v == 1, "gemm skinny: %ld not in {0,1}", v);
         c.skinny = (int)v;
@@ -2308,6 +2313,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_DYNAMIC: return c.dynamic;
     case MOLLY_GEMM_KEY_SMALL_SPLIT: return c.small_split;
     case MOLLY_GEMM_KEY_ROWS_TILED: return c.rows_tiled;
+    case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK: return c.dynamic_min_work;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

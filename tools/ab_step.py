@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--b", type=int, required=True)
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--set", nargs="*", default=[], help="other keys held fixed for both variants: key=value ...")
     args = ap.parse_args()
     import molly_amd
     from molly_amd import config as C
@@ -39,6 +40,9 @@ def main():
     def step():
         m.forward_backward(*a)
         opt.step(lr=3e-5)
+    for kv in args.set:
+        k, v = kv.split("=")
+        m._rt.gemm_ctx.set(k, int(v))
     for _ in range(2):
         step()
     res = {args.a: [], args.b: []}
