@@ -30,6 +30,7 @@ def main():
     finally:
         lib().call("molly_gemm_set_persistent_blocks", 256)
         lib().call("molly_gemm_force_tile", 0)
+        lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["dynamic"], 0)
     print(f"{a.cases} cases, {bad} failures")
     sys.exit(1 if bad else 0)
 
@@ -42,8 +43,10 @@ def _cases(a, rng, rnd, dev):
         tile = rng.choice([0, 0, 512])
         lib().call("molly_gemm_set_persistent_blocks", mode)
         lib().call("molly_gemm_force_tile", tile)
-        M = rng.choice([8, 64, 136, 256, 300, 512, 1000, 1026, 2048, 4096]) if form != "grp" else rng.choice([256, 512, 768, 1024])
-        N = rng.choice([64, 128, 200, 256, 520, 1024, 2048, 3000])
+        lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["dynamic"], rng.choice([0, 1]) if mode == 256 else 0)
+        # (M <= 64 in the nt form: the two decode-row kernels; 8192 x 3000+: more than one round, the dynamic tile fetch)
+        M = rng.choice([1, 8, 17, 33, 48, 64, 136, 256, 300, 512, 1000, 1026, 2048, 4096, 8192]) if form != "grp" else rng.choice([256, 512, 768, 1024])
+        N = rng.choice([64, 128, 200, 256, 520, 1024, 2048, 3000, 4096, 6144])
         if form in ("nt", "nn"):
             K = 64 * rng.choice([1, 2, 3, 5, 8, 17, 32, 64])
         else:
