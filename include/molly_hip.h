@@ -125,6 +125,13 @@ enum {
  * tail_out = silu(gate) * up [M][N / 2] (HF:models/qwen3/modeling_qwen3.py:76-83).  Same roundings as the separate kernels.
  * molly_gemm_rows_tail_supported: 1 when this context would run M x N x K that way (else use the GEMM and the kernel). */
 int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, int tail);
+/* tail 3 (a projection of its own because of its arguments): A W^T (+ bias) = the q | k | v row of one decode step -> q/k-norm + rotary
+ * (molly_norm_rope_cache_fwd's arithmetic), q | k to dst [M][ld_dst], k and v appended to the caches at slot[m]
+ * (HF:models/qwen3/modeling_qwen3.py:225-236; DynamicCache.update) — norm + qkv + rope + cache write as two launches instead of five. */
+int molly_gemm_rows_qkv_bf16_ctx(void* ctx, void* stream, const void* A, const void* W, const void* bias, int M, int N, int K, int lda,
+                                 int ldw, const void* q_norm_w, const void* k_norm_w, const float* cos, const float* sin,
+                                 const int* positions, float eps, int n_q_heads, int n_k_heads, int head_dim, void* dst, int ld_dst,
+                                 void* kcache, void* vcache, const int* slot, int ld_cache);
 int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
                                   int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int tail, const void* gain,
                                   float eps, void* tail_out, int ld_tail);

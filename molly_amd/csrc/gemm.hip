@@ -1713,6 +1713,92 @@ __global__ __launch_bounds__(256) void rows_tail_swiglu_kernel(const float* __re
     }
 }
 
+// qkv tail: the fused q | k | v projection of one decode step (one row per sample) -> per-head RMSNorm of the q and k heads, rotary,
+// q | k to `dst`, and the KV-cache append (k after norm + rotary, v as it is, to cache row slot[m]) — the arithmetic and roundings of
+// norm_rope_fwd_kernel (elementwise.hip; HF:models/qwen3/modeling_qwen3.py:225-236, 148-170) on the slice sums rounded to bf16 first,
+// as the GEMM's own bf16 output would be.  hd / 8 threads per head, each 4 consecutive (i, i + hd/2) pairs.
+struct QkvTail {
+    const bf16_t* qw; const bf16_t* kw; const float* cos; const float* sin; const int* pos;
+    bf16_t* dst; bf16_t* kc; bf16_t* vc; const int* slot;
+    int nq, nk, hd, ld_dst, ld_cache;
+    float eps;
+};
+__global__ __launch_bounds__(256) void rows_tail_qkv_kernel(const float* __restrict__ ws, int splits, int M, int N,
+                                                            const bf16_t* __restrict__ bias, QkvTail t) {
+    const int half = t.hd >> 1, tph = half >> 2;
+    const int i = (threadIdx.x % tph) * 4;
+    const long item = (long)blockIdx.x * (256 / tph) + threadIdx.x / tph;
+    const int nh = t.nq + 2 * t.nk;
+    const bool live = item < (long)M * nh;
+    const int m = live ? (int)(item / nh) : 0, head = live ? (int)(item % nh) : 0;
+    const long MN = (long)M * N;
+    float x1[4] = {0, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+    if (live) {
+        const float* src = ws + (size_t)m * N + head * t.hd + i;
+        f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + half);
+        for (int s2 = 1; s2 < splits; ++s2) {
+            a += *reinterpret_cast<const f32x4*>(src + (size_t)s2 * MN);
+            b += *reinterpret_cast<const f32x4*>(src + (size_t)s2 * MN + half);
+        }
+        if (bias) {
+            const u32x2 ba = *reinterpret_cast<const u32x2*>(bias + head * t.hd + i), bb = *reinterpret_cast<const u32x2*>(bias + head * t.hd + i + half);
+            a[0] += bflo(ba[0]); a[1] += bfhi(ba[0]); a[2] += bflo(ba[1]); a[3] += bfhi(ba[1]);
+            b[0] += bflo(bb[0]); b[1] += bfhi(bb[0]); b[2] += bflo(bb[1]); b[3] += bfhi(bb[1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x1[e] = bf2f(f2bf(a[e])); x2[e] = bf2f(f2bf(b[e])); }      // the projection's bf16 output
+    }
+    if (head >= t.nq + t.nk) {                              // a v head (whole groups of tph lanes): to the cache as it is
+        if (live) {
+            bf16_t* d = t.vc + (size_t)t.slot[m] * t.ld_cache + (head - t.nq - t.nk) * t.hd;
+            *reinterpret_cast<u32x2*>(d + i) = u32x2{pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
+            *reinterpret_cast<u32x2*>(d + i + half) = u32x2{pack_bf2(x2[0], x2[1]), pack_bf2(x2[2], x2[3])};
+        }
+        return;
+    }
+    const bool isq = head < t.nq;
+    const bf16_t* w = isq ? t.qw : t.kw;
+    if (w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
+        for (int o = tph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = rsqrtf(ss / (float)t.hd + t.eps);
+        const u32x2 wa = *reinterpret_cast<const u32x2*>(w + i), wb = *reinterpret_cast<const u32x2*>(w + i + half);
+        const float w1[4] = {bflo(wa[0]), bfhi(wa[0]), bflo(wa[1]), bfhi(wa[1])};
+        const float w2[4] = {bflo(wb[0]), bfhi(wb[0]), bflo(wb[1]), bfhi(wb[1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x1[e] = bf2f(f2bf(bf2f(f2bf(x1[e] * rstd)) * w1[e]));
+            x2[e] = bf2f(f2bf(bf2f(f2bf(x2[e] * rstd)) * w2[e]));
+        }
+    }
+    float y1[4], y2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+    if (t.cos) {
+        const int pos = t.pos ? t.pos[m] : 0;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(t.cos + (size_t)pos * half + i);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(t.sin + (size_t)pos * half + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y1[e] = x1[e] * c[e] - x2[e] * sn[e];
+            y2[e] = x2[e] * c[e] + x1[e] * sn[e];
+        }
+    }
+    if (live) {
+        const u32x2 o1 = u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])}, o2 = u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
+        bf16_t* d = t.dst + (size_t)m * t.ld_dst + head * t.hd;
+        *reinterpret_cast<u32x2*>(d + i) = o1;
+        *reinterpret_cast<u32x2*>(d + i + half) = o2;
+        if (!isq) {
+            bf16_t* c = t.kc + (size_t)t.slot[m] * t.ld_cache + (head - t.nq) * t.hd;
+            *reinterpret_cast<u32x2*>(c + i) = o1;
+            *reinterpret_cast<u32x2*>(c + i + half) = o2;
+        }
+    }
+}
+
 // ---- launch state.  Everything a launch decision reads lives in a CONTEXT: the tuning knobs, the scratch memory and the record
 // of the last configuration.  molly_gemm_ctx_* create and edit contexts; the *_ctx entry points launch through one.  The entry
 // points without a context use the calling thread's default context (thread_local: what one host thread sets, another never
@@ -1962,7 +2048,8 @@ inline bool rows_applicable(const GemmCtx& c, int M, int N, int K, int flags) {
            !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD));
 }
 int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
-                int lda, int ldb, int ldc, int ldres, int flags, int tail, const void* gain, float eps, void* tail_out, int ld_tail) {
+                int lda, int ldb, int ldc, int ldres, int flags, int tail, const void* gain, float eps, void* tail_out, int ld_tail,
+                const QkvTail* qt = nullptr) {
     RowsArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, nullptr,
                M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1};
     // K slices, priced in K-tile times of one workgroup (~0.75 us with two workgroups per CU): whole rounds of the 512 slots x
@@ -1995,6 +2082,10 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
     if (tail == 1) {
         hipLaunchKernelGGL(rows_tail_norm_kernel, dim3(M), dim3(1024), 0, st, q.ws, splits, M, N, (bf16_t*)C, ldc, bp, rp, ldres,
                            (const bf16_t*)gain, eps, (bf16_t*)tail_out, ld_tail);
+    } else if (tail == 3) {
+        const int hpb = 256 / (qt->hd / 8);
+        const long items = (long)M * (qt->nq + 2 * qt->nk);
+        hipLaunchKernelGGL(rows_tail_qkv_kernel, dim3((unsigned)((items + hpb - 1) / hpb)), dim3(256), 0, st, q.ws, splits, M, N, bp, *qt);
     } else if (tail == 2) {
         const long total = (long)M * (N / 8);
         hipLaunchKernelGGL(rows_tail_swiglu_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, st, q.ws, splits, M, N,
@@ -2251,7 +2342,7 @@ extern "C" int molly_gemm_bf16_ctx(void* ctx, void* stream, const void* A, const
 // norm; tail 2: SwiGLU of a gate|up output), in the launch that combines the K slices
 extern "C" int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, int tail) {
     const GemmCtx& c = ctx_of(ctx);
-    if (!(tail == 1 || tail == 2) || !rows_applicable(c, M, N, K, 0) || !c.ws) return 0;
+    if (!(tail >= 1 && tail <= 3) || !rows_applicable(c, M, N, K, 0) || !c.ws) return 0;
     if (tail == 1 && N > 8192) return 0;
     if (tail == 2 && N % 8 != 0) return 0;
     // a streaming-kernel shape stays there (its one launch is cheaper than slices + tail): the same rule as launch_gemm
@@ -2273,6 +2364,29 @@ extern "C" int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void
     MOLLY_CHECK(!(flags & MOLLY_GEMM_BIAS) || bias, "gemm rows tail: MOLLY_GEMM_BIAS without bias pointer");
     MOLLY_CHECK(!(flags & MOLLY_GEMM_RESIDUAL) || (res && ldres % 4 == 0), "gemm rows tail: bad residual");
     const int rc = launch_rows(c, (hipStream_t)stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, tail, gain, eps, tail_out, ld_tail);
+    if (rc) return rc;
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+// decode rows: the fused q | k | v projection with q/k-norm + rotary + the KV-cache append in the launch that combines the K slices
+// (molly_gemm_rows_tail_supported(ctx, M, N, K, 3) says whether this context runs the shape that way)
+extern "C" int molly_gemm_rows_qkv_bf16_ctx(void* ctx, void* stream, const void* A, const void* W, const void* bias, int M, int N, int K,
+                                            int lda, int ldw, const void* q_norm_w, const void* k_norm_w, const float* cos, const float* sin,
+                                            const int* positions, float eps, int n_q_heads, int n_k_heads, int head_dim, void* dst, int ld_dst,
+                                            void* kcache, void* vcache, const int* slot, int ld_cache) {
+    MOLLY_ENTER();
+    GemmCtx& c = ctx_of(ctx);
+    MOLLY_CHECK(molly_gemm_rows_tail_supported(ctx, M, N, K, 3), "gemm rows qkv: M=%d N=%d K=%d is not a shape of the tiled decode-row "
+                "kernel (ask molly_gemm_rows_tail_supported first)", M, N, K);
+    MOLLY_CHECK(head_dim >= 16 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0 && N == (n_q_heads + 2 * n_k_heads) * head_dim,
+                "gemm rows qkv: N=%d is not (%d + 2 x %d) heads of %d", N, n_q_heads, n_k_heads, head_dim);
+    MOLLY_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr) && (cos == nullptr) == (sin == nullptr), "gemm rows qkv: norm gains / cos, sin in pairs");
+    MOLLY_CHECK(dst && kcache && vcache && slot && lda % 8 == 0 && ldw % 8 == 0 && ld_dst % 4 == 0 && ld_cache % 4 == 0, "gemm rows qkv: pointers / strides");
+    QkvTail t{(const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, cos, sin, positions, (bf16_t*)dst, (bf16_t*)kcache, (bf16_t*)vcache, slot,
+              n_q_heads, n_k_heads, head_dim, ld_dst, ld_cache, eps};
+    const int rc = launch_rows(c, (hipStream_t)stream, A, W, nullptr, bias, nullptr, M, N, K, lda, ldw, 0, 0, bias ? MOLLY_GEMM_BIAS : 0, 3,
+                               nullptr, 0.f, nullptr, 0, &t);
     if (rc) return rc;
     MOLLY_LAUNCH_CHECK();
     return 0;

@@ -134,6 +134,7 @@ class GenerationSession:
         # the larger matrices) — residual + next RMSNorm behind o / down, SwiGLU behind gate|up — and the cache appends into norm + rope
         fuse = e.lora is None and os.environ.get("MOLLY_DECODE_FUSE", "1") != "0"
         H = x.shape[1]
+        f_qkv = fuse and ops.gemm_rows_tail_supported(B, nq + 2 * nkvd, H, "qkv")
         f_o = fuse and ops.gemm_rows_tail_supported(B, H, nq, "norm")
         f_gu = fuse and ops.gemm_rows_tail_supported(B, 2 * e.ff, H, "swiglu")
         f_dn = fuse and ops.gemm_rows_tail_supported(B, H, e.ff, "norm")
@@ -142,11 +143,17 @@ class GenerationSession:
             w = e.W[i]
             if not normed:
                 ops.rmsnorm_fwd(x, w["ln1"], eps, out=s["xn"])
-            ops.gemm_nt(s["xn"], w["qkv"], out=s["qkv"])
-            self._lora(i, "q_proj", s["xn"], s["qkv"][:, :nq])
-            self._lora(i, "k_proj", s["xn"], s["qkv"][:, nq:nq + nkvd])
-            self._lora(i, "v_proj", s["xn"], s["qkv"][:, nq + nkvd:])
-            if fuse:
+            if f_qkv:
+                ops.gemm_rows_qkv(s["xn"], w["qkv"], s["qk"], e.nh, e.nkv, e.hd, w["qn"], w["kn"], self.cos, self.sin, self.pos, eps,
+                                  self.kc[i].view(B * self.Tmax, nkvd), self.vc[i].view(B * self.Tmax, nkvd), self.slot)
+            else:
+                ops.gemm_nt(s["xn"], w["qkv"], out=s["qkv"])
+                self._lora(i, "q_proj", s["xn"], s["qkv"][:, :nq])
+                self._lora(i, "k_proj", s["xn"], s["qkv"][:, nq:nq + nkvd])
+                self._lora(i, "v_proj", s["xn"], s["qkv"][:, nq + nkvd:])
+            if f_qkv:
+                pass
+            elif fuse:
                 ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin, positions=self.pos, eps=eps,
                                   kcache=self.kc[i].view(B * self.Tmax, nkvd), vcache=self.vc[i].view(B * self.Tmax, nkvd), slot=self.slot)
             else:

@@ -138,7 +138,17 @@ def ensure_gemm_workspace(nbytes: int = 512 << 20, device="cuda"):
 
 def gemm_rows_tail_supported(M: int, N: int, K: int, tail: str) -> bool:
     """Would the current context run the decode-row GEMM M x N x K with `tail` ('norm' | 'swiglu') folded into its slab combine?"""
-    return bool(lib().query("molly_gemm_rows_tail_supported", _ctx(), M, N, K, {"norm": 1, "swiglu": 2}[tail]))
+    return bool(lib().query("molly_gemm_rows_tail_supported", _ctx(), M, N, K, {"norm": 1, "swiglu": 2, "qkv": 3}[tail]))
+
+
+def gemm_rows_qkv(x, w, dst, nq, nk, hd, qw, kw, cos, sin, positions, eps, kcache, vcache, slot, bias=None):
+    """Decode rows: q | k | v = x w^T, then q/k-norm + rotary -> dst [M, (nq + nk) hd] and the KV-cache append, in the launch that
+    combines the K slices."""
+    M, K = x.shape
+    N = w.shape[0]
+    lib().call("molly_gemm_rows_qkv_bf16_ctx", _ctx(), _stream(), x, w, bias, M, N, K, x.stride(0), w.stride(0), qw, kw, cos, sin,
+               positions, float(eps), nq, nk, hd, dst, dst.stride(0), kcache, vcache, slot, kcache.stride(0))
+    return dst
 
 
 def gemm_rows_norm(x, w, out, norm_w, eps, norm_out, res=None, bias=None):

@@ -697,6 +697,38 @@ def test_norm_rope_with_cache_append_equals_the_three_launches():
     assert kc1.abs().sum().item() > 0 and vc1.abs().sum().item() > 0
 
 
+def test_gemm_decode_rows_qkv_tail_equals_the_separate_launches():
+    """Decode step: fused q | k | v projection -> q/k-norm -> rotary -> KV-cache append as GEMM + ONE tail launch
+    (molly_gemm_rows_qkv_bf16_ctx; HF:models/qwen3/modeling_qwen3.py:225-236) — bit-identical q | k rows and cache rows to
+    gemm_nt + norm_rope_fwd + the two copy_rows."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, nh, nkv, hd, H, Tmax = 32, 32, 8, 128, 4096, 24
+    nq, nkvd = nh * hd, nkv * hd
+    rnd = lambda *s, sc=1.0: ((torch.rand(*s, device="cuda", generator=g) * 2 - 1) * sc).to(BF)
+    x, w = rnd(B, H), rnd(nq + 2 * nkvd, H, sc=H ** -0.5 * 4)
+    qn, kn = (rnd(hd) * 0.5 + 1.0).to(BF), (rnd(hd) * 0.5 + 1.0).to(BF)
+    cos = torch.rand(64, hd // 2, device="cuda", generator=g)
+    sin = torch.rand(64, hd // 2, device="cuda", generator=g)
+    pos = torch.randint(0, Tmax, (B,), generator=torch.Generator().manual_seed(1)).int().cuda()
+    slot = (torch.arange(B, device="cuda", dtype=torch.int32) * Tmax + pos).int()
+    c = ops.GemmContext()
+    c.ensure_workspace(64 << 20)
+    with ops.use_gemm_context(c):
+        assert ops.gemm_rows_tail_supported(B, nq + 2 * nkvd, H, "qkv")
+        qkv = ops.gemm_nt(x, w)
+        qk0 = torch.empty(B, nq + nkvd, dtype=BF, device="cuda")
+        kc0 = torch.zeros(B * Tmax, nkvd, dtype=BF, device="cuda"); vc0 = torch.zeros_like(kc0)
+        ops.norm_rope_fwd(qkv, qk0, nh, nkv, hd, 1, qn, kn, cos, sin, positions=pos)
+        ops.copy_rows(qk0[:, nq:], kc0, B, dst_idx32=slot)
+        ops.copy_rows(qkv[:, nq + nkvd:], vc0, B, dst_idx32=slot)
+        qk1 = torch.empty_like(qk0)
+        kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+        ops.gemm_rows_qkv(x, w, qk1, nh, nkv, hd, qn, kn, cos, sin, pos, 1e-6, kc1, vc1, slot)
+    torch.cuda.synchronize()
+    assert torch.equal(qk0, qk1) and torch.equal(kc0, kc1) and torch.equal(vc0, vc1)
+    assert kc1.abs().sum().item() > 0 and vc1.abs().sum().item() > 0
+
+
 def test_gelu_epilogue_erf_accuracy_over_the_whole_range():
     """The GELU epilogue / kernels use a 1.5e-7-accurate erf (A&S 7.1.26): against torch's erf-GELU on a dense sweep of
     pre-activations (exact zeros, tiny, moderate, saturated tails, both signs) the bf16 results differ by at most one ulp."""
