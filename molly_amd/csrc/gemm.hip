@@ -2043,6 +2043,16 @@ int resolve_zero_page(const bf16_t** out) {
 // ---- the tiled decode-row kernel's launcher.  tail: 0 none | 1 RMSNorm of the output rows (gain, eps -> tail_out [M][N]) | 2 SwiGLU
 // of an output that is [gate | up] (-> tail_out [M][N / 2]); a tail runs inside the slab combine, so it forces >= 2 K slices.
 // (not the lm_head: with >= 512 column tiles the 128x128 kernel streams it at 5.0 TB/s, this one at 4.8)
+// which of the two decode-row kernels takes an M <= 64 forward GEMM: the register-streaming one wherever launches, not bytes, set the
+// time (matrices up to 9 M elements; M <= 16 on matrices of at most 4,096 rows), the tiled one everywhere else it applies
+// (tools/bench_decode_gemm.py, gpurun_out/r03/rows_bench3.log) — ONE rule for launch_gemm and molly_gemm_rows_tail_supported
+inline bool rows_applicable(const GemmCtx& c, int M, int N, int K, int flags);
+inline bool streaming_rows(const GemmCtx& c, int M, int N, int K, int flags) {
+    if (!(M <= 64 && c.skinny && c.force_tile == 0 && K % 256 == 0 && N % 4 == 0 && N >= 256) ||
+        (flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) return false;
+    if (!rows_applicable(c, M, N, K, flags)) return M <= 16 || (long)N * K <= (32L << 20);     // (round 3's first rule, where the tiled kernel is off)
+    return (long)N * K <= (9L << 20) || (M <= 16 && N <= 4096);
+}
 inline bool rows_applicable(const GemmCtx& c, int M, int N, int K, int flags) {
     return M <= 64 && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < 65536 &&
            !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD));
@@ -2128,9 +2138,7 @@ int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, 
     // 21.7 / 18.8) and any matrix at M <= 16 (8B gate|up at M = 8: 4.5 against 4.0 TB/s).  The 100-200 MB matrices at M = 32 stay on
     // the tile kernel (3.1-3.6 TB/s there, 5.0 on the 1.2 GB lm_head): x enters through the same 64-byte request path as W, and
     // at 32 rows it is the larger stream unless a wave keeps 64 rows of W — which leaves too few waves for the 4096-row matrices.
-    if (!at && !bt && M <= 64 && c.skinny && c.force_tile == 0 && K % 256 == 0 && N % 4 == 0 && N >= 256 &&
-        ((long)N * K <= (9L << 20) || (M <= 16 && N <= 4096) || !c.rows_tiled || K % 64 != 0 || N < 128) &&
-        (M <= 16 || (long)N * K <= (32L << 20)) && !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) {
+    if (!at && !bt && streaming_rows(c, M, N, K, flags)) {
         SkinnyArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, M, N, K, lda, ldb, ldc, ldres, flags};
         // W rows per wave (16 NT) and K parts per workgroup (KW): as much reuse of x as still leaves >= ~1000 waves on the chip
         const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4;
@@ -2345,9 +2353,7 @@ extern "C" int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, in
     if (!(tail >= 1 && tail <= 3) || !rows_applicable(c, M, N, K, 0) || !c.ws) return 0;
     if (tail == 1 && N > 8192) return 0;
     if (tail == 2 && N % 8 != 0) return 0;
-    // a streaming-kernel shape stays there (its one launch is cheaper than slices + tail): the same rule as launch_gemm
-    if (c.skinny && K % 256 == 0 && N >= 256 && ((long)N * K <= (9L << 20) || (M <= 16 && N <= 4096)) &&
-        (M <= 16 || (long)N * K <= (32L << 20))) return 0;
+    if (streaming_rows(c, M, N, K, 0)) return 0;          // a streaming-kernel shape stays there: its one launch is cheaper than slices + tail
     return (size_t)2 * M * N * sizeof(float) <= ws_slab_bytes(c) ? 1 : 0;
 }
 extern "C" int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias,

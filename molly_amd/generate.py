@@ -68,19 +68,22 @@ class GenerationSession:
             self._lora(i, "q_proj", a["xn"], a["qkv"][:, :nq])
             self._lora(i, "k_proj", a["xn"], a["qkv"][:, nq:nq + nk_])
             self._lora(i, "v_proj", a["xn"], a["qkv"][:, nq + nk_:])
+            # q/k-norm + rotary + the cache write of the whole prompt (row b * Tmax + t) in one launch
             ops.norm_rope_fwd(a["qkv"], a["qk"], e.nh, e.nkv, e.hd, T, w["qn"], w["kn"], self.cos, self.sin,
-                              positions=positions, eps=e.cfg.rms_norm_eps)
-            ops.copy_rows(a["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B * T, dst_idx32=rows)
-            ops.copy_rows(a["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B * T, dst_idx32=rows)
+                              positions=positions, eps=e.cfg.rms_norm_eps,
+                              kcache=self.kc[i].view(B * self.Tmax, nkvd), vcache=self.vc[i].view(B * self.Tmax, nkvd), slot=rows)
             ops.attn_fwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, e.nqk:], B, T, e.nh, e.nkv, e.hd, e.hd ** -0.5, True,
                          lo, hi, out=a["attn"], lse=False)
             ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=x)
             self._lora(i, "o_proj", a["attn"], a["x2"])
             ops.rmsnorm_fwd(a["x2"], w["ln2"], e.cfg.rms_norm_eps, out=a["xn2"])
-            ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
-            self._lora(i, "gate_proj", a["xn2"], a["gu"][:, :e.ff])
-            self._lora(i, "up_proj", a["xn2"], a["gu"][:, e.ff:])
-            ops.swiglu_fwd(a["gu"], out=a["act"])
+            if e.fused_swiglu:                                              # (no live adapters) SwiGLU in the gate|up GEMM's epilogue, as in training
+                ops.gemm_gate_up_swiglu(a["xn2"], w["gu"], a["gu"], a["act"])
+            else:
+                ops.gemm_nt(a["xn2"], w["gu"], out=a["gu"])
+                self._lora(i, "gate_proj", a["xn2"], a["gu"][:, :e.ff])
+                self._lora(i, "up_proj", a["xn2"], a["gu"][:, e.ff:])
+                ops.swiglu_fwd(a["gu"], out=a["act"])
             ops.gemm_nt(a["act"], w["down"], out=e.x_out, res=a["x2"])
             self._lora(i, "down_proj", a["act"], e.x_out)
             x = e.x_out
