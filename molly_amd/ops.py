@@ -71,6 +71,12 @@ class GemmContext:
         import os
         if os.environ.get("MOLLY_GEMM_STREAMK") is not None:       # A/B and bisection knob: 0 off, 1 cost model (default), 2 wherever able
             self.set("streamk", int(os.environ["MOLLY_GEMM_STREAMK"]))
+        # test mode: every context launches the 256x256 GEMM the way a rank of a multi-GPU job does (dyn: resident blocks that draw
+        # their tiles, the N > 1 default; 0 / -t: round 2's shapes) — `MOLLY_TEST_GEMM_BLOCKS=dyn pytest -m gpu` runs the suite that way
+        mode = os.environ.get("MOLLY_TEST_GEMM_BLOCKS")
+        if mode:
+            self.set("persistent_blocks", 256 if mode == "dyn" else int(mode))
+            self.set("dynamic", 1 if mode == "dyn" else 0)
 
     def set(self, key: str, value: int):
         lib().call("molly_gemm_ctx_set", self.handle, GEMM_KEYS[key], int(value))

@@ -28,12 +28,16 @@ def _release_gpu_memory(request):
 
 @pytest.fixture(scope="session", autouse=True)
 def _gemm_launch_shape():
-    """MOLLY_TEST_GEMM_BLOCKS=-3 (or 0) runs the whole GPU suite with the 256x256 GEMM launched the way Zero2Optimizer launches it at
-    N > 1 (blocks of at most three tiles / one tile per block) instead of one persistent block per CU."""
+    """MOLLY_TEST_GEMM_BLOCKS=dyn (or -3, 0) runs the whole GPU suite with the 256x256 GEMM launched the way a rank of a multi-GPU job
+    launches it (resident blocks that draw their tiles: the N > 1 default; or round 2's blocks of three tiles / one tile per block)
+    instead of the static walk: every GemmContext reads the variable (ops.GemmContext), this fixture sets the thread's default one."""
     mode = os.environ.get("MOLLY_TEST_GEMM_BLOCKS")
-    if mode is not None and torch.cuda.is_available():
+    if mode and torch.cuda.is_available():
+        from molly_amd import ops
         from molly_amd._lib import lib
-        lib().call("molly_gemm_set_persistent_blocks", int(mode))
+        ops.ensure_gemm_workspace(1 << 28)
+        lib().call("molly_gemm_set_persistent_blocks", 256 if mode == "dyn" else int(mode))
+        lib().call("molly_gemm_ctx_set", None, ops.GEMM_KEYS["dynamic"], 1 if mode == "dyn" else 0)
     yield
 
 
