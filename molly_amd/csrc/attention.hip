@@ -738,40 +738,36 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     }
 }
 
-// the head-split pass's second half: block = (batch, kv head, key block) like the unsplit dK/dV kernel, wave = its 32 keys; adds the
-// group's images in head order, then the same row store (dK scaled, dV not)
+// the head-split pass's second half: one WAVE per (batch, kv head, key block, 32 keys, dK | dV) — 100 MB of images at one sample
+// per GPU want thousands of waves with loads in flight, not 192 workgroups (41 -> ~20 us at B = 1, T = 3072) — adds the group's
+// images in head order, then the same row store as the unsplit kernel (dK scaled, dV not)
 template <int HD>
-__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(64) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
     constexpr int ND = HD / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t slab_all[4 * 32 * (HD + 8)];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kb = blockIdx.y, kvh = blockIdx.x % p.nkv, b = blockIdx.x / p.nkv;
+    __shared__ __attribute__((aligned(16))) bf16_t slab[32 * (HD + 8)];
+    const int lane = threadIdx.x;
+    const int wave = blockIdx.x & 3, bx = blockIdx.x >> 2, which = blockIdx.z;        // which: 0 dV, 1 dK
+    const int kb = blockIdx.y, kvh = bx % p.nkv, b = bx / p.nkv;
     const int group = p.nh / p.nkv;
-    const size_t nimg = (size_t)gridDim.x * group * gridDim.y;
+    const size_t nimg = (size_t)(gridDim.x >> 2) * group * gridDim.y;
     const int key0w = kb * 128 + wave * 32;
     if (key0w >= p.T) return;
-#pragma unroll 1
-    for (int which = 0; which < 2; ++which) {                    // 0: dV, 1: dK
-        const float* src = p.part + (((size_t)blockIdx.x * gridDim.y + kb) * group + (which ? nimg : 0)) * (4 * ND * 16 * 64) +
-                           (size_t)wave * (ND * 16 * 64) + lane * 4;
-        f32x16 acc[ND];
+    const float* src = p.part + (((size_t)bx * gridDim.y + kb) * group + (which ? nimg : 0)) * (4 * ND * 16 * 64) +
+                       (size_t)wave * (ND * 16 * 64) + lane * 4;
+    f32x16 acc[ND];
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(src + (d * 4 + g4) * 256);
-                for (int g = 1; g < group; ++g) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(src + (size_t)g * (4 * ND * 16 * 64) + (d * 4 + g4) * 256);
-                    v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
-                }
-                acc[d][4 * g4] = v[0]; acc[d][4 * g4 + 1] = v[1]; acc[d][4 * g4 + 2] = v[2]; acc[d][4 * g4 + 3] = v[3];
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + (d * 4 + g4) * 256);
+            for (int g = 1; g < group; ++g) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(src + (size_t)g * (4 * ND * 16 * 64) + (d * 4 + g4) * 256);
+                v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
             }
-        bf16_t* slab = slab_all + wave * 32 * (HD + 8);
-        if (which) store_rows<HD, ND>(slab, acc, p.scale, p.dK + ((size_t)b * p.T + key0w) * p.lddk + kvh * HD, p.lddk, p.T - key0w, lane);
-        else store_rows<HD, ND>(slab, acc, 1.0f, p.dV + ((size_t)b * p.T + key0w) * p.lddv + kvh * HD, p.lddv, p.T - key0w, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the slab is the wave's own: its reads are done before the next round's writes
-    }
+            acc[d][4 * g4] = v[0]; acc[d][4 * g4 + 1] = v[1]; acc[d][4 * g4 + 2] = v[2]; acc[d][4 * g4 + 3] = v[3];
+        }
+    if (which) store_rows<HD, ND>(slab, acc, p.scale, p.dK + ((size_t)b * p.T + key0w) * p.lddk + kvh * HD, p.lddk, p.T - key0w, lane);
+    else store_rows<HD, ND>(slab, acc, 1.0f, p.dV + ((size_t)b * p.T + key0w) * p.lddv + kvh * HD, p.lddv, p.T - key0w, lane);
 }
 
 }  // namespace
@@ -871,7 +867,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
             const dim3 gs(n_heads * B, cdiv(T, 128));
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, p);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, p);
-            hipLaunchKernelGGL(attn_dkv_reduce_kernel<128>, gk, dim3(256), 0, st, p);
+            hipLaunchKernelGGL(attn_dkv_reduce_kernel<128>, dim3(gk.x * 4, gk.y, 2), dim3(64), 0, st, p);
         } else if (one_pass) {
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk, dim3(256), lds_dkv, st, p);
         } else {
