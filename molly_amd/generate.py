@@ -146,24 +146,23 @@ class GenerationSession:
             w = e.W[i]
             if not normed:
                 ops.rmsnorm_fwd(x, w["ln1"], eps, out=s["xn"])
-            if f_qkv:
+            kc_i, vc_i = self.kc[i].view(B * self.Tmax, nkvd), self.vc[i].view(B * self.Tmax, nkvd)
+            if f_qkv:                                   # projection + q/k-norm + rotary + cache append: GEMM and one tail launch
                 ops.gemm_rows_qkv(s["xn"], w["qkv"], s["qk"], e.nh, e.nkv, e.hd, w["qn"], w["kn"], self.cos, self.sin, self.pos, eps,
-                                  self.kc[i].view(B * self.Tmax, nkvd), self.vc[i].view(B * self.Tmax, nkvd), self.slot)
+                                  kc_i, vc_i, self.slot)
             else:
                 ops.gemm_nt(s["xn"], w["qkv"], out=s["qkv"])
                 self._lora(i, "q_proj", s["xn"], s["qkv"][:, :nq])
                 self._lora(i, "k_proj", s["xn"], s["qkv"][:, nq:nq + nkvd])
                 self._lora(i, "v_proj", s["xn"], s["qkv"][:, nq + nkvd:])
-            if f_qkv:
-                pass
-            elif fuse:
-                ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin, positions=self.pos, eps=eps,
-                                  kcache=self.kc[i].view(B * self.Tmax, nkvd), vcache=self.vc[i].view(B * self.Tmax, nkvd), slot=self.slot)
-            else:
-                ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin,
-                                  positions=self.pos, eps=eps)
-                ops.copy_rows(s["qk"][:, nq:], self.kc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
-                ops.copy_rows(s["qkv"][:, e.nqk:], self.vc[i].view(B * self.Tmax, nkvd), B, dst_idx32=self.slot)
+                if fuse:
+                    ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin, positions=self.pos,
+                                      eps=eps, kcache=kc_i, vcache=vc_i, slot=self.slot)
+                else:
+                    ops.norm_rope_fwd(s["qkv"], s["qk"], e.nh, e.nkv, e.hd, 1, w["qn"], w["kn"], self.cos, self.sin,
+                                      positions=self.pos, eps=eps)
+                    ops.copy_rows(s["qk"][:, nq:], kc_i, B, dst_idx32=self.slot)
+                    ops.copy_rows(s["qkv"][:, e.nqk:], vc_i, B, dst_idx32=self.slot)
             ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
                             e.hd ** -0.5, kv_len_hint=self.Tmax, workspace=self.dec_ws)
             if f_o:
