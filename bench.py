@@ -525,7 +525,11 @@ def main(argv=None):
                  (True, True): "TN gemm256_kernel<true,true>"}
         def klass(kcfg, lay):
             # cfg = 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems of a grouped launch)
-            key = names[lay] if kcfg % 1000 in (512, 513) else "gemm_kernel<...,128,2,64> (a side narrower than a tile)"
+            key = (names[lay] if kcfg % 1000 in (512, 513) else
+                   "gemm_rows_kernel (64-row tiles: small grids at <= 1,024 rows)" if kcfg % 1000 == 32 else
+                   "gemm_skinny_kernel (decode rows)" if kcfg % 1000 == 16 else "gemm_kernel<...,128,2,64> (a side narrower than a tile)")
+            if kcfg % 1000 in (16, 32):
+                return key
             if kcfg >= 100000:
                 key += f" grouped x{kcfg // 100000} (a layer's weight gradients in one launch)"
             elif kcfg // 1000 >= 50:

@@ -116,6 +116,8 @@ enum {
                                              0: split-K through the 256x256 kernel (round 2's path; A/B) */
     MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK = 13, /* with DYNAMIC = 1: only launches of at least this many work items draw their tiles (default 257: every
                                              launch of more than one round) */
+    MOLLY_GEMM_KEY_ROWS_MAX_M = 14,       /* largest M (64..8192) for which a forward GEMM whose 128x128 grid has at most 192 blocks runs as 64-row
+                                             tiles of the tiled decode-row kernel (the encoders' projections at 512 / 1024 rows) */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };

@@ -1466,6 +1466,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs p) {
 struct RowsArgs {
     const bf16_t* X; const bf16_t* W; void* C; const bf16_t* bias; const bf16_t* res; float* ws;
     int M, N, K, ldx, ldw, ldc, ldres, flags, tiles_n, splits;
+    int tiles_m;               // 16 MT-row tiles of x (1 for decode rows; > 1: small grids of the encoders at one sample per GPU)
 };
 
 template <int MT, int NSTAGE>
@@ -1477,8 +1478,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);          // [stage][x tile | W tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tn = blockIdx.x % p.tiles_n, sp = blockIdx.x / p.tiles_n;
-    const int n0 = tn * 128;
+    // (column tile fastest, then row tile, then K slice: neighbours in the launch order share the x tile and stream different W tiles)
+    const int tn = blockIdx.x % p.tiles_n, tm = (blockIdx.x / p.tiles_n) % p.tiles_m, sp = blockIdx.x / (p.tiles_n * p.tiles_m);
+    const int n0 = tn * 128, m0 = tm * BM;
     const int nk_all = p.K / BK;
     const int kt0 = (int)((long)nk_all * sp / p.splits), nk = (int)((long)nk_all * (sp + 1) / p.splits) - kt0;
 
@@ -1490,7 +1492,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
 
     auto stage = [&](int t, int slot) {
         bf16_t* dst = smem + slot * STAGE;
-        stage_kc<BM, 4, BK, true>(p.X, p.ldx, 0, p.M, (kt0 + t) * BK, dst, wave, lane);
+        stage_kc<BM, 4, BK, true>(p.X, p.ldx, m0, p.M, (kt0 + t) * BK, dst, wave, lane);
         stage_kc<128, 4, BK, true>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane);
     };
     // s_waitcnt vmcnt(k * NLOAD): everything but the k youngest stages has landed (k = 0 .. NSTAGE - 2)
@@ -1532,7 +1534,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
     // ---- lane owns C[m = 16 i + fr][n = n0 + 32 wave + 16 j + 4 fq + 0..3]
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int m = i * 16 + fr;
+        const int m = m0 + i * 16 + fr;
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1813,6 +1815,8 @@ struct GemmCtx {
     int small3 = 0;                // 1 = 128x128 grids of at most one tile per CU on the 3-stage ring; 0 (default): the 2-stage loop — measured equal
                                    // (tools/bench_esm_gemm.py: 22.4 / 24.4 / 27.5 us against 21.8 / 22.7 / 27.5 at M = 1024): these launches are not
                                    // bound by the LDS-DMA drain
+    int rows_max_m = 1024;         // largest M the tiled decode-row kernel takes (64-row tiles; > 64 only where the 128x128 grid has <= 192 blocks:
+                                   // 512 rows: 20.8 -> 15.8 us qkv, 30.0 -> 24.4 ffn2; at 2048 rows it loses to split-K: tools/bench_esm_gemm.py)
     int rows_tiled = 1;            // 1 = M <= 64 forward GEMMs the weight-streaming kernel does not take run on the tiled decode-row kernel; 0 = split-K
                                    // through the 256x256 kernel (round 2's path; A/B)
     int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
@@ -2054,14 +2058,18 @@ inline bool streaming_rows(const GemmCtx& c, int M, int N, int K, int flags) {
     return (long)N * K <= (9L << 20) || (M <= 16 && N <= 4096);
 }
 inline bool rows_applicable(const GemmCtx& c, int M, int N, int K, int flags) {
-    return M <= 64 && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < 65536 &&
+    // (M > 64, up to the context's rows_max_m: grids that leave most CUs with less than one 128x128 block — the encoders' projections
+    // at one sample per GPU — as 64-row tiles of this kernel: four times the workgroups, two per CU)
+    const bool small_m = M <= 64 || (M <= c.rows_max_m && (long)cdiv(M, 128) * cdiv(N, 128) <= 192);
+    return small_m && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < 65536 &&
            !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD));
 }
 int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
                 int lda, int ldb, int ldc, int ldres, int flags, int tail, const void* gain, float eps, void* tail_out, int ld_tail,
                 const QkvTail* qt = nullptr) {
     RowsArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, nullptr,
-               M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1};
+               M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1, M <= 64 ? 1 : cdiv(M, 64)};
+    const int ntile = q.tiles_n * q.tiles_m;
     // K slices, priced in K-tile times of one workgroup (~0.75 us with two workgroups per CU): whole rounds of the 512 slots x
     // (slice length + ring fill) + the reduce launch and its slab traffic; slices of >= 4 K-tiles, within the scratch
     const int nk = K / 64;
@@ -2069,7 +2077,7 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
     double best_cost = 1e30;
     for (int sp = tail ? 2 : 1; sp <= 32 && (nk / sp >= 4 || (tail && sp == 2)); ++sp) {
         if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_slab_bytes(c)) break;
-        const double cost = cdiv(q.tiles_n * sp, 512) * ((double)nk / sp + 3.0) +
+        const double cost = cdiv(ntile * sp, 512) * ((double)nk / sp + 3.0) +
                             (sp > 1 ? (5.0 + 8.0 * sp * M * N / 5e6) / 0.75 : 0.0);
         if (cost < best_cost) { best_cost = cost; splits = sp; }
     }
@@ -2085,8 +2093,8 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
         (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * 64 * 2);
         rows_attr = true;
     }
-    if (M <= 32) hipLaunchKernelGGL((gemm_rows_kernel<2, 4>), dim3(q.tiles_n * splits), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
-    else hipLaunchKernelGGL((gemm_rows_kernel<4, 3>), dim3(q.tiles_n * splits), dim3(256), 3 * (64 + 128) * 64 * 2, st, q);
+    if (M <= 32) hipLaunchKernelGGL((gemm_rows_kernel<2, 4>), dim3(ntile * splits), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
+    else hipLaunchKernelGGL((gemm_rows_kernel<4, 3>), dim3(ntile * splits), dim3(256), 3 * (64 + 128) * 64 * 2, st, q);
     const bf16_t* bp = (flags & MOLLY_GEMM_BIAS) ? (const bf16_t*)bias : nullptr;
     const bf16_t* rp = (flags & MOLLY_GEMM_RESIDUAL) ? (const bf16_t*)res : nullptr;
     if (tail == 1) {
@@ -2292,6 +2300,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v == 0 || v == 1, "gemm rows_tiled: %ld not in {0,1}", v);
         c.rows_tiled = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_ROWS_MAX_M:
+        MOLLY_CHECK(v >= 64 && v <= 8192, "gemm rows_max_m: %ld not in 64..8192", v);
+        c.rows_max_m = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK:
         MOLLY_CHECK(v >= 257 && v <= (1 << 30), "gemm dynamic_min_work: %ld < 257", v);
         c.dynamic_min_work = (int)v;
@@ -2434,6 +2446,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_SMALL_SPLIT: return c.small_split;
     case MOLLY_GEMM_KEY_ROWS_TILED: return c.rows_tiled;
     case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK: return c.dynamic_min_work;
+    case MOLLY_GEMM_KEY_ROWS_MAX_M: return c.rows_max_m;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

@@ -638,6 +638,38 @@ def test_gemm_decode_rows_tiled_kernel(M, N, K):
         assert torch.equal(outw[:, :N], wide[:, 64:].float() @ w.float().t()) and outw[:, N:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("M", [100, 512, 1000])
+@pytest.mark.parametrize("N,K", [(1280, 1280), (1280, 5120), (3840, 1280), (5120, 1280)])
+def test_gemm_small_grids_as_64_row_tiles(M, N, K):
+    """Encoder projections at one sample per GPU (HF:models/esm/modeling_esm.py:350-463 at 512 / 1,000 rows: BASELINE configs 3 / 4 / 5):
+    grids of at most 192 128x128 blocks run as 64-row tiles of the tiled decode-row kernel (MOLLY_GEMM_KEY_ROWS_MAX_M) — exact on
+    small integers with the encoders' epilogues, ragged last row tile, K slices or not."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    ints = lambda *s: torch.randint(-3, 4, s, device="cuda", generator=g).to(BF)
+    x, w, bias, res = ints(M, K), ints(N, K), ints(N), ints(M, N)
+    ref = x.float() @ w.float().t()
+    c = ops.GemmContext()
+    c.ensure_workspace(64 << 20)
+    small = -(-M // 128) * -(-N // 128) <= 192
+    with ops.use_gemm_context(c):
+        out = ops.gemm_nt(x, w, out_dtype=torch.float32)
+        assert (c.get("last_config") % 1000 == 32) == small, (c.get("last_config"), small)
+        assert torch.equal(out, ref)
+        assert torch.equal(ops.gemm_nt(x, w, bias=bias, res=res, out_dtype=torch.float32), ref + bias.float() + res.float())
+        acc = ints(M, N).float()
+        want = acc + ref
+        ops.gemm_nt(x, w, out=acc, accumulate=True)
+        assert torch.equal(acc, want)
+        got = ops.gemm_nt(x, w, bias=bias, gelu=True)
+        wg = torch.nn.functional.gelu(ref + bias.float())
+        assert (got.float() - wg).abs().max().item() <= 2 ** -7 * wg.abs().max().item()
+    off = ops.GemmContext()
+    off.ensure_workspace(64 << 20)
+    off.set("rows_max_m", 64)
+    with ops.use_gemm_context(off):
+        assert torch.equal(ops.gemm_nt(x, w, out_dtype=torch.float32), ref) and off.get("last_config") % 1000 != 32
+
+
 @pytest.mark.parametrize("M", [17, 32, 64])
 def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
     """The decode step's launches folded into the decode-row GEMM's slab combine (molly_gemm_rows_tail_bf16_ctx): residual + RMSNorm

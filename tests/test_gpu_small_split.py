@@ -14,6 +14,7 @@ def _ctx(small_split):
     c.ensure_workspace(256 << 20)
     c.set("small_split", small_split)
     c.set("streamk", 0)
+    c.set("rows_max_m", 64)                  # (up to 1,024 rows the 64-row tiles of the decode-row kernel take these grids by default: test_gpu_kernels.py)
     return c
 
 

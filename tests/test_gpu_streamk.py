@@ -16,6 +16,7 @@ def _ctx(**knobs):
     c = ops.GemmContext()
     c.ensure_workspace(0)
     knobs.setdefault("streamk", 2)            # 2 = stream-K wherever it is able to run (the default, 1, asks the cost model)
+    knobs.setdefault("rows_max_m", 64)        # (small grids at <= 1,024 rows otherwise run as 64-row tiles of the decode-row kernel)
     for k, v in knobs.items():
         c.set(k, v)
     return c

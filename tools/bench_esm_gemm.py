@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The encoders' forward GEMMs (ESM-2 650M / NT-500M widths) with their real epilogues at the row counts the BASELINE configs
 give them: M = 4096 (C2: 8 samples x 512 residues), 1024 and 512 (C3 / C4 / C5 at B = 1).  Columns: the launcher's default, the
-default without the priced split-K of small long-K grids (round 2's rule), and the 128x128 kernel forced (MOLLY_3STAGE=1: its
+tiled decode-row kernel taking the small grids as 64-row tiles (MOLLY_GEMM_KEY_ROWS_MAX_M), and the 128x128 kernel forced (MOLLY_3STAGE=1: its
 3-stage ring, a knob measured equal).  python tools/bench_esm_gemm.py"""
 import os
 import sys
@@ -20,10 +20,11 @@ def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
-    ctxs = {"default": ops.GemmContext(), "small_split 0": ops.GemmContext(), "128x128": ops.GemmContext()}
+    ctxs = {"default": ops.GemmContext(), "64-row tiles": ops.GemmContext(), "128x128": ops.GemmContext()}
     for c in ctxs.values():
         c.ensure_workspace(256 << 20)
-    ctxs["small_split 0"].set("small_split", 0)
+    ctxs["default"].set("rows_max_m", 64)            # (first column: without the 64-row tiles, which are the default up to 1,024 rows)
+    ctxs["64-row tiles"].set("rows_max_m", 8192)
     ctxs["128x128"].set("force_tile", 128); ctxs["128x128"].set("small3", int(os.environ.get("MOLLY_3STAGE", "0")))
     for M in (int(x) for x in os.environ.get("M", "4096,1024,512").split(",")):
         print(f"M = {M}")
