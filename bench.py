@@ -585,6 +585,7 @@ def main(argv=None):
                                "(identical loss/gradients).  executed_* count the FLOPs the kernels ran; model_* credit the full "
                                "algorithmic count of SURVEY 8d (lm_head on every row)"},
             "step_ms_p50": round(statistics.median(step_ms), 2),
+            "step_ms": [round(x, 1) for x in step_ms],      # per step, HIP events (ms_per_step is the wall clock over all of them / steps)
             "executed_tflops_per_gpu": round(exec_step / sps / 1e12, 1),
             "mfma_roofline_frac_step_executed": round(exec_step / sps / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "model_tflops_per_gpu": round(flops_step / sps / 1e12, 1),
