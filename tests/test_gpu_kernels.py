@@ -670,6 +670,38 @@ def test_gemm_small_grids_as_64_row_tiles(M, N, K):
         assert torch.equal(ops.gemm_nt(x, w, out_dtype=torch.float32), ref) and off.get("last_config") % 1000 != 32
 
 
+@pytest.mark.parametrize("H,FF", [(2560, 9728), (2048, 6144), (3584, 18944)])
+def test_gemm_decode_rows_tails_at_other_model_widths(H, FF):
+    """The same tails at the Qwen3-4B / 1.7B widths and a 3584 x 18944 pair (row lengths that are no multiple of 4,096; shapes the streaming kernel
+    keeps are reported unsupported and skipped)."""
+    M = 32
+    g = torch.Generator(device="cuda").manual_seed(H)
+    c = ops.GemmContext()
+    c.ensure_workspace(64 << 20)
+    rnd = lambda *s, sc=1.0: ((torch.rand(*s, device="cuda", generator=g) * 2 - 1) * sc).to(BF)
+    checked = 0
+    with ops.use_gemm_context(c):
+        if ops.gemm_rows_tail_supported(M, H, FF, "norm"):
+            x, w, res, gain = rnd(M, FF), rnd(H, FF, sc=FF ** -0.5), rnd(M, H), rnd(H)
+            y0 = ops.gemm_nt(x, w, res=res)
+            n0 = ops.rmsnorm_fwd(y0, gain, 1e-6)
+            y1, n1 = torch.empty_like(y0), torch.empty_like(y0)
+            ops.gemm_rows_norm(x, w, y1, gain, 1e-6, n1, res=res)
+            assert torch.equal(y0, y1)
+            d = (n0.float() - n1.float()).abs()
+            assert d.max().item() <= 2 ** -7 * n0.float().abs().max().item() and (d > 0).float().mean().item() < 0.02
+            checked += 1
+        if ops.gemm_rows_tail_supported(M, 2 * FF, H, "swiglu"):
+            x2, w2 = rnd(M, H), rnd(2 * FF, H, sc=H ** -0.5)
+            gu0 = ops.gemm_nt(x2, w2)
+            a0 = ops.swiglu_fwd(gu0)
+            gu1, a1 = torch.empty_like(gu0), torch.empty_like(a0)
+            ops.gemm_rows_swiglu(x2, w2, gu1, a1)
+            assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+            checked += 1
+    assert checked >= 1
+
+
 @pytest.mark.parametrize("M", [17, 32, 64])
 def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
     """The decode step's launches folded into the decode-row GEMM's slab combine (molly_gemm_rows_tail_bf16_ctx): residual + RMSNorm
