@@ -36,6 +36,7 @@ def load(d, counter):
 
 def main():
     df, dw, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    what = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline   (MI355X, B=8 T=2048 K=512; 2 steps incl. warmup)"
     fe, wr = load(df, "FETCH_SIZE"), load(dw, "WRITE_SIZE")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rows, by, tot_b, tot_n = [], {}, 0.0, 0
@@ -48,8 +49,7 @@ def main():
             tot_b += per * n
             tot_n += n
     with open(os.path.join(root, "profiles", f"{tag}_pmc_hbm_traffic.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace) -- python3 bench.py "
-                "--steps 1 --warmup 1 --no-cpu-baseline   (MI355X, B=8 T=2048 K=512; 2 steps incl. warmup)\n"
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace) -- {what}\n"
                 "# hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE reads half the bytes of 16-B/lane streams on "
                 "gfx950 (MI355X_MICROARCH.md §HBM); Infinity-Cache hits are included (fabric-side counter)\n"
                 "kernel,launches,fetch_size_kb_raw_per_launch,write_size_kb_per_launch,hbm_bytes_per_launch\n")
