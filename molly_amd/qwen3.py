@@ -158,7 +158,10 @@ class Qwen3Engine:
                     # Qwen3-0.6B/1.7B widths) and the combined grid does; where every weight gradient fills the chip by
                     # itself (4B: two of four, 8B: all) deferring the GEMMs only costs cache locality (measured -2...-4 %)
                     split = sum(1 for t in per if not (t >= 200 and eff(t) >= 0.8))
-                    if split >= 3 and eff(sum(per)) >= 0.85:
+                    # (at one sample per GPU the contraction is only M / 64 = 48-64 K-tiles long: the launches' fixed costs and split-K
+                    # reduces weigh more, and two of four is enough — Molly-4B at M = 3072: 211.2 -> 209.0 ms/step; Molly-8B, one of
+                    # four, stays ungrouped: 396.6 against 398.7 grouped.  MOLLY_GROUPED_WGRAD=2 forces it for an A/B)
+                    if ((split >= 3 or (split >= 2 and M <= 4096)) and eff(sum(per)) >= 0.85) or os.environ.get("MOLLY_GROUPED_WGRAD") == "2":
                         self.tTg = [e(min(n, k) * M) for n, k in dims]
             if not self.train_base:
                 self.junk = torch.zeros(max(h, 2 * self.hd), dtype=BF16, device=dev)   # gain gradients nobody reads
