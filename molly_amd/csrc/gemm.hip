@@ -1856,12 +1856,15 @@ inline int grid256(const GemmCtx& c, int nwork) {
     const int t = -c.persist_blocks;
     return min(nwork, 256 * cdiv(nwork, 256 * t));                  // whole rounds of 256 blocks, at most t tiles per block
 }
-// blocks of a STREAM-K launch over `ntile` tiles of `upt` units: the same three modes — n > 0: n resident blocks; 0: as many
-// blocks as whole rounds of one tile's worth each need; -t: shares of at most t tiles — always a multiple of 8 (the XCD labels),
-// never more than one block per two units, and within what the scratch memory holds slabs for.
+// blocks of a STREAM-K launch over `ntile` tiles of `upt` units: the context's resident-block count (256 in the modes that have
+// none) — always a multiple of 8 (the XCD labels), never more than one block per two units, and within what the scratch memory
+// holds slabs for.
 inline int grid_sk(const GemmCtx& c, int ntile, int upt) {
-    int g = c.persist_blocks > 0 ? c.persist_blocks : 256 * cdiv(ntile, 256 * (c.persist_blocks == 0 ? 1 : -c.persist_blocks));
-    g = min(g, SK_MAX_BLOCKS);
+    // (never more than 256: the scratch every context is given holds 256 blocks' slabs, so the cut — and with it the fp32 order of
+    // the sums — does not change when a caller later grows the workspace; found by the config-5 test under MOLLY_TEST_GEMM_BLOCKS=0,
+    // where the second prefill of a batch was cut over 512 blocks and its argmax differed on two near-ties)
+    int g = c.persist_blocks > 0 ? c.persist_blocks : 256;
+    g = min(g, 256);
     g = min(g, (int)min((long)ntile * upt / 2, (long)(ws_slab_bytes(c) / SK_SLAB_BYTES)));
     g = min(g, 6 * ntile);                       // a tile in at most 6 + 2 pieces: the reducer's list holds 10, and it reads them one by one
     return g / 8 * 8;
