@@ -45,6 +45,9 @@ class GenerationSession:
         pos = (mask.cumsum(1) - 1).clamp(min=0)                              # HF: position_ids = cumsum(mask)-1, pads -> 0/1
         self.lo = lo if lo is not None else torch.zeros(B, dtype=torch.int32, device=dev)
         self.n_valid = mask.sum(1).to(torch.int32).to(dev)                    # next position id per sample
+        # the session's GEMM scratch is sized BEFORE its first GEMM (the launcher's split-K choices look at how much there is: a
+        # workspace that grew between the prefill and a later one of the same shape could cut the second differently)
+        ops.ensure_gemm_workspace(32 * 4 * max(B, 8) * max(2 * e.ff, e.nqkv), dev)
         hs, _ = m._embed_and_inject(m._stage(input_ids, None, None, omic_ids, omic_info_list, want_sort=False), False)
         e.reserve(B * T, B, T, training=False)
         # rope tables must cover prompt + generated positions
