@@ -732,6 +732,18 @@ def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
         gu1, a1 = torch.empty_like(gu0), torch.empty_like(a0)
         ops.gemm_rows_swiglu(x2, w2, gu1, a1)
         assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+        # with a bias in front of either tail
+        bias, bias2 = rnd(H), rnd(2 * 6144)
+        yb0 = ops.gemm_nt(x, w, bias=bias, res=res)
+        nb0 = ops.rmsnorm_fwd(yb0, gain, 1e-6)
+        yb1, nb1 = torch.empty_like(yb0), torch.empty_like(yb0)
+        ops.gemm_rows_norm(x, w, yb1, gain, 1e-6, nb1, res=res, bias=bias)
+        assert torch.equal(yb0, yb1) and (nb0.float() - nb1.float()).abs().max().item() <= 2 ** -7 * nb0.float().abs().max().item()
+        gub0 = ops.gemm_nt(x2, w2, bias=bias2)
+        ab0 = ops.swiglu_fwd(gub0)
+        gub1, ab1 = torch.empty_like(gub0), torch.empty_like(ab0)
+        ops.gemm_rows_swiglu(x2, w2, gub1, ab1, bias=bias2)
+        assert torch.equal(gub0, gub1) and torch.equal(ab0, ab1)
         assert not ops.gemm_rows_tail_supported(8, 4096, 4096, "norm")        # a streaming-kernel shape keeps its one launch
         assert not ops.gemm_rows_tail_supported(M, 151936, 4096, "norm")      # the lm_head is not a decode-row-kernel shape
 
