@@ -19,12 +19,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cus", type=int, nargs="+", default=[0, 16, 32, 64])
     ap.add_argument("--modes", nargs="+", default=["256", "0", "-3", "dyn"])
+    ap.add_argument("--shapes", default="b8", help="b8: Molly-1.7B at 8 x 2048 tokens (the headline); b1: Molly-4B / 8B at one sample per GPU "
+                                                   "(BASELINE configs 3 / 4: what the 8-GPU runs launch)")
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
     shapes = [("qkv fwd", "nt", 16384, 4096, 2048), ("gate|up fwd", "nt", 16384, 12288, 2048), ("down dgrad", "nn", 16384, 6144, 2048),
               ("gate|up dgrad", "nn", 16384, 2048, 12288), ("8b qkv B=1 (stream-K)", "nt", 4096, 6144, 4096)]
+    if a.shapes == "b1":
+        shapes = [("4b qkv fwd", "nt", 3072, 6144, 2560), ("4b gate|up fwd", "nt", 3072, 19456, 2560), ("4b down fwd", "nt", 3072, 2560, 9728),
+                  ("4b down dgrad", "nn", 3072, 9728, 2560), ("8b gate|up fwd", "nt", 4096, 24576, 4096), ("8b o fwd", "nt", 4096, 4096, 4096),
+                  ("8b down dgrad", "nn", 4096, 12288, 4096)]
     ctx = ops.GemmContext()
     ctx.ensure_workspace(1 << 28)
     side = torch.cuda.Stream()
