@@ -356,6 +356,8 @@ def main(argv=None):
     ap.add_argument("--exposed-comm-steps", type=int, default=4,
                     help="N>1: extra steps after the timed region with the exchange NOT overlapped, to report the exposed "
                          "communication time (0 = skip)")
+    ap.add_argument("--gemm-mode-ab-steps", type=int, default=2,
+                    help="N>1: steps per GEMM launch shape (-3 | dyn | 0) measured before the warm-up; the fastest is kept (0 = skip)")
     ap.add_argument("--event-stride", type=int, default=7,
                     help="HIP events around every n-th GEMM launch of the timed region (1 = all: 2-3 %% slower steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -470,12 +472,34 @@ def main(argv=None):
         dt = time.perf_counter() - t0
         return dt, [a.elapsed_time(b) for a, b in evs], loss
 
+    # ---- N > 1: which launch shape of the 256x256 GEMM runs fastest beside this job's own collectives?  Measured on the ranks
+    # themselves before the warm-up (untimed region): one settling step + `--gemm-mode-ab-steps` timed steps per shape, max over
+    # ranks, the fastest kept for the timed region.  Every shape computes bit-identical results (tests/test_gpu_dynamic_fetch.py),
+    # so the choice is speed only.  MOLLY_GEMM_PERSISTENT_MULTI pins one shape and skips this.
+    gemm_mode_ab = None
+    if world > 1 and opt.overlap and args.gemm_mode_ab_steps > 0 and "MOLLY_GEMM_PERSISTENT_MULTI" not in os.environ:
+        gemm_mode_ab = {}
+        for mode in (-3, "dyn", 0):
+            opt.set_gemm_blocks_mode(mode, m)
+            step(0)
+            dtm, _, _ = timed_steps(args.gemm_mode_ab_steps, 1)
+            tm = torch.tensor([dtm], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            gemm_mode_ab[str(mode)] = round(float(tm.item()) / args.gemm_mode_ab_steps * 1e3, 2)
+        best = min(gemm_mode_ab, key=gemm_mode_ab.get)              # same dict on every rank (all-reduced times)
+        opt.set_gemm_blocks_mode("dyn" if best == "dyn" else int(best), m)
+        gemm_mode_ab = {"ms_per_step": gemm_mode_ab, "chosen": best, "steps_each": args.gemm_mode_ab_steps}
+
     for i in range(args.warmup):
         step(i)
+    if world > 1:
+        opt.comm_events = []                    # per-bucket events of the timed region's collectives (on the stream they ran on)
     ops.GEMM_PROFILE = []
     ops.GEMM_PROFILE_STRIDE = args.event_stride
     dt, step_ms, loss = timed_steps(args.steps, args.warmup)
     prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    comm_timings = opt.comm_timings() if world > 1 else None
+    opt.comm_events = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -493,12 +517,23 @@ def main(argv=None):
                 # own behaviour with bf16 gradients); the all-to-all variant sums the `world` copies in fp32 on the owner, once
                 "reduce_dtype": ("fp32 on the owning rank, rank order, one rounding (all_to_all + molly_reduce_rows)"
                                  if opt.rs_algo == "a2a" else "bf16 in the collective (RCCL reduce_scatter: one rounding per hop)"),
-                "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256)}
+                "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256), "gemm_mode_ab": gemm_mode_ab,
+                # per bucket, HIP events on the communication stream around each collective of the timed region (overlapped: the
+                # time includes waiting for CUs beside the backward); us_per_bucket = the first timed step's buckets in launch order
+                "timings_us": comm_timings}
+        # the world as the BACKEND counts it: a sum of ones through its own all-reduce (a communicator that silently spans fewer
+        # ranks than WORLD_SIZE shows here)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        comm["world_size_by_all_reduce"] = int(ones.item())
         if backend == "nccl":
             try:
                 comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
             except Exception:
                 pass
+            for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY"):
+                if k in os.environ:
+                    comm.setdefault("env", {})[k] = os.environ[k]
         if args.exposed_comm_steps > 0 and opt.overlap:
             opt.set_overlap(False)
             step(0)

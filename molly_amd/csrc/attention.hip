@@ -33,6 +33,7 @@ struct AttnArgs {
     int T, nh, nkv, ldq, ldk, ldv, ldo;
     float scale_log2;                        // softmax scale * log2(e)
     int causal;
+    int nblk, order_set;                     // block order (block_item): query blocks per head, (batch, kv head) pairs walked together
 };
 
 // One LDS image serves row reads (ds_read_b128: tile row on the lane) AND transposed reads (ds_read_b64_tr_b16: tile
@@ -204,6 +205,35 @@ __device__ __forceinline__ float xhalf_max(float v) {
 #endif
 }
 
+// ---- which (batch, kv head, query head of the group, block) a workgroup works on.
+// The 8 XCDs have an L2 each and the dispatcher deals workgroups over them round-robin (blocks b and b + 8 share one).  Round 3's
+// grid (x = head + n_heads * batch fastest) therefore put the two query heads of a GQA group on DIFFERENT XCDs and gave every XCD
+// 16 (batch, head) pairs' K/V at once — 16 MB against a 4 MB L2: the forward moved 760 MB per launch on the fabric side for 201 MB
+// of Q + K + V + O (profiles/r03_pmc_hbm_traffic.csv).  Now: a 1-D grid; the workgroups of one XCD label take a contiguous chunk of
+// the item order (the same chunking gemm.hip uses), and the item order is (batch, kv head) PAIR-major — every block of every
+// query head of a pair before the next pair — so an XCD's 64 resident workgroups work on two or three pairs (1 MB of K/V each at
+// T = 2048) and each K/V byte leaves HBM once.  Inside a pair: heaviest block first (causal: the last query block / the first key
+// block), the heads of the group side by side.  `set` > 1 walks that many pairs interleaved (a knob for measurements);
+// set = 0 is round 3's order (for A/B).  Speed only: any placement computes the same thing.
+struct BlockItem { int b, kvh, g, blk; };
+__device__ __forceinline__ BlockItem block_item(int bid, int nwg, int nkv, int group, int nblk, int set) {
+    if (set <= 0) {                                    // round 3: x = (kv head * group + g) + n_heads * batch fastest, y = block slot
+        const int nx = nwg / nblk, x = bid % nx, y = bid / nx;
+        const int head = x % (nkv * group);
+        return BlockItem{x / (nkv * group), head / group, head % group, y};
+    }
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int bp = group * nblk;                       // workgroups per pair
+    const int npairs = nwg / bp;
+    const int s = v / (set * bp), pair0 = s * set;
+    const int pc = min(set, npairs - pair0);
+    const int w = v - s * set * bp;
+    const int blk = w / (pc * group), rem = w - blk * (pc * group);
+    const int pair = pair0 + rem / group;
+    return BlockItem{pair / nkv, pair % nkv, rem % group, blk};
+}
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -215,12 +245,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // grid: x = head + n_heads*batch (fastest), y = query-block slot.  The dispatcher hands out blocks in linear order,
-    // so the heaviest causal blocks (largest query index) all start first and the light ones fill the tail (LPT).
-    const int nqb = gridDim.y;
-    const int qb = nqb - 1 - blockIdx.y;
-    const int head = blockIdx.x % p.nh, b = blockIdx.x / p.nh;
-    const int kvh = head / (p.nh / p.nkv);
+    // 1-D grid, XCD-aware item order (block_item); within a pair the heaviest causal blocks (largest query index) start first
+    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);
+    const int qb = p.nblk - 1 - bi.blk;
+    const int b = bi.b, kvh = bi.kvh, head = kvh * (p.nh / p.nkv) + bi.g;
     const int q0 = qb * BQ + wave * 32;                        // this wave's first query row
     const int T = p.T;
     const int lo = p.kv_lo ? p.kv_lo[b] : 0;
@@ -443,6 +471,7 @@ struct AttnBwdArgs {
     float scale, scale_log2;
     int causal;
     float* part;               // head-split dK/dV pass: per-(block, query head) accumulator images, register order (see SPLIT)
+    int nblk, order_set;       // block order (block_item): query / key blocks per head, (batch, kv head) pairs walked together
 };
 
 template <int HD>
@@ -454,9 +483,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int qb = gridDim.y - 1 - blockIdx.y;                 // heaviest first (see attn_fwd_kernel)
-    const int head = blockIdx.x % p.nh, b = blockIdx.x / p.nh;
-    const int kvh = head / (p.nh / p.nkv);
+    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);   // see attn_fwd_kernel
+    const int qb = p.nblk - 1 - bi.blk;                        // heaviest first
+    const int b = bi.b, kvh = bi.kvh, head = kvh * (p.nh / p.nkv) + bi.g;
     const int q0 = qb * BQ + wave * 32;
     const int T = p.T;
     const int lo = p.kv_lo ? p.kv_lo[b] : 0;
@@ -589,8 +618,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     const int r = lane & 31, h = lane >> 5;
     // causal: key block 0 sees every query tile (heaviest) -> slot order = key-block order already is heaviest-first
     const int group = p.nh / p.nkv;
-    const int bx = SPLIT ? blockIdx.x / group : blockIdx.x, g0 = SPLIT ? blockIdx.x % group : 0;
-    const int kb = blockIdx.y, kvh = bx % p.nkv, b = bx / p.nkv;
+    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, SPLIT ? group : 1, p.nblk, p.order_set);
+    const int kb = bi.blk, kvh = bi.kvh, b = bi.b, g0 = bi.g;
+    const int bx = b * p.nkv + kvh;                              // the (batch, kv head) pair
     const int T = p.T;
     const int lo = p.kv_lo ? p.kv_lo[b] : 0;
     const int hi = p.kv_hi ? p.kv_hi[b] : T;
@@ -720,8 +750,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     }
     if constexpr (SPLIT) {
         // image [(b, kvh, kb)][g][wave][d][g4][lane] f32x4; the dV pass owns the first half of `part`, the dK pass the second
-        const size_t nimg = (size_t)gridDim.x * gridDim.y;
-        const size_t img = ((size_t)bx * gridDim.y + kb) * group + g0 + (DO_DK ? nimg : 0);
+        const size_t nimg = (size_t)gridDim.x;
+        const size_t img = ((size_t)bx * p.nblk + kb) * group + g0 + (DO_DK ? nimg : 0);
         float* dst = p.part + img * (4 * ND * 16 * 64) + (size_t)wave * (ND * 16 * 64) + lane * 4;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
@@ -772,6 +802,21 @@ __global__ __launch_bounds__(64) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
 
 }  // namespace
 
+// (batch, kv head) pairs an XCD label's workgroups walk together (block_item).  Default: ALL the pairs of the label's chunk, up to 8
+// — inside an XCD the order is then heaviest block first over its pairs, the launch-wide order round 3 had, which matters more than
+// the L2 footprint (r04 attn_order.log, B8 T2048 16/8 heads: one pair at a time 188.7 us forward, two 173.8, four 168.6, round 3's
+// order 173.3; every XCD has the same work, so the labels finish together) — when the pairs divide evenly over the 8 labels;
+// otherwise round 3's order (0).  MOLLY_ATTN_ORDER_SET (forward, dQ pass) / MOLLY_ATTN_ORDER_SET_DKV (dK / dV passes) pin a value.
+static int order_set(int dkv, int npairs) {
+    static const int v[2] = {[] { const char* e = getenv("MOLLY_ATTN_ORDER_SET"); return e ? atoi(e) : -1; }(),
+                             [] { const char* e = getenv("MOLLY_ATTN_ORDER_SET_DKV"); return e ? atoi(e) : -1; }()};
+    if (v[dkv != 0] >= 0) return v[dkv != 0];
+    if (npairs % 8 != 0) return 0;
+    int s = npairs / 8;                              // pairs per XCD label; a set must not straddle two labels' chunks
+    while (s > 8) s = (s % 2 == 0) ? s / 2 : (s % 3 == 0) ? s / 3 : (s % 5 == 0) ? s / 5 : 1;
+    return s;
+}
+
 extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
                               const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim,
                               int ldq, int ldk, int ldv, int ldo, float scale, int causal) {
@@ -785,7 +830,7 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     MOLLY_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0, "attn_fwd: alignment");
     MOLLY_CHECK(B > 0 && T > 0, "attn_fwd: empty problem");
     AttnArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, lse2, kv_lo, kv_hi, T, n_heads,
-               n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal};
+               n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal, cdiv(T, BQ), order_set(0, B * n_kv_heads)};
     if (head_dim < 64) {
         const dim3 g(n_heads * B, cdiv(T, 128));
 #define MOLLY_SMALL(HD_) case HD_: hipLaunchKernelGGL(attn_fwd_small_kernel<HD_>, g, dim3(128), 0, (hipStream_t)stream, p); break
@@ -794,7 +839,7 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
         MOLLY_LAUNCH_CHECK();
         return 0;
     }
-    dim3 grid(n_heads * B, cdiv(T, BQ));
+    dim3 grid(n_heads * B * cdiv(T, BQ));                  // 1-D: block_item() decodes it
     // MOLLY_ATTN_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, e.g. 40960 leaves room for ONE workgroup per CU — what the
     // second wave of every SIMD is worth is then the ratio of the two run times
     static const size_t pad = [] { const char* e = getenv("MOLLY_ATTN_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
@@ -840,7 +885,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     hipStream_t st = (hipStream_t)stream;
     AttnBwdArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, (const bf16_t*)O, lse2, delta_ws,
                   (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, kv_lo, kv_hi, T, n_heads, n_kv_heads, ldq, ldk, ldv, ldo,
-                  lddq, lddk, lddv, scale, scale * LOG2E, causal, nullptr};
+                  lddq, lddk, lddv, scale, scale * LOG2E, causal, nullptr, cdiv(T, BQ), order_set(0, B * n_kv_heads)};
     const size_t lds_dq = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
     const size_t lds_dkv = lds_dq + 2 * 128 * sizeof(float);
     static bool attr_set = false;
@@ -855,7 +900,11 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         attr_set = true;
     }
-    dim3 gq(n_heads * B, cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));
+    const dim3 gq(n_heads * B * cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));   // dQ pass 1-D; gk: the reduce kernel's 2-D shape
+    const dim3 gk1(gk.x * gk.y);                                                    // dK / dV passes 1-D (block_item)
+    AttnBwdArgs pk = p;                                                             // their block order
+    pk.nblk = cdiv(T, 128);
+    pk.order_set = order_set(1, B * n_kv_heads);
     // MOLLY_ATTN_DKV_ONE_PASS=1: dK and dV from one pass (7 MFMA products in the backward instead of 8, but 256 accumulator
     // registers = one wave per SIMD); default: two passes at two waves per SIMD (measured faster: DESIGN.md §4)
     static const bool one_pass = [] { const char* e = getenv("MOLLY_ATTN_DKV_ONE_PASS"); return e && atoi(e) != 0; }();
@@ -863,20 +912,20 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
         const long need = molly_attn_bwd_workspace(B, T, n_heads, n_kv_heads, head_dim);
         if (!one_pass && need > 0 && workspace && workspace_floats >= need) {
-            p.part = workspace;
-            const dim3 gs(n_heads * B, cdiv(T, 128));
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, p);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, p);
+            p.part = pk.part = workspace;
+            const dim3 gs(n_heads * B * cdiv(T, 128));
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, pk);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, pk);
             hipLaunchKernelGGL(attn_dkv_reduce_kernel<128>, dim3(gk.x * 4, gk.y, 2), dim3(64), 0, st, p);
         } else if (one_pass) {
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk, dim3(256), lds_dkv, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk1, dim3(256), lds_dkv, st, pk);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk, dim3(256), lds_dkv, st, p);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2>), gk, dim3(256), lds_dkv, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk1, dim3(256), lds_dkv, st, pk);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2>), gk1, dim3(256), lds_dkv, st, pk);
         }
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), lds_dq, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 0>), gk, dim3(256), lds_dkv, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 0>), gk1, dim3(256), lds_dkv, st, pk);
     }
     MOLLY_LAUNCH_CHECK();
     return 0;

@@ -117,7 +117,7 @@ class GenerationSession:
         self.slot = torch.arange(B, device=dev, dtype=torch.int32) * self.Tmax + self.cur_len
         self.hi = torch.full((B,), self.cur_len + 1, dtype=torch.int32, device=dev)
         self.logits = torch.empty(B, e.V, dtype=torch.float32, device=dev)
-        self._graph, self._steps_done = None, 0
+        self._graph, self._graph_ws, self._graph_ws_ptr, self._steps_done = None, None, 0, 0
         self.dec_ws = ops.attn_decode_workspace(B, e.nh, e.hd, dev)
         # decode GEMMs are M = B rows against whole weight matrices: the library splits K over the chip and needs slab space
         ops.ensure_gemm_workspace(32 * 4 * max(B, 8) * max(2 * e.ff, e.nqkv), dev)
@@ -214,11 +214,20 @@ class GenerationSession:
         self._steps_done += 1
         if not self.use_graph or self._steps_done == 1:
             return self._step_body()
+        # The captured launches carry the context's scratch pointers (split-K slabs, the decode-row tails' slabs, stream-K and
+        # dynamic-fetch counters).  Another session or a training reserve() on the same model may have grown — i.e. replaced — that
+        # scratch since the capture: the graph then keeps its own reference to the tensor it was captured with (`_graph_ws`, so a
+        # replay in flight never reads freed memory) and is dropped and captured again before the next replay.
+        ws = self.rt.gemm_ctx.ws
+        if self._graph is not None and (ws is None or ws.data_ptr() != self._graph_ws_ptr):
+            self._graph = None
         if self._graph is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step_body()
-            self._graph = g          # capture does not execute: fall through to the replay
+            assert self.rt.gemm_ctx.ws is ws, "the GEMM scratch was replaced during graph capture"
+            self._graph, self._graph_ws, self._graph_ws_ptr = g, ws, (ws.data_ptr() if ws is not None else 0)
+            # capture does not execute: fall through to the replay
         self._graph.replay()
         return self.logits
 

@@ -87,6 +87,11 @@ class GemmContext:
     def ensure_workspace(self, nbytes: int, device="cuda"):
         nbytes = max(int(nbytes), 0) + STREAMK_SCRATCH
         if self.ws is None or self.ws.numel() * 4 < nbytes:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                # molly_gemm_ctx_set_workspace clears the header with hipMemset + a device synchronize, and a captured launch
+                # would keep the OLD pointer: scratch is sized before a capture starts (GenerationSession._alloc_step)
+                raise RuntimeError(f"GEMM scratch would have to grow to {nbytes} bytes during a hipGraph capture; "
+                                   "call ensure_workspace() with the largest size before capturing")
             self.ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
             lib().call("molly_gemm_ctx_set_workspace", self.handle, self.ws, self.ws.numel() * 4)
         return self.ws

@@ -231,6 +231,9 @@ class Zero2Optimizer:
         self.overlap = self.overlap and flat_params.is_cuda
         self.P_out = flat_params                # AdamW writes here; the all-gather publishes into P (same buffer in production)
         self.hooked = False                     # set by OmicsOne.attach_optimizer: somebody will call wait_params()
+        # per-bucket timing of the exchange (bench.py at N > 1): [(kind, bucket, start event, end event)] on the stream the
+        # collective ran on; None = off (two events per collective are not free)
+        self.comm_events = None
         # one rank, hooked: nothing to exchange, but the AdamW pass itself (HBM-bound, 28 B per parameter) can run on a side
         # stream under the NEXT step's first layers (MFMA-bound), bucket by bucket in the order the forward consumes
         # parameters; the forward's wait_params() calls then wait for AdamW events exactly as they wait for all-gather events
@@ -241,16 +244,18 @@ class Zero2Optimizer:
             if self.world > 1 and flat_params.is_cuda:
                 # RCCL's collective kernels hold CUs for milliseconds.  The persistent GEMM launches exactly one block per
                 # CU, each owning 1/256 of the tiles: with a few CUs taken, the blocks that cannot start wait for a whole
-                # share to finish and the launch takes twice as long (-40 % with 16 CUs held).  Default at N > 1: the same 256
-                # resident blocks DRAW their tiles (MOLLY_GEMM_KEY_DYNAMIC; gemm.hip 'DYN'): a block that starts late takes
-                # what is left, so held CUs cost their share of the chip plus tile quantisation (-13 % / -24 % with 16 / 64 held;
-                # measured on one GPU with a stand-in that holds CUs: tools/diag/gemm_beside_hog.py; not yet
-                # on 8 GPUs).  It costs one exposed ticket per launch, +1.4 % of the N = 1 step, which is why one rank keeps the
-                # static walk.  MOLLY_GEMM_PERSISTENT_MULTI = dyn (default) | 256 static, one block per CU | 0 one block per
-                # tile | -t static blocks of t tiles (round 2's -3).
+                # share to finish and the launch takes twice as long (-40 % with 16 CUs held; measured on one GPU with a
+                # stand-in that holds CUs: tools/diag/gemm_beside_hog.py).  Launch shapes for N > 1,
+                # MOLLY_GEMM_PERSISTENT_MULTI = -t static blocks of at most t tiles placed by the hardware dispatcher (default -3,
+                # round 2's shape: plain launches, nothing a block waits for) | dyn 256 resident blocks that DRAW their tiles
+                # (gemm.hip 'DYN': best beside the stand-in, -13 % / -24 % with 16 / 64 CUs held, but one exposed ticket per
+                # launch and — like every shape here — never yet run beside real RCCL kernels, so it is opt-in: ADVICE r03) |
+                # 0 one block per tile | 256 (or 1) static, one block per CU.  bench.py at N > 1 measures the shapes against
+                # each other on the job's own ranks before its warm-up and keeps the fastest (`comm.gemm_mode_ab`), so the
+                # first multi-GPU run records the measurement this default is waiting for.
                 # The optimizer only RECORDS the wish: `OmicsOne.attach_optimizer` applies it to the GEMM context of the model
                 # this optimizer steps — no other model, evaluator or later test in the process inherits it.
-                mode = os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "dyn")
+                mode = os.environ.get("MOLLY_GEMM_PERSISTENT_MULTI", "-3")
                 self.gemm_blocks_mode = "dyn" if mode == "dyn" else 256 if mode == "1" else int(mode)
             self.cstream = torch.cuda.Stream(device=dev, priority=-1)     # collectives first whenever CUs free up
             self._rs_done = [False] * len(self.buckets)
@@ -303,12 +308,54 @@ class Zero2Optimizer:
     def wait_all_params(self):
         self.wait_params(0, self.n)
 
+    def _timed(self, kind: str, start: int):
+        """context manager: HIP events on the current stream around one bucket's collective when comm_events is on."""
+        opt = self
+
+        class _T:
+            def __enter__(self_t):
+                if opt.comm_events is not None and opt.P.is_cuda:
+                    self_t.e0 = torch.cuda.Event(enable_timing=True)
+                    self_t.e0.record(torch.cuda.current_stream())
+
+            def __exit__(self_t, *exc):
+                if opt.comm_events is not None and opt.P.is_cuda:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(torch.cuda.current_stream())
+                    opt.comm_events.append((kind, start, self_t.e0, e1))
+                return False
+        return _T()
+
+    def comm_timings(self) -> dict:
+        """{kind: {"n": collectives timed, "us_p50": ..., "us_max": ..., "us_per_bucket": [first step's buckets in launch order]}}
+        from the events gathered since `comm_events = []` (synchronises).  With the exchange overlapped a collective's time
+        includes what it waited for CUs beside the backward — that is the number the bucket size is tuned against."""
+        if not self.comm_events:
+            return {}
+        torch.cuda.synchronize()
+        import statistics
+        out = {}
+        for kind in sorted({k for k, *_ in self.comm_events}):
+            ev = [(b, e0.elapsed_time(e1) * 1e3) for k, b, e0, e1 in self.comm_events if k == kind]
+            us = [t for _, t in ev]
+            nb = len({b for b, _ in ev})
+            out[kind] = {"n": len(us), "us_p50": round(statistics.median(us), 1), "us_max": round(max(us), 1),
+                         "us_per_bucket": [round(t, 1) for _, t in ev[:nb]]}
+        return out
+
+    def set_gemm_blocks_mode(self, mode, model=None):
+        """Change the GEMM launch shape this optimizer asks for (see __init__) and, given the model it steps, apply it."""
+        self.gemm_blocks_mode = "dyn" if mode == "dyn" else int(mode)
+        if model is not None:
+            model.attach_optimizer(self)
+
     def _reduce_bucket(self, start: int, per: int):
         region = self.G[start:start + per * self.world]
-        if self.stage == 0:
-            self.comm.all_reduce_region(region)
-        else:
-            self.comm.reduce_scatter(region[self.rank * per:(self.rank + 1) * per], region)
+        with self._timed("all_reduce" if self.stage == 0 else "reduce_scatter", start):
+            if self.stage == 0:
+                self.comm.all_reduce_region(region)
+            else:
+                self.comm.reduce_scatter(region[self.rank * per:(self.rank + 1) * per], region)
 
     # ---- pieces (also used by the multi-process CPU tests) ---------------------------------------------------
     def reduce_scatter_grads(self):
@@ -334,8 +381,9 @@ class Zero2Optimizer:
             with torch.cuda.stream(self.cstream):
                 for b in order:
                     start, per = self.buckets[b]
-                    self.comm.all_gather(self.P[start:start + per * self.world],
-                                         self.P_out[start + self.rank * per:start + (self.rank + 1) * per])
+                    with self._timed("all_gather", start):
+                        self.comm.all_gather(self.P[start:start + per * self.world],
+                                             self.P_out[start + self.rank * per:start + (self.rank + 1) * per])
                     e = torch.cuda.Event()
                     e.record(self.cstream)
                     self._ag_events[b] = e
@@ -347,7 +395,8 @@ class Zero2Optimizer:
             return
         for start, per in self.buckets:
             region = self.P[start:start + per * self.world]
-            self.comm.all_gather(region, region[self.rank * per:(self.rank + 1) * per])
+            with self._timed("all_gather", start):
+                self.comm.all_gather(region, region[self.rank * per:(self.rank + 1) * per])
 
     def grad_norm_and_clip(self):
         first = True

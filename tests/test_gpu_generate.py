@@ -262,3 +262,43 @@ def test_sampled_generate_calls_with_one_generator_are_independent(tiny_meta):
     assert not torch.equal(c, d)
     torch.manual_seed(123)
     assert torch.equal(c, m.generate(ids, mask, omic, info, **kw))
+
+
+def test_captured_decode_graph_survives_a_replaced_gemm_scratch(tiny_meta):
+    """a session's captured decode graph carries the model context's scratch pointers.  When something else on the same
+    model grows — i.e. replaces — that scratch, the session must keep the captured tensor alive and capture again, not replay into
+    freed memory.  Reference role: HF generate's decode loop, `src/model/omics_one.py:220-232`."""
+    from molly_amd.generate import GenerationSession
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)
+
+    def run(disturb):
+        sess = GenerationSession(m, max_new_tokens=8, use_graph=True)
+        logits = sess.prefill(ids, mask, omic, info)
+        outs = []
+        for step in range(6):
+            nxt = logits.argmax(-1)
+            logits = sess.step(nxt)
+            outs.append(logits.clone())
+            if disturb and step == 2:
+                assert sess._graph is not None
+                old = sess._graph_ws_ptr
+                ctx = sess.rt.gemm_ctx
+                ctx.ensure_workspace(ctx.ws.numel() * 4 + (64 << 20), sess.rt.dev)      # somebody else's larger request
+                assert ctx.ws.data_ptr() != old and sess._graph_ws.data_ptr() == old     # the captured tensor is still alive
+                torch.empty(ctx.ws.numel(), dtype=torch.float32, device="cuda").fill_(float("nan"))   # whatever reuses memory
+        return outs
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_gemm_scratch_refuses_to_grow_inside_a_capture():
+    from molly_amd import ops
+    ctx = ops.GemmContext()
+    ctx.ensure_workspace(1 << 20)
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="during a hipGraph capture"):
+        with torch.cuda.graph(g):
+            ctx.ensure_workspace(ctx.ws.numel() * 4 + (8 << 20))

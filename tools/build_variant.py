@@ -47,10 +47,10 @@ def _patch_tilestamp(t):
         nonlocal t
         assert t.count(a) == 1, (t.count(a), a)
         t = t.replace(a, b)
-    once("template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false>", """__device__ unsigned long long g_tstamp[2048 * 8 * 16];
+    once("template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false, bool DYN = false>", """__device__ unsigned long long g_tstamp[2048 * 8 * 16];
 #define TSTAMP(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define TLAP(i) do { TSTAMP(tq1_); ts##i##_ += tq1_ - tq0_; tq0_ = tq1_; } while (0)
-template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false>""")
+template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false, bool DYN = false>""")
     once("    for (;;) {\n", """    unsigned long long tq0_, tq1_, ts0_ = 0, ts1_ = 0, ts2_ = 0, ts3_ = 0, ts4_ = 0, ts5_ = 0, ts6_ = 0, ts7_ = 0, ts8_ = 0, ts9_ = 0, ts10_ = 0, ntile_ = 0;
     for (;;) {
     TSTAMP(tq0_);
@@ -64,7 +64,7 @@ template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false>"
     once("    if (wr == 0) SEG_BARRIER();               // balance the stagger barrier (every LDS read of this tile has returned)\n",
          "    if (wr == 0) SEG_BARRIER();               // balance the stagger barrier (every LDS read of this tile has returned)\n    TLAP(7);\n")
     once("    landed0 = roll && more;\n", "    landed0 = roll && more;\n    TLAP(8);\n")
-    once("    if (!more) break;\n", "    TLAP(9); ++ntile_;\n    if (!more) break;\n")
+    once("    }   // epilogue variants\n", "    }   // epilogue variants\n    TLAP(9); ++ntile_;\n")
     once("    }   // persistent tile loop\n", """    }   // persistent tile loop
     if (lane == 0 && blockIdx.x < 2048) { unsigned long long* q = g_tstamp + (blockIdx.x * 8 + wave) * 16;
         q[0] += ts0_; q[1] += ts1_; q[2] += ts2_; q[3] += ts3_; q[4] += ts4_; q[5] += ts5_; q[6] += ts6_; q[7] += ts7_; q[8] += ts8_;
