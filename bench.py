@@ -333,6 +333,43 @@ def attention_flops_per_step(cfg, enc_cfgs, B, T, micro, train_bio=False):
     return llm + enc
 
 
+def vendor_gemm_yardstick(dev, M):
+    """torch.matmul (the vendor library: hipBLASLt / rocBLAS) beside molly's own kernel on the forward and dgrad shapes of the
+    decoder layer at this batch, same process, same box, OUTSIDE the timed region: a same-node yardstick next to `vs_baseline:
+    null`.  Random data, best of 3 rounds of 5 launches each, HIP events.  TFLOP/s."""
+    import torch
+    from molly_amd import ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
+    shapes = [("qkv fwd", "nt", 4096, 2048), ("o fwd", "nt", 2048, 2048), ("gate|up fwd", "nt", 12288, 2048), ("down fwd", "nt", 2048, 6144),
+              ("qkv dgrad", "nn", 2048, 4096), ("down dgrad", "nn", 6144, 2048)]
+
+    def t_of(f):
+        f()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 5)
+        return best
+    out = {}
+    for name, form, n, k in shapes:
+        a = rnd(M, k)
+        b = rnd(n, k) if form == "nt" else rnd(k, n)
+        c = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
+        fl = 2.0 * M * n * k
+        if form == "nt":
+            ours, vend = (lambda: ops.gemm_nt(a, b, out=c)), (lambda: torch.matmul(a, b.t(), out=c))
+        else:
+            ours, vend = (lambda: ops.gemm(a, b, out=c, b_kmajor=True)), (lambda: torch.matmul(a, b, out=c))
+        out[name] = {"M": M, "N": n, "K": k, "molly": round(fl / t_of(ours) / 1e9, 1), "torch_matmul": round(fl / t_of(vend) / 1e9, 1)}
+    return out
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -361,6 +398,7 @@ def main(argv=None):
     ap.add_argument("--event-stride", type=int, default=7,
                     help="HIP events around every n-th GEMM launch of the timed region (1 = all: 2-3 %% slower steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vendor-gemm", action="store_true", help="skip the torch.matmul yardstick (roofline.vendor_gemm_tflops)")
     ap.add_argument("--cpu-budget", type=float, default=150.0,
                     help="wall-time box (s) of the down-scaled-C2 CPU run (2 warm-ups + 5 timed steps of ~12 s fit); C1 gets half")
     ap.add_argument("--micro", default=None,
@@ -621,10 +659,13 @@ def main(argv=None):
                                "algorithmic count of SURVEY 8d (lm_head on every row)"},
             "step_ms_p50": round(statistics.median(step_ms), 2),
             "step_ms": [round(x, 1) for x in step_ms],      # per step, HIP events (ms_per_step is the wall clock over all of them / steps)
+            # THE step fraction: FLOPs the kernels executed / step time / dense bf16 MFMA peak
             "executed_tflops_per_gpu": round(exec_step / sps / 1e12, 1),
             "mfma_roofline_frac_step_executed": round(exec_step / sps / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            # credit for work the kernels SKIP (lm_head + CE on the 75 % of rows whose label is -100: exact, zero loss and gradient):
+            # SURVEY 8d's algorithmic count / step time — not a utilisation figure
             "model_tflops_per_gpu": round(flops_step / sps / 1e12, 1),
-            "mfma_roofline_frac_step": round(flops_step / sps / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "model_flops_credit_frac_incl_skipped_rows": round(flops_step / sps / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "loss": round(loss_v, 4),
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM (gemm256_kernel / gemm_kernel, all launches of the timed region)",
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -635,6 +676,11 @@ def main(argv=None):
         }
         if comm is not None:
             out["comm"] = comm
+        if world == 1 and not args.no_vendor_gemm:
+            try:
+                out["roofline"]["vendor_gemm_tflops"] = vendor_gemm_yardstick(dev, B * T)
+            except Exception as e:          # noqa: BLE001  (a yardstick must never cost the line)
+                out["roofline"]["vendor_gemm_tflops"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
         if world == 1 and not args.no_secondary and args.secondary_worker is None:
             # the other BASELINE configs, each in a child of its own: release this process's HBM first
             del m, opt, rt, batches

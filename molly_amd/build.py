@@ -98,5 +98,50 @@ def _build_locked(force: bool, verbose: bool) -> str:
     return LIB
 
 
+# ---- host-sanitizer build (CPU box only) ------------------------------------------------------------------
+HOST_ASAN_DIR = os.path.join(HERE, "csrc", "build_host_asan")
+HOST_ASAN_FLAGS = ["--cuda-host-only", "-O1", "-g", "-fPIC", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
+                   "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-DMOLLY_HOST_DRY=1",
+                   "-Wno-unused-value", "-Wno-inline-asm"]
+
+
+def build_host_asan(verbose: bool = True) -> str:
+    """The HOST half of every csrc translation unit under AddressSanitizer + UBSan, launches recorded instead of issued
+    (common.h MOLLY_HOST_DRY), linked with tools/host_asan_driver.cpp into an executable that walks the entry points' argument
+    space.  No device code is compiled (--cuda-host-only: seconds per file); the code-object symbols the host objects refer to
+    are satisfied by empty stand-ins — nothing here can run a kernel, and nothing here is ever run on the GPU box.
+    Returns the path of the driver executable."""
+    os.makedirs(HOST_ASAN_DIR, exist_ok=True)
+
+    def comp(src):
+        path = os.path.join(CSRC, src) if not os.path.isabs(src) else src
+        obj = os.path.join(HOST_ASAN_DIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        lang = ["-x", "hip"] if src.endswith(".hip") else ["-x", "c++"]
+        r = subprocess.run([HIPCC] + HOST_ASAN_FLAGS + lang + ["-c", path, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"host-asan compile failed for {src}:\n{r.stderr[-4000:]}")
+        return obj
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(comp, _sources() + [os.path.join(ROOT, "tools", "host_asan_driver.cpp")]))
+    nm = subprocess.run(["nm"] + objs, capture_output=True, text=True, check=True).stdout
+    syms = sorted({ln.split()[-1] for ln in nm.splitlines() if " U __hip_fatbin_" in ln})
+    stub = os.path.join(HOST_ASAN_DIR, "fatbin_stub.c")
+    with open(stub, "w") as f:
+        f.write("/* generated: the device code objects a --cuda-host-only build refers to do not exist */\n")
+        for sy in syms:
+            f.write(f'__attribute__((section(".hip_fatbin"), aligned(4096))) const char {sy}[4096] = {{0}};\n')
+    subprocess.run(["gcc", "-c", stub, "-o", stub[:-2] + ".o"], check=True)
+    exe = os.path.join(HOST_ASAN_DIR, "host_asan_driver")
+    r = subprocess.run([HIPCC, "-fsanitize=address,undefined"] + objs + [stub[:-2] + ".o", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host-asan link failed:\n{r.stderr[-4000:]}")
+    if verbose:
+        print(f"[molly_amd.build] host-sanitizer driver: {exe}", file=sys.stderr)
+    return exe
+
+
 if __name__ == "__main__":
+    if "--host-asan" in sys.argv:
+        exe = build_host_asan()
+        sys.exit(subprocess.run([exe] + [a for a in sys.argv[1:] if a.isdigit()]).returncode)
     build(force="--force" in sys.argv)

@@ -964,9 +964,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             SEG_BARRIER();
             // the A slot the K loop read last is dead until the next item's P1: its first word carries the ticket to all waves
             volatile unsigned* mail = reinterpret_cast<volatile unsigned*>(smem + ((abuf == 0 ? 2 : abuf - 1) * 2) * HT);
-            if (tid == 0)
+            if (tid == 0) {
+                // the slab stores above are write-through (sc1) and drained by every wave before the barrier; the release makes
+                // the ordering against the ticket explicit for pieces that meet across XCD L2s (sk_tile_aligned = 0) — one
+                // buffer_wbl2 with nothing dirty behind write-through stores
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 *mail = __hip_atomic_fetch_add(p.sk_flag + (size_t)tile * 16, (unsigned)my_units, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             SEG_BARRIER();
             const int before = __builtin_amdgcn_readfirstlane((int)*mail);
@@ -986,7 +991,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 for (int b2 = first;; b2 = (b2 >> 3) < nl - 1 ? b2 + 8 : (b2 & 7) + 1) {
                     sk_range(b2, u0, u1);
                     // (a block without work wrote nothing)  slab index = 2 * block + (0: the piece holds the block's last unit)
-                    if (u1 > u0 && nc < SK_MAXC) cb[nc++] = b2 * 2 + ((u1 - 1) / sk_upt == tile ? 0 : 1);
+                    if (u1 > u0) {
+                        if (nc < SK_MAXC) cb[nc++] = b2 * 2 + ((u1 - 1) / sk_upt == tile ? 0 : 1);
+                        // a tile cut into more pieces than the reducer's list holds would be stored with part of its K sum missing:
+                        // never silently — the error word of the header (what molly_gemm_ctx_streamk_timeouts reads; the host's
+                        // grid rule keeps a tile at <= 9 pieces, tests assert the word stays 0)
+                        else if (tid == 0) atomicOr(p.sk_flag - 16, 1u);
+                    }
                     if (u1 >= tile_u1) break;
                 }
                 if (wave == 0) {
@@ -1999,7 +2010,7 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
         // persistent: at most persist_blocks (one per CU; a multiple of 8 so a block keeps its XCD across rounds)
         const int nwork = p.tiles_m * p.tiles_n * p.splits;
         const int grid = grid256(c, nwork);
-        if (c.dynamic && !two_phase(c) && c.ws && nwork > 256 && nwork >= c.dynamic_min_work && nk / p.splits >= 8) {
+        if (c.dynamic && !two_phase(c) && c.ws && c.ws_bytes > SK_HDR_BYTES /* counters exist and were cleared */ && nwork > 256 && nwork >= c.dynamic_min_work && nk / p.splits >= 8) {
             // 256 resident blocks (32 per XCD label) that draw their tiles
             p.dyn_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c.ws) + DYN_CNT_OFF);
             c.last_cfg += 1;                                       // 513: the 256x256 kernel drawing its tiles
@@ -2455,7 +2466,8 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     }
 }
 extern "C" int molly_gemm_ctx_set_workspace(void* ctx, void* ptr, long bytes) { return ctx_set_workspace(ctx_of(ctx), ptr, bytes); }
-// the error word of the stream-K hand-off (a wait that gave up): a device read, for tests and diagnostics only
+// the error word of the stream-K hand-off (bit 0: a tile was cut into more pieces than the reducer lists — its sum would be short): a
+// device read, for tests and diagnostics only
 extern "C" int molly_gemm_ctx_streamk_timeouts(void* ctx) {
     const GemmCtx& c = ctx_of(ctx);
     if (!c.ws || c.ws_bytes <= SK_HDR_BYTES) return 0;

@@ -159,16 +159,33 @@ class Trainer:
         return n_micro // self.world
 
     def _mirror_skipped(self):
+        """After optimizer step s: copy the device-side skipped-step counter into pinned slot s % 2 and record an event behind
+        the copy.  (Two slots: the copy of step s never overwrites the value step s's reader may still be looking at.)"""
         scal = getattr(self.opt, "scal", None)
         if scal is None or not scal.is_cuda:
             return
         if getattr(self, "_skip_host", None) is None:
-            self._skip_host = torch.zeros(1, dtype=torch.float32, pin_memory=True)
-        self._skip_host.copy_(scal[3:4], non_blocking=True)
+            self._skip_host = torch.zeros(2, dtype=torch.float32, pin_memory=True)
+            self._skip_ev = [None, None]
+            self._skip_n = 0
+        k = self._skip_n % 2
+        self._skip_host[k:k + 1].copy_(scal[3:4], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._skip_ev[k] = ev
+        self._skip_n += 1
 
     def _skipped_seen(self) -> int:
-        h = getattr(self, "_skip_host", None)
-        return int(h[0]) if h is not None else 0
+        """Skipped steps among ALL earlier optimizer steps: waits for the copy made after the previous step (its event), so the
+        LR sequence after an overflow-skipped step is the same on every run — the tick does not depend on how far the host runs
+        ahead of the GPU.  The wait is free in steady state: it is called after this step's forward / backward have
+        been queued, so the GPU has a whole step of work while the host waits for the end of the previous one.  (No resume state
+        exists to persist it in: like the reference's run, the loop saves model weights only — save_model.)"""
+        if getattr(self, "_skip_host", None) is None or self._skip_n == 0:
+            return 0
+        k = (self._skip_n - 1) % 2
+        self._skip_ev[k].synchronize()
+        return int(self._skip_host[k])
 
     def train(self):
         """Window bookkeeping of the pasted HF loop (reference src/trainer/domain_loss.py:584-608): an epoch of
@@ -200,8 +217,8 @@ class Trainer:
                     continue
                 # DeepSpeed (what the reference runs under) does not step the LR scheduler on an overflow-skipped step: the
                 # schedule's tick is the number of steps APPLIED.  The skipped counter lives on the device; it is mirrored into
-                # pinned memory by an asynchronous copy after every step, so the tick trails a skip by at most one optimizer step
-                # and the loop never waits for the GPU.
+                # pinned memory behind every step and read back through that copy's event: the tick counts every earlier skip,
+                # deterministically, and the host still runs one step ahead of the GPU (_skipped_seen).
                 lr = linear_warmup_lr(step - self._skipped_seen(), a.learning_rate, warmup, total)
                 gnorm = self.opt.step(lr=lr)
                 self._mirror_skipped()
