@@ -34,6 +34,7 @@ struct AttnArgs {
     float scale_log2;                        // softmax scale * log2(e)
     int causal;
     int nblk, order_set;                     // block order (block_item): query blocks per head, (batch, kv head) pairs walked together
+    int prio;                                // wave_priority(): 0 none, n: the odd wave slot of every SIMD runs at priority n
 };
 
 // One LDS image serves row reads (ds_read_b128: tile row on the lane) AND transposed reads (ds_read_b64_tr_b16: tile
@@ -152,6 +153,22 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int base) {
 // back as whole rows: 16 bytes per lane, 4 full 256-byte rows per instruction (forward 189 -> 176 us at B8 T2048 H16 D128, same box).
 // `mul` is per lane (the row's 1/l in the forward, the softmax scale in the backward); rows >= rows_valid are not stored.
 // -DMOLLY_ATTN_ROWS_VIA_LDS=0 restores the direct stores (A/B).
+// -DMOLLY_ATTN_PHASE_PRIO=1 (A/B build): the matrix segments of the forward run at raised priority (the GEMM's per-segment flips)
+#ifndef MOLLY_ATTN_PHASE_PRIO
+#define MOLLY_ATTN_PHASE_PRIO 0
+#endif
+// -DMOLLY_ATTN_STAMP=1 (diagnostic build, tools/r04/attn_stamp.py): s_memtime laps around the segments of the forward's half-step,
+// summed per wave into g_attn_stamp[block][wave][8]; molly_exp_attn_stamps copies them out
+#ifndef MOLLY_ATTN_STAMP
+#define MOLLY_ATTN_STAMP 0
+#endif
+#if MOLLY_ATTN_STAMP
+__device__ unsigned long long g_attn_stamp[32768 * 4 * 8];
+#define ASTAMP(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ALAP(i) do { ASTAMP(tq1_); ts_[i] += tq1_ - tq0_; tq0_ = tq1_; } while (0)
+#else
+#define ALAP(i) do { } while (0)
+#endif
 #ifndef MOLLY_ATTN_ROWS_VIA_LDS
 #define MOLLY_ATTN_ROWS_VIA_LDS 1
 #endif
@@ -234,6 +251,22 @@ __device__ __forceinline__ BlockItem block_item(int bid, int nwg, int nkv, int g
     return BlockItem{pair / nkv, pair % nkv, rem % group, blk};
 }
 
+// Two workgroups share a CU: on every SIMD one wave of each, running the same loop — a matrix segment (S^T, then P.V: 16 MFMAs) and a
+// vector segment (the softmax: ~70 vector instructions + 16 exponentials) of about the same length.  The matrix pipe is busy 43-48 %
+// of the time (profiles/r03_pmc_sq_summary.csv): the two waves drift into the SAME segment and take turns on one pipe while the other
+// idles.  A fixed priority difference between the two resident waves lets one of them finish its segment first whenever they
+// collide, which puts them in opposite segments from then on.  The wave's slot on its SIMD (HW_ID bits 3:0) tells the two apart.
+__device__ __forceinline__ void wave_priority(int prio) {
+    if (prio <= 0) return;
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hwid));
+    if (hwid & 1) {
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+}
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -245,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    wave_priority(p.prio);
     // 1-D grid, XCD-aware item order (block_item); within a pair the heaviest causal blocks (largest query index) start first
     const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);
     const int qb = p.nblk - 1 - bi.blk;
@@ -287,6 +321,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int tw_last = p.causal ? min(t_last, (q0 + 31) / BKV) : t_last;
     const int qi = q0 + r;
 
+#if MOLLY_ATTN_STAMP
+    unsigned long long tq0_ = 0, tq1_ = 0, ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // S^T(32 keys x 32 queries) of one half tile
     auto qk_half = [&](const bf16_t* sK, int sub) {
         bf16x8 kf[NS];
@@ -298,8 +335,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         f32x16 sc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[e] = 0.f;
+        if (MOLLY_ATTN_PHASE_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < NS; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sc, 0, 0, 0);
+        if (MOLLY_ATTN_PHASE_PRIO) __builtin_amdgcn_s_setprio(0);
         return sc;
     };
     auto v_half = [&](const bf16_t* sV, int sub, bf16x8 (&vf)[2][ND]) {
@@ -342,19 +381,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[e] = fast_exp2(sc[e] * p.scale_log2 - m_ref);       // one fma + one exp2 per score
+        // (tried, round 4: the fma and the row sum as packed fp32 — v_pk_fma_f32 / v_pk_add_f32, two scores per instruction, 15 % fewer
+        // vector instructions in this loop: 164.0-164.9 us against 162.0-162.3 at B8 T2048 H16 D128, the backward unchanged too —
+        // these loops are not bound by vector-instruction throughput: profiles/r04_logs/attn_pk.log)
         // row sum as a tree (a 16-deep dependent add chain would serialise on the add latency)
         float rs[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) rs[g4] = (sc[4 * g4] + sc[4 * g4 + 1]) + (sc[4 * g4 + 2] + sc[4 * g4 + 3]);
         l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);                                                    // per-half-wave partial; merged at the end
         const bf16x8 p0 = acc_to_frag(sc, 0), p1 = acc_to_frag(sc, 8);
+#if MOLLY_ATTN_STAMP
+        asm volatile("" ::"v"(p0), "v"(p1));
+#endif
+        ALAP(2);                                          // max, rescale decision, 16 exponentials, row sum, bf16 packing
+        if (MOLLY_ATTN_PHASE_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][d], p0, o[d], 0, 0, 0);
             o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][d], p1, o[d], 0, 0, 0);
         }
+        if (MOLLY_ATTN_PHASE_PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
+#if MOLLY_ATTN_STAMP
+    ASTAMP(tq0_);
+#endif
     // ---- main loop: double-buffered K/V tiles (64 keys), two 32-key halves per tile.  Two waves per SIMD (<= 256
     // registers) provide the matrix-pipe / VALU overlap; a source-level software pipeline (QK^T of the next half issued
     // before the softmax of the current one) was measured slower here — it needs > 256 registers at hd 128.
@@ -378,16 +429,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 if (p.causal && (k0 + 32 * sub > q0 + 31)) continue;      // half entirely above the diagonal (uniform)
+                ALAP(0);                                  // loop overhead + LDS-DMA issue of the next tile (first half of a tile)
                 f32x16 sc = qk_half(sK, sub);
                 bf16x8 vf[2][ND];
                 v_half(sV, sub, vf);
+#if MOLLY_ATTN_STAMP
+                { float probe = sc[0] + sc[15]; asm volatile("" ::"v"(probe)); ++ts_[7]; }   // the S^T chain has completed
+#endif
+                ALAP(1);                                  // K fragment reads + the 8 S^T MFMAs (+ V fragment reads issued)
                 softmax_pv(sc, k0 + 32 * sub, vf);
+                ALAP(3);                                  // rest of the softmax (after the lap inside) + P.V MFMA issue
             }
         }
+        ALAP(0);
         dma_wait();
         __syncthreads();
+        ALAP(4);                                          // wait for the next tile + the workgroup barrier
         cur ^= 1;
     }
+    ALAP(0);
 
     // ---- epilogue: O[q][d] = o / l ; LSE2 = m + log2(l)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -395,6 +455,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     store_rows<HD, ND>(smem + wave * 32 * (HD + 8), o, inv, p.O + ((size_t)b * T + q0) * p.ldo + head * HD, p.ldo, T - q0, lane);
     if (qi < T && p.LSE && h == 0)
         p.LSE[((size_t)b * p.nh + head) * T + qi] = l_tot > 0.f ? m_run + log2f(l_tot) : -INFINITY;
+#if MOLLY_ATTN_STAMP
+    ALAP(5);                                              // epilogue
+    if (lane == 0 && blockIdx.x < 32768) {
+        unsigned long long* q = g_attn_stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] += ts_[i];
+    }
+#endif
 }
 
 
@@ -472,6 +540,7 @@ struct AttnBwdArgs {
     int causal;
     float* part;               // head-split dK/dV pass: per-(block, query head) accumulator images, register order (see SPLIT)
     int nblk, order_set;       // block order (block_item): query / key blocks per head, (batch, kv head) pairs walked together
+    int prio;                  // wave_priority()
 };
 
 template <int HD>
@@ -483,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    wave_priority(p.prio);
     const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);   // see attn_fwd_kernel
     const int qb = p.nblk - 1 - bi.blk;                        // heaviest first
     const int b = bi.b, kvh = bi.kvh, head = kvh * (p.nh / p.nkv) + bi.g;
@@ -616,6 +686,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    wave_priority(p.prio);
     // causal: key block 0 sees every query tile (heaviest) -> slot order = key-block order already is heaviest-first
     const int group = p.nh / p.nkv;
     const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, SPLIT ? group : 1, p.nblk, p.order_set);
@@ -807,6 +878,10 @@ __global__ __launch_bounds__(64) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
 // the L2 footprint (r04 attn_order.log, B8 T2048 16/8 heads: one pair at a time 188.7 us forward, two 173.8, four 168.6, round 3's
 // order 173.3; every XCD has the same work, so the labels finish together) — when the pairs divide evenly over the 8 labels;
 // otherwise round 3's order (0).  MOLLY_ATTN_ORDER_SET (forward, dQ pass) / MOLLY_ATTN_ORDER_SET_DKV (dK / dV passes) pin a value.
+static int wave_prio() {          // MOLLY_ATTN_PRIO: see wave_priority()
+    static const int v = [] { const char* e = getenv("MOLLY_ATTN_PRIO"); return e ? atoi(e) : 0; }();
+    return v;
+}
 static int order_set(int dkv, int npairs) {
     static const int v[2] = {[] { const char* e = getenv("MOLLY_ATTN_ORDER_SET"); return e ? atoi(e) : -1; }(),
                              [] { const char* e = getenv("MOLLY_ATTN_ORDER_SET_DKV"); return e ? atoi(e) : -1; }()};
@@ -830,7 +905,7 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     MOLLY_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0, "attn_fwd: alignment");
     MOLLY_CHECK(B > 0 && T > 0, "attn_fwd: empty problem");
     AttnArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, lse2, kv_lo, kv_hi, T, n_heads,
-               n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal, cdiv(T, BQ), order_set(0, B * n_kv_heads)};
+               n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal, cdiv(T, BQ), order_set(0, B * n_kv_heads), wave_prio()};
     if (head_dim < 64) {
         const dim3 g(n_heads * B, cdiv(T, 128));
 #define MOLLY_SMALL(HD_) case HD_: hipLaunchKernelGGL(attn_fwd_small_kernel<HD_>, g, dim3(128), 0, (hipStream_t)stream, p); break
@@ -857,6 +932,15 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     MOLLY_LAUNCH_CHECK();
     return 0;
 }
+
+#if MOLLY_ATTN_STAMP
+extern "C" int molly_exp_attn_stamps(void* dst, int clear) {
+    if (dst) (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_stamp), sizeof(unsigned long long) * 32768 * 4 * 8);
+    if (clear) (void)hipMemset((void*)nullptr, 0, 0);
+    if (clear) { void* p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_attn_stamp)); (void)hipMemset(p, 0, sizeof(unsigned long long) * 32768 * 4 * 8); }
+    return 0;
+}
+#endif
 
 // floats of scratch with which molly_attn_bwd_ws runs the dK / dV passes split by query head (0: the split does not apply —
 // the grid over (kv head, key block) already fills the chip, or there is one query head per kv head, or head_dim != 128)
@@ -885,7 +969,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     hipStream_t st = (hipStream_t)stream;
     AttnBwdArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, (const bf16_t*)O, lse2, delta_ws,
                   (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, kv_lo, kv_hi, T, n_heads, n_kv_heads, ldq, ldk, ldv, ldo,
-                  lddq, lddk, lddv, scale, scale * LOG2E, causal, nullptr, cdiv(T, BQ), order_set(0, B * n_kv_heads)};
+                  lddq, lddk, lddv, scale, scale * LOG2E, causal, nullptr, cdiv(T, BQ), order_set(0, B * n_kv_heads), wave_prio()};
     const size_t lds_dq = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
     const size_t lds_dkv = lds_dq + 2 * 128 * sizeof(float);
     static bool attr_set = false;

@@ -471,15 +471,38 @@ class OmicsOne(_MetaSafe):
                 if w is not None:
                     w()
             wait_embed = wait_proj = None
-        for name, eng, proj in (("dna_rna", rt.dna, "dna_rna_projector"), ("protein", rt.prot, "protein_projector")):
-            if name not in st.groups:
-                continue
+        present = [(name, eng, proj) for name, eng, proj in (("dna_rna", rt.dna, "dna_rna_projector"), ("protein", rt.prot, "protein_projector"))
+                   if name in st.groups]
+        # Both modality groups in one batch (BASELINE configs 3 / 4: DNA / RNA spans through the NT encoder, protein spans through
+        # ESM-2) and both encoders frozen: the two stacks share nothing, and at one sample per GPU (512-1,024 rows) neither fills
+        # the chip — a projection is 40-160 workgroups for 256 CUs — so the first one runs on a side stream with a GEMM context
+        # (scratch) of its own, beside the second.  Same kernels, same values; MOLLY_ENC_STREAMS=0 runs them one after the other.
+        side_done = None
+        if len(present) == 2 and not rt.train_bio and os.environ.get("MOLLY_ENC_STREAMS", "1") != "0":
+            if getattr(rt, "enc_stream", None) is None:
+                rt.enc_stream = torch.cuda.Stream(device=rt.dev)
+                rt.enc_ctx = ops.GemmContext()
+                rt.enc_ctx.ensure_workspace(0, rt.dev)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())              # the staged ids (and whatever wrote the engine's buffers last)
+            rt.enc_stream.wait_event(ready)
+        for k, (name, eng, proj) in enumerate(present):
             ids64, dst, N, K = st.groups[name]
+            on_side = len(present) == 2 and k == 0 and getattr(rt, "enc_stream", None) is not None and not rt.train_bio \
+                and os.environ.get("MOLLY_ENC_STREAMS", "1") != "0"
             try:
-                enc_out = eng.forward(ids64, training=keep_for_backward and rt.train_bio)
+                if on_side:
+                    with torch.cuda.stream(rt.enc_stream), ops.use_gemm_context(rt.enc_ctx):
+                        enc_out = eng.forward(ids64, training=False)
+                        side_done = torch.cuda.Event()
+                        side_done.record(rt.enc_stream)
+                else:
+                    enc_out = eng.forward(ids64, training=keep_for_backward and rt.train_bio)
             except Exception as e:  # reference re-wraps encoder failures (omics_one.py:89-90)
                 raise RuntimeError(f"Error processing omic sequences: {e}")
             encoded.append((name, eng, proj, enc_out, dst))
+        if side_done is not None:
+            torch.cuda.current_stream().wait_event(side_done)
         if wait_embed is not None:
             wait_embed()
         ops.copy_rows(rt.llm.embed, hs, M, src_idx32=st.ids32)

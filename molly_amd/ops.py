@@ -77,6 +77,10 @@ class GemmContext:
         if mode:
             self.set("persistent_blocks", 256 if mode == "dyn" else int(mode))
             self.set("dynamic", 1 if mode == "dyn" else 0)
+        # A/B knob for whole-step measurements: MOLLY_GEMM_SET="small3=1,group_m=8" applies to every context created afterwards
+        for kv in filter(None, os.environ.get("MOLLY_GEMM_SET", "").split(",")):
+            k, v = kv.split("=")
+            self.set(k.strip(), int(v))
 
     def set(self, key: str, value: int):
         lib().call("molly_gemm_ctx_set", self.handle, GEMM_KEYS[key], int(value))
