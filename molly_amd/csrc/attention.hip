@@ -104,6 +104,40 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
     }
 }
 
+// ---- the same staging with the address arithmetic hoisted out of the tile loop (round 4).  Stamped (tools/r04/attn_stamp.py,
+// profiles/r04_logs/attn_stamp.log), a wave of the forward spent ~470 cycles per 32-key half-step issuing the next tile's LDS-DMA:
+// per piece a clamp, a 32-bit multiply (quarter rate), an add-shift and the address-space checks of the generic -> LDS pointer
+// cast — against 512 cycles of MFMA.  For a tile that lies entirely inside the sequence nothing needs clamping, and the slot a
+// lane fills differs between a wave's pieces only by a row step and two XOR-ed column bits:
+//   piece i of wave w = instruction w * NP + i:  row = row0 + RSTEP * i,  col = col0 ^ cx(i)      (row0 / col0: stage_lane_const)
+// so a piece costs one XOR, one three-operand add with a scalar, the m0 move and the load.
+template <int HD> struct StageConst { unsigned rowb, colb; };          // per lane: row0 * ld * 2 bytes, col0 * 2 bytes
+template <int HD>
+__device__ __forceinline__ void stage_lane_const(int ld, int wave, int lane, unsigned& rowb, unsigned& colb) {
+    constexpr int NCB = HD / 16, NP = BKV * HD * 2 / 1024 / 4;
+    const int P = wave * NP * 64 + lane;                  // piece 0 of this wave
+    const int blk = P >> 3, cin = P & 7;
+    const int rowblk = blk / NCB, cbs = blk % NCB;
+    const int b0 = rowblk & 1, b1 = (rowblk >> 1) & 1;
+    rowb = (unsigned)(rowblk * 4 + (cin >> 1)) * (unsigned)ld * 2u;
+    colb = (unsigned)((((cbs ^ b0) << 4) + (((cin & 1) ^ b1) << 3)) * 2);
+}
+// base = tile row 0 of the (batch, head) slice (wave-uniform), lds_addr = LDS byte address of the tile image (wave-uniform, 32 bit)
+template <int HD>
+__device__ __forceinline__ void stage_tile_fast(const char* base, int ld, unsigned rowb, unsigned colb, unsigned lds_addr, int wave) {
+    constexpr int NP = BKV * HD * 2 / 1024 / 4;           // pieces per wave: 4 (hd 128) / 2 (hd 64)
+    constexpr int RSTEP = HD == 128 ? 4 : 8;              // tile rows between two pieces of a wave
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        // hd 128: rowblk = instruction -> b0 = i & 1, b1 = (i >> 1) & 1 (w * NP is a multiple of 4); hd 64: rowblk = 2 * instruction +
+        // (lane >> 5) -> b0 is a lane bit (in colb already), b1 = i & 1
+        const unsigned cx = HD == 128 ? (unsigned)((((i & 1) << 4) ^ (((i >> 1) & 1) << 3)) * 2) : (unsigned)(((i & 1) << 3) * 2);
+        const unsigned off = rowb + (colb ^ cx) + (unsigned)(i * RSTEP * 2) * (unsigned)ld;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + (unsigned)((wave * NP + i) * 1024));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+    }
+}
+
 // "this register has arrived": an empty asm that READS v makes hipcc place the wait for v's pending global load HERE.  Used on
 // the per-kernel operand fragments (Q, dO, K, V rows, row statistics) right after their loads: left to itself hipcc waits for
 // them lazily inside the tile loop with counted `vmcnt(N)` that cannot see the asm-issued LDS-DMA — and those waits would then
@@ -409,21 +443,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     // ---- main loop: double-buffered K/V tiles (64 keys), two 32-key halves per tile.  Two waves per SIMD (<= 256
     // registers) provide the matrix-pipe / VALU overlap; a source-level software pipeline (QK^T of the next half issued
     // before the softmax of the current one) was measured slower here — it needs > 256 registers at hd 128.
-    if (t_last >= t_first) {
-        stage_kv<HD, false>(Kb, p.ldk, t_first * BKV, T, smem, wave, lane);
-        stage_kv<HD, true>(Vb, p.ldv, t_first * BKV, T, smem + TILE, wave, lane);
-    }
+    // K/V tile `t` into stage `stg`: the hoisted form for tiles inside the sequence, the clamping one for a ragged last tile
+    unsigned rbK, rbV, cbK, cbV;
+    stage_lane_const<HD>(p.ldk, wave, lane, rbK, cbK);
+    stage_lane_const<HD>(p.ldv, wave, lane, rbV, cbV);
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));
+    auto stage_tile = [&](int t, int stg) {
+        const int key0 = t * BKV;
+        if (key0 + BKV <= T) {
+            stage_tile_fast<HD>(reinterpret_cast<const char*>(Kb + (size_t)key0 * p.ldk), p.ldk, rbK, cbK, smem_lds + stg * 2 * TILE * 2, wave);
+            stage_tile_fast<HD>(reinterpret_cast<const char*>(Vb + (size_t)key0 * p.ldv), p.ldv, rbV, cbV, smem_lds + (stg * 2 + 1) * TILE * 2, wave);
+        } else {
+            stage_kv<HD, false>(Kb, p.ldk, key0, T, smem + stg * 2 * TILE, wave, lane);
+            stage_kv<HD, true>(Vb, p.ldv, key0, T, smem + stg * 2 * TILE + TILE, wave, lane);
+        }
+    };
+    if (t_last >= t_first) stage_tile(t_first, 0);
     dma_wait();
     __syncthreads();
     int cur = 0;
     for (int t = t_first; t <= t_last; ++t) {
         const bf16_t* sK = smem + cur * 2 * TILE;
         const bf16_t* sV = sK + TILE;
-        if (t + 1 <= t_last) {
-            bf16_t* nK = smem + (cur ^ 1) * 2 * TILE;
-            stage_kv<HD, false>(Kb, p.ldk, (t + 1) * BKV, T, nK, wave, lane);
-            stage_kv<HD, true>(Vb, p.ldv, (t + 1) * BKV, T, nK + TILE, wave, lane);
-        }
+        if (t + 1 <= t_last) stage_tile(t + 1, cur ^ 1);
         const int k0 = t * BKV;
         if (t <= tw_last) {
 #pragma unroll
@@ -605,21 +647,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int kv_end = p.causal ? min(blk_q_last + 1, hi) : hi;
     const int t_first = lo / BKV;
     const int t_last = kv_end > lo ? (kv_end - 1) / BKV : t_first - 1;
-    if (t_last >= t_first) {
-        stage_kv<HD, false>(Kb, p.ldk, t_first * BKV, T, smem, wave, lane);
-        stage_kv<HD, true>(Vb, p.ldv, t_first * BKV, T, smem + TILE, wave, lane);
-    }
+    unsigned rbK, rbV, cbK, cbV;                               // see attn_fwd_kernel
+    stage_lane_const<HD>(p.ldk, wave, lane, rbK, cbK);
+    stage_lane_const<HD>(p.ldv, wave, lane, rbV, cbV);
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));
+    auto stage_tile = [&](int t, int stg) {
+        const int key0 = t * BKV;
+        if (key0 + BKV <= T) {
+            stage_tile_fast<HD>(reinterpret_cast<const char*>(Kb + (size_t)key0 * p.ldk), p.ldk, rbK, cbK, smem_lds + stg * 2 * TILE * 2, wave);
+            stage_tile_fast<HD>(reinterpret_cast<const char*>(Vb + (size_t)key0 * p.ldv), p.ldv, rbV, cbV, smem_lds + (stg * 2 + 1) * TILE * 2, wave);
+        } else {
+            stage_kv<HD, false>(Kb, p.ldk, key0, T, smem + stg * 2 * TILE, wave, lane);
+            stage_kv<HD, true>(Vb, p.ldv, key0, T, smem + stg * 2 * TILE + TILE, wave, lane);
+        }
+    };
+    if (t_last >= t_first) stage_tile(t_first, 0);
     dma_wait();
     __syncthreads();
     int cur = 0;
     for (int t = t_first; t <= t_last; ++t) {
         const bf16_t* sK = smem + cur * 2 * TILE;
         const bf16_t* sV = sK + TILE;
-        if (t + 1 <= t_last) {
-            bf16_t* nK = smem + (cur ^ 1) * 2 * TILE;
-            stage_kv<HD, false>(Kb, p.ldk, (t + 1) * BKV, T, nK, wave, lane);
-            stage_kv<HD, true>(Vb, p.ldv, (t + 1) * BKV, T, nK + TILE, wave, lane);
-        }
+        if (t + 1 <= t_last) stage_tile(t + 1, cur ^ 1);
         const int k0 = t * BKV;
         const bool skip = p.causal && (k0 > q0 + 31);
         if (!skip) {
@@ -724,14 +773,28 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     const int n_tiles = nqt > qt_first ? nqt - qt_first : 0;
     const int total = SPLIT ? n_tiles : n_tiles * group;         // iteration it -> (head g, tile qt_first + j)
 
-    auto stage = [&](int it, int stg) {
-        const int g = SPLIT ? g0 : it / n_tiles, qt = qt_first + it % n_tiles;
+    unsigned rbQ, rbD, cbQ, cbD;
+    stage_lane_const<HD>(p.ldq, wave, lane, rbQ, cbQ);
+    stage_lane_const<HD>(p.ldo, wave, lane, rbD, cbD);
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));
+    // iteration it = (head g of the group, query tile qt_first + j): both walked by counters (a division by n_tiles per staged
+    // tile and another per computed one was ~100 scalar / vector instructions per iteration)
+    int sg = 0, sj = 0;                                          // (g, j) of the NEXT tile to stage
+    int cj = 0;                                                  // j of the tile being computed
+    auto stage = [&](int /*it*/, int stg) {
+        const int g = SPLIT ? g0 : sg, qt = qt_first + sj;
+        if (++sj == n_tiles) { sj = 0; ++sg; }
         const int head = kvh * group + g;
         const bf16_t* Qb = p.Q + (size_t)b * T * p.ldq + head * HD;
         const bf16_t* Db = p.dO + (size_t)b * T * p.ldo + head * HD;
         bf16_t* sQ = smem + stg * 2 * TILE;
-        stage_kv<HD, false>(Qb, p.ldq, qt * BKV, T, sQ, wave, lane);
-        stage_kv<HD, false>(Db, p.ldo, qt * BKV, T, sQ + TILE, wave, lane);
+        if (qt * BKV + BKV <= T) {                                   // (the hoisted form: attn_fwd_kernel)
+            stage_tile_fast<HD>(reinterpret_cast<const char*>(Qb + (size_t)qt * BKV * p.ldq), p.ldq, rbQ, cbQ, smem_lds + stg * 2 * TILE * 2, wave);
+            stage_tile_fast<HD>(reinterpret_cast<const char*>(Db + (size_t)qt * BKV * p.ldo), p.ldo, rbD, cbD, smem_lds + (stg * 2 + 1) * TILE * 2, wave);
+        } else {
+            stage_kv<HD, false>(Qb, p.ldq, qt * BKV, T, sQ, wave, lane);
+            stage_kv<HD, false>(Db, p.ldo, qt * BKV, T, sQ + TILE, wave, lane);
+        }
         // row statistics through LDS-DMA as well (4 B/lane): an ordinary global_load here would make hipcc drain
         // vmcnt(0) — i.e. the whole tile prefetch — at its first use (guide §5 "Three .s-level traps" (b))
         if (wave < 2) {
@@ -749,7 +812,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     int cur = 0;
     for (int it = 0; it < total; ++it) {
         if (it + 1 < total) stage(it + 1, cur ^ 1);
-        const int qt = qt_first + it % n_tiles;
+        const int qt = qt_first + cj;
+        if (++cj == n_tiles) cj = 0;
         const int qbase = qt * BKV;
         const bf16_t* sQ = smem + cur * 2 * TILE;
         const bf16_t* sD = sQ + TILE;

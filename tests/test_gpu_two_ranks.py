@@ -147,6 +147,82 @@ def test_bench_launches_its_own_ranks_end_to_end():
     assert c["world_size"] == 2 and c["backend"] == "gloo" and c["preflight"]["all_reduce"] is True
     assert c["comm_bytes_per_step_per_gpu"] > 0 and c["buckets"] >= 1 and "step_ms_p50_no_overlap" in c
     assert d["config"]["global_batch"] == 4
+    # round 4: the launch-shape A/B before the warm-up, the per-bucket timings and the backend's own count of the world
+    ab = c["gemm_mode_ab"]
+    assert set(ab["ms_per_step"]) == {"-3", "dyn", "0"} and ab["chosen"] in ab["ms_per_step"] and all(v > 0 for v in ab["ms_per_step"].values())
+    assert str(c["gemm_blocks_mode"]) == ab["chosen"]
+    assert c["world_size_by_all_reduce"] == 2
+    t = c["timings_us"]
+    assert t["reduce_scatter"]["n"] == 2 * c["buckets"] and t["all_gather"]["n"] == 2 * c["buckets"]          # 2 timed steps
+    assert len(t["reduce_scatter"]["us_per_bucket"]) == c["buckets"] and t["all_gather"]["us_p50"] > 0
+
+
+def test_four_ranks_contend_for_one_chip():
+    """`bench.py --gpus 4` on the ONE GPU of the box (gloo as the transport): four ranks' GEMMs, communication
+    streams and optimizer kernels share the chip — each launch shape of the 256x256 GEMM (-3 | dyn | 0) runs for real beside the
+    other ranks' kernels during the launch-shape A/B, then the timed steps run in the chosen one.  Nothing above world 2 had ever
+    executed the overlapped path; a hang or a wrong ticket shows here as a timeout or a diverged loss.  Reference role: the 8 ranks
+    of scripts/train/examples/run_train_4B_z2_b1.sh:60-66."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MOLLY_GEMM_PERSISTENT_MULTI")}
+    env.update(MOLLY_BENCH_DEVICE="0", MOLLY_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--seq", "1024", "--k-protein", "256", "--exposed-comm-steps", "0", "--gemm-mode-ab-steps", "1", "--bucket-mib", "64"],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["comm"]
+    assert d["n_gpus"] == 4 and c["world_size"] == 4 and c["world_size_by_all_reduce"] == 4 and d["config"]["global_batch"] == 8
+    assert c["buckets"] >= 7 and c["overlap"] is True                       # 3.4 GB of bf16 in 64 MiB buckets
+    assert set(c["gemm_mode_ab"]["ms_per_step"]) == {"-3", "dyn", "0"}
+    assert 0.5 < d["loss"] < 20.0                                           # the step still trains (random-init CE ~ ln V = 11.9)
+
+
+def _rccl_world1_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import datetime
+    dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(minutes=5), device_id=dev)
+    from molly_amd.trainer.zero2 import _DistComm, preflight_collectives
+    rep = preflight_collectives(dev)
+    # the in-place forms the ZeRO step uses, on a bucket-sized buffer, through RCCL's own kernels (world 1: a copy, but the library
+    # is loaded, the communicator exists, the aliased send / receive buffers are accepted and the stream semantics are RCCL's)
+    comm = _DistComm()
+    g = torch.arange(1 << 22, device=dev).remainder(251).to(torch.bfloat16)
+    want = g.clone()
+    side = torch.cuda.Stream(device=dev, priority=-1)
+    ev = torch.cuda.Event(); ev.record(); side.wait_event(ev)
+    with torch.cuda.stream(side):
+        comm.reduce_scatter(g, g)
+        comm.all_gather(g, g)
+        comm.all_reduce_region(g)
+    torch.cuda.current_stream().wait_stream(side)
+    ok = bool(torch.equal(g, want))
+    try:
+        ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:      # noqa: BLE001
+        ver = f"unknown ({e})"
+    ret[0] = (rep, ok, ver)
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+
+
+def test_rccl_first_contact_world_one():
+    """RCCL itself on the test box (one rank is all one GPU allows): process-group construction exactly as bench.py does it
+    (backend nccl, device_id, timeout — reference src/train.py:606-610), the collective pre-flight, and the three in-place collectives
+    of the ZeRO step on a high-priority side stream.  It cannot measure xGMI; it does catch a library that does not load, a refused
+    aliased buffer or a device_id / IPC-mode problem before the driver's first 8-GPU run does."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_world1_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    rep, ok, ver = ret[0]
+    assert ok and rep["world"] == 1 and rep["all_reduce"] is True and rep["inplace_reduce_scatter"] and rep["inplace_all_gather"], (rep, ok, ver)
 
 
 def test_world2_smoke_entry_point():
