@@ -5,9 +5,11 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-secondary"
+B="--no-cpu-baseline --no-secondary --no-vendor-gemm --no-batch8-reference"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_step -- python3 $R/bench.py --steps 4 --warmup 2 $B > $O/prof_step.log 2>&1
 cp /tmp/p_step/*/*kernel_stats.csv $R/profiles/r04_bench_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_step8 -- python3 $R/bench.py --batch 8 --steps 4 --warmup 2 $B > $O/prof_step8.log 2>&1
+cp /tmp/p_step8/*/*kernel_stats.csv $R/profiles/r04_bench_b8_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3 -- python3 $R/bench.py --steps 3 --warmup 2 $B --model 4b --batch 1 --seq 3072 --micro "dna:512,rna:512,protein:512;dna:512,rna:512,protein:512" > $O/prof_c3.log 2>&1
 cp /tmp/p_c3/*/*kernel_stats.csv $R/profiles/r04_c3_4b_b1_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- python3 $R/bench.py --steps 3 --warmup 2 $B --model 8b --batch 1 --seq 4096 --micro "protein:1024;dna:1000" > $O/prof_c4.log 2>&1
@@ -20,6 +22,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -- pyt
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -- python3 $R/bench.py --steps 1 --warmup 1 $B > $O/pmc_w.log 2>&1
 cd $R
 python tools/pmc_sq_summary.py r04 "round 4: XCD-aware attention block order, hoisted attention staging, two-stream encoders" /tmp/p_sq_a /tmp/p_sq_b | head -30
-python tools/pmc_hbm_traffic.py /tmp/p_f /tmp/p_w r04 | head -30
+python tools/pmc_hbm_traffic.py /tmp/p_f /tmp/p_w r04 "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary   (MI355X, B=16 T=2048 K=512; 2 steps incl. warmup)" | head -40
 cp profiles/r04_* $O/ 2>/dev/null
 ls -la $O | head -40
