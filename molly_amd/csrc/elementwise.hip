@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
         for (int e = 0; e < 4; ++e) {
             const float ga = bflo(g[e]), gb = bfhi(g[e]);
             // HF computes silu in bf16 (rounds), then the product (rounds)
-            const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+            const float sa = bf2f(f2bf(ga * sigmoid_fast(ga))), sb = bf2f(f2bf(gb * sigmoid_fast(gb)));
             o[e] = pack_bf2(sa * bflo(u[e]), sb * bfhi(u[e]));
         }
         st_stream<u32x4>(out + (size_t)r * ff + c * 8, o);

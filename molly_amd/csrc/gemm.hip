@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float ga = bflo(gq[jj][e]), gb = bfhi(gq[jj][e]);
-                    const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+                    const float sa = bf2f(f2bf(ga * sigmoid_fast(ga))), sb = bf2f(f2bf(gb * sigmoid_fast(gb)));
                     aq[jj][e] = pack_bf2(sa * bflo(uq[jj][e]), sb * bfhi(uq[jj][e]));
                 }
             }
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float ga = bflo(gq[e]), gb = bfhi(gq[e]);
-                    const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+                    const float sa = bf2f(f2bf(ga * sigmoid_fast(ga))), sb = bf2f(f2bf(gb * sigmoid_fast(gb)));
                     o[e] = pack_bf2(sa * bflo(uq[e]), sb * bfhi(uq[e]));
                 }
                 *reinterpret_cast<u32x2*>(act + (size_t)m * p.ldres + c) = o;
@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(256) void rows_tail_swiglu_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float ga = bflo(gq[e]), gb = bfhi(gq[e]);
-            const float sa = bf2f(f2bf(ga / (1.f + __expf(-ga)))), sb = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+            const float sa = bf2f(f2bf(ga * sigmoid_fast(ga))), sb = bf2f(f2bf(gb * sigmoid_fast(gb)));
             o[e] = pack_bf2(sa * bflo(uq[e]), sb * bfhi(uq[e]));
         }
         *reinterpret_cast<u32x2*>(out + (size_t)m * ldo + n) = o;
