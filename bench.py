@@ -467,11 +467,11 @@ def main(argv=None):
     micro = parse_micro(args.micro or f"protein:{args.k_protein}")
     GA = len(micro)
     cfg = C.molly(args.model, k_tokens=max(k for spans in micro for _, k in spans))
+    torch.manual_seed(1234)                  # before the shells: whatever they materialise at construction comes from this generator
     m = molly_amd.OmicsOne(cfg)
     m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)
     m.dna_rna_model = molly_amd.EsmForMaskedLM(cfg.dna_rna_config)
     m.protein_model = molly_amd.EsmForMaskedLM(cfg.protein_config)
-    torch.manual_seed(1234)
     if args.train_mode in ("full", "bio"):
         m.prepare(dev, random_init_seed=1234, train_bio=args.train_mode == "bio")   # same seed on every rank: replicas start identical
     else:

@@ -16,6 +16,7 @@ batches = [synth_batch(B, T, [("protein", 512)], seed=42 + 1000 * i) for i in ra
 
 
 def run(tag):
+    torch.manual_seed(1234)                      # (the embedding shell is materialised from the global generator at construction)
     cfg = C.molly("1.7b", k_tokens=512)
     m = molly_amd.OmicsOne(cfg)
     m.model = molly_amd.Qwen3ForCausalLM(cfg.text_config)
