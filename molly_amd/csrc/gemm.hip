@@ -523,15 +523,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int ntile = ctm * ctn;
         // K-slice is the SLOWEST index: the work items that run side by side on one XCD then belong to one slice and
         // keep sharing operand panels through its L2 (slices of one tile share nothing: they read different K ranges)
-        t.split = SKM ? 0 : work / ntile;
-        const int swz = work - t.split * ntile;
+        // (this runs twice per tile in every wave, once of them inside the K loop: without slices — every launch of the step's big
+        // GEMMs — it is two unsigned 32-bit divisions; the general form below adds one more and two 64-bit ones, ~0.7 us per tile)
+        const bool one_slice = SKM || p.splits == 1;
+        t.split = one_slice ? 0 : work / ntile;
+        const unsigned swz = (unsigned)(work - t.split * ntile);
         const int GROUP_M = p.group_m;
-        const int per_group = GROUP_M * ctn;
-        const int grp = swz / per_group;
+        const unsigned per_group = (unsigned)(GROUP_M * ctn);
+        const int grp = (int)(swz / per_group);
+        const unsigned in_grp = swz - (unsigned)grp * per_group;
         const int first_m = grp * GROUP_M;
-        const int gsz = min(ctm - first_m, GROUP_M);
-        t.m0 = (first_m + (swz % per_group) % gsz) * 256;
-        t.n0 = ((swz % per_group) / gsz) * 256;
+        const unsigned gsz = (unsigned)min(ctm - first_m, GROUP_M);
+        const unsigned nq = in_grp / gsz;
+        t.m0 = (first_m + (int)(in_grp - nq * gsz)) * 256;
+        t.n0 = (int)nq * 256;
         if constexpr (SKM) {
             // the piece of tile `work` inside [sk_u0, sk_u1); split = 0: the whole tile, 1: a piece (slab + ticket); gi = the tile
             const int ua = max(sk_u0, work * sk_upt) - work * sk_upt, ub = min(sk_u1, (work + 1) * sk_upt) - work * sk_upt;
@@ -539,6 +544,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             t.nk = (ub == sk_upt ? nk_all : ub * p.sk) - t.kt0;
             t.split = t.nk == nk_all ? 0 : 1;
             t.gi = work;
+        } else if (one_slice) {
+            t.kt0 = 0;
+            t.nk = nk_all;
         } else {
             t.kt0 = (int)((long)nk_all * t.split / p.splits);
             t.nk = (int)((long)nk_all * (t.split + 1) / p.splits) - t.kt0;      // K-tiles of this slice
