@@ -1,3 +1,4 @@
+# whole-step / kernel A/B of the working tree against the committed library (python tools/build_head_variant.py first)
 O=gpurun_out/r04; mkdir -p $O
 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_streamk.py tests/test_gpu_dynamic_fetch.py tests/test_gpu_small_split.py -x -q -m gpu -k "gemm or streamk or dynamic or split" 2>&1 | tail -2
 python tools/gemm_diag/cmp_libs.py head 2>&1 | tail -2
