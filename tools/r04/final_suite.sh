@@ -1,0 +1,3 @@
+mkdir -p gpurun_out/r04
+python -m pytest tests -x -q -m gpu > gpurun_out/r04/final_gpu_suite.log 2>&1; tail -3 gpurun_out/r04/final_gpu_suite.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
