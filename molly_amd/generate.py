@@ -252,10 +252,53 @@ def _process_logits(logits, generated, temperature, top_k, top_p, repetition_pen
     return logits
 
 
+class NoRepeatNGram:
+    """HF `NoRepeatNGramLogitsProcessor` (HF:generation/logits_process.py, `_calc_banned_ngram_tokens`): a token is banned when it
+    would complete an n-gram that already occurs in the row's generated sequence.  HF rebuilds the n-gram table of every row at every
+    step; here it is kept per row and extended by the one n-gram each new token completes.  The reference passes
+    `no_repeat_ngram_size` through to HF generate (src/model/omics_one.py:199-200, 227); with `inputs_embeds` and no `input_ids` HF's
+    `input_ids` hold the GENERATED tokens only, so the prompt never contributes n-grams."""
+
+    def __init__(self, n: int, batch: int):
+        assert n >= 1
+        self.n = n
+        self.table = [dict() for _ in range(batch)]            # row -> {(n-1)-gram prefix: set of tokens that followed it}
+        self.hist = [[] for _ in range(batch)]
+
+    def push(self, tokens):
+        """tokens: the B tokens just appended (python ints)."""
+        n = self.n
+        for b, t in enumerate(tokens):
+            h = self.hist[b]
+            h.append(int(t))
+            if len(h) >= n:
+                self.table[b].setdefault(tuple(h[len(h) - n:len(h) - 1]), set()).add(h[-1])
+
+    def banned(self):
+        """per row: the tokens that must not come next (HF: none while fewer than n - 1... tokens exist: cur_len + 1 < n)."""
+        n, out = self.n, []
+        for b, h in enumerate(self.hist):
+            if len(h) + 1 < n:
+                out.append(())
+            else:
+                out.append(tuple(self.table[b].get(tuple(h[len(h) + 1 - n:]), ())))
+        return out
+
+    def apply(self, logits: torch.Tensor) -> torch.Tensor:
+        rows, cols = [], []
+        for b, toks in enumerate(self.banned()):
+            rows += [b] * len(toks)
+            cols += list(toks)
+        if rows:
+            logits = logits.clone()
+            logits[torch.tensor(rows, device=logits.device), torch.tensor(cols, device=logits.device)] = float("-inf")
+        return logits
+
+
 @torch.no_grad()
 def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_list=None, max_new_tokens=3072, do_sample=True,
              temperature=0.8, top_p=0.95, top_k=None, repetition_penalty=None, pad_token_id=None, eos_token_id=None,
-             generator: Optional[torch.Generator] = None) -> torch.Tensor:
+             generator: Optional[torch.Generator] = None, no_repeat_ngram_size: Optional[int] = None) -> torch.Tensor:
     """Returns the NEW tokens only, int64 [B, n_new] (what HF returns when called with inputs_embeds and no input_ids)."""
     sess = GenerationSession(model, max_new_tokens)
     logits = sess.prefill(input_ids, attention_mask, omic_ids, omic_info_list)
@@ -275,7 +318,12 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
     if fused:
         gdev = generator.device if generator is not None else "cpu"
         seed = int(torch.randint(0, 1 << 62, (1,), generator=generator, device=gdev, dtype=torch.int64).item())
+    ngram = NoRepeatNGram(int(no_repeat_ngram_size), B) if no_repeat_ngram_size else None
     for it in range(max_new_tokens):
+        if ngram is not None:
+            # HF's order: repetition penalty, then the n-gram ban, then the warpers; a banned logit is -inf and the penalty leaves -inf
+            # where it is, so banning first gives the same scores
+            logits = ngram.apply(logits)
         if fused:
             nxt = ops.sample_logits(logits, out if out.shape[1] else None, repetition_penalty, temperature, top_k, top_p,
                                     seed, it)
@@ -288,6 +336,8 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
                 nxt = ops.argmax(lg) if lg.dtype == torch.float32 else lg.argmax(-1)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
         out = torch.cat([out, nxt[:, None]], 1)
+        if ngram is not None:
+            ngram.push(nxt.tolist())
         if eos is not None:
             unfinished = unfinished & ~torch.isin(nxt, eos)
             if not bool(unfinished.any()):

@@ -302,3 +302,18 @@ def test_gemm_scratch_refuses_to_grow_inside_a_capture():
     with pytest.raises(RuntimeError, match="during a hipGraph capture"):
         with torch.cuda.graph(g):
             ctx.ensure_workspace(ctx.ws.numel() * 4 + (8 << 20))
+
+
+def test_generate_with_no_repeat_ngram(tiny_meta):
+    """`no_repeat_ngram_size` through the reference's generate signature (src/model/omics_one.py:199-200, 227): greedy decoding of the
+    random-init tiny model repeats itself at once without it; with n = 2 no bigram of a row's new tokens occurs twice.  (The ban itself
+    is checked against HuggingFace's processor in tests/test_no_repeat_ngram.py.)"""
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)
+    out = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=24, no_repeat_ngram_size=2)
+    assert out.shape == (2, 24)
+    for row in out.tolist():
+        grams = list(zip(row[:-1], row[1:]))
+        assert len(grams) == len(set(grams)), row
+    with pytest.raises(NotImplementedError):
+        m.generate(ids, mask, omic, info, num_beams=4)
