@@ -85,6 +85,17 @@ __device__ __forceinline__ float fast_erf(float x) {
     return copysignf(r, x);
 }
 
+// sum over an aligned group of LPR (8 | 16) lanes, result in every one of them: DPP adds (quad_perm, quad_perm, row_half_mirror,
+// row_mirror) — one VALU instruction each, no LDS permute (first used by the decode attention, decode.hip)
+template <int LPR>
+__device__ __forceinline__ float dpp_row_sum(float d) {
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xf, 0xf, true));       // quad_perm [2,3,0,1]
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xf, 0xf, true));      // row_half_mirror
+    if (LPR == 16) d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x140, 0xf, 0xf, true));   // row_mirror
+    return d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

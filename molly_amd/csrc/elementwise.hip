@@ -275,7 +275,10 @@ __global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
-        for (int o = tph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (tph == 16) ss = dpp_row_sum<16>(ss);             // (VALU-only cross-lane adds: common.h)
+        else if (tph == 8) ss = dpp_row_sum<8>(ss);
+        else
+            for (int o = tph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         const float rstd = rsqrtf(ss / (float)p.hd + p.eps);
         const u32x2 wa = *reinterpret_cast<const u32x2*>(w + i), wb = *reinterpret_cast<const u32x2*>(w + i + half);
         const float w1[4] = {bflo(wa[0]), bfhi(wa[0]), bflo(wa[1]), bfhi(wa[1])};
@@ -345,10 +348,22 @@ __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
     float dwq1[4] = {0, 0, 0, 0}, dwq2[4] = {0, 0, 0, 0}, dwk1[4] = {0, 0, 0, 0}, dwk2[4] = {0, 0, 0, 0};
     const long begin = (long)blockIdx.x * p.items_per_blk;
     const long end = min(begin + p.items_per_blk, total);
+    // (token, head) of this thread's item walk by counters: the 64-bit division and the modulo per iteration were most of this
+    // kernel's instructions — it is bound by them, not by HBM (82.7 us at 16 k tokens whatever the access width or the grid:
+    // profiles/r04_logs/rope_bwd_kernel.log, rope_bwd_blocks.log)
+    int m_run = (int)((begin + sub) / nh), head_run = (int)((begin + sub) % nh);
+    int pos_run = p.T > 0 ? m_run % p.T : 0;
     for (long base = begin; base < end; base += heads_per_it) {
         const long item = base + sub;
         const bool live = item < end;
-        const int m = live ? (int)(item / nh) : 0, head = live ? (int)(item % nh) : 0;
+        const int m = live ? m_run : 0, head = live ? head_run : 0;
+        const int pos_m = live ? pos_run : 0;
+        head_run += heads_per_it;
+        while (head_run >= nh) {
+            head_run -= nh;
+            ++m_run;
+            if (++pos_run == p.T) pos_run = 0;
+        }
         const bool isq = head < p.nq;
         const bf16_t* s = p.src + (size_t)m * p.ld_src + head * p.hd;
         const bf16_t* gg = p.g + (size_t)m * p.ld_g + head * p.hd;
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
             g2[0] = bflo(d[0]); g2[1] = bfhi(d[0]); g2[2] = bflo(d[1]); g2[3] = bfhi(d[1]);
         }
         if (p.cos) {
-            const int pos = p.pos ? p.pos[m] : (m % p.T);
+            const int pos = p.pos ? p.pos[m] : pos_m;
             const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)pos * half + i);
             const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sin + (size_t)pos * half + i);
 #pragma unroll
@@ -389,9 +404,15 @@ __global__ __launch_bounds__(256) void norm_rope_bwd_kernel(RopeBwdArgs p) {
                 ss += x1[e] * x1[e] + x2[e] * x2[e];
                 dot += g1[e] * w1[e] * x1[e] + g2[e] * w2[e] * x2[e];
             }
-            for (int o = tph >> 1; o > 0; o >>= 1) {
-                ss += __shfl_xor(ss, o, 64);
-                dot += __shfl_xor(dot, o, 64);
+            if (tph == 16 || tph == 8) {
+                // the 8 / 16 lanes of a head are a DPP row (or half of one): sums by VALU-only cross-lane adds instead of LDS permutes
+                ss = tph == 16 ? dpp_row_sum<16>(ss) : dpp_row_sum<8>(ss);
+                dot = tph == 16 ? dpp_row_sum<16>(dot) : dpp_row_sum<8>(dot);
+            } else {
+                for (int o = tph >> 1; o > 0; o >>= 1) {
+                    ss += __shfl_xor(ss, o, 64);
+                    dot += __shfl_xor(dot, o, 64);
+                }
             }
             const float rstd = rsqrtf(ss / (float)p.hd + p.eps);
             const float coef = dot * rstd * rstd * rstd / (float)p.hd;
@@ -1251,7 +1272,13 @@ extern "C" int molly_norm_rope_cache_fwd(void* stream, const void* src, void* ds
     return 0;
 }
 
-extern "C" int molly_norm_rope_bwd_blocks(void) { return 1024; }
+// workgroups of the norm + rope backward (each leaves one row of gain-gradient partials).  What bounds the kernel is the bytes it keeps in
+// flight: a thread has one item's four 8-byte loads outstanding, so 1,024 workgroups = 4 per CU = 32 KB per CU ran at 3.5-3.8 TB/s;
+// MOLLY_ROPE_BWD_BLOCKS overrides (A/B)
+extern "C" int molly_norm_rope_bwd_blocks(void) {
+    static const int nb = [] { const char* e = getenv("MOLLY_ROPE_BWD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    return nb;
+}
 
 extern "C" int molly_norm_rope_bwd(void* stream, const void* src, const void* g, void* dsrc, const void* q_norm_w,
                                    const void* k_norm_w, const float* cos, const float* sin, const int* positions,
