@@ -200,6 +200,19 @@ class GenerationSession:
         return self.logits
 
     @torch.no_grad()
+    def reorder(self, rows: torch.Tensor):
+        """Row i of the session becomes what row rows[i] was (beam search: the cache follows the beams that continue — HF's
+        `DynamicCache.reorder_cache`, HF:cache_utils.py).  In place, so the captured decode graph's pointers stay valid; only the
+        filled part of the caches moves."""
+        rows = rows.to(self.rt.dev).long()
+        n = self.cur_len
+        self.kc[:, :, :n] = self.kc[:, :, :n].index_select(1, rows)
+        self.vc[:, :, :n] = self.vc[:, :, :n].index_select(1, rows)
+        for t in (self.pos, self.hi, self.lo, self.n_valid):
+            t.copy_(t.index_select(0, rows))
+        # (slot = row * Tmax + cur_len belongs to the ROW, not to the beam that moved into it)
+
+    @torch.no_grad()
     def step(self, token_ids: torch.Tensor) -> torch.Tensor:
         """token_ids int64 [B] (the tokens chosen from the previous logits).  Returns next-token logits [B, V] fp32 (a
         buffer that the next step overwrites).  The first step runs eagerly (it also sizes workspaces and sets kernel
@@ -298,8 +311,12 @@ class NoRepeatNGram:
 @torch.no_grad()
 def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_list=None, max_new_tokens=3072, do_sample=True,
              temperature=0.8, top_p=0.95, top_k=None, repetition_penalty=None, pad_token_id=None, eos_token_id=None,
-             generator: Optional[torch.Generator] = None, no_repeat_ngram_size: Optional[int] = None) -> torch.Tensor:
+             generator: Optional[torch.Generator] = None, no_repeat_ngram_size: Optional[int] = None, num_beams: int = 1,
+             length_penalty: float = 1.0, early_stopping=False) -> torch.Tensor:
     """Returns the NEW tokens only, int64 [B, n_new] (what HF returns when called with inputs_embeds and no input_ids)."""
+    if num_beams and num_beams > 1:
+        return _generate_beams(model, input_ids, attention_mask, omic_ids, omic_info_list, max_new_tokens, do_sample, repetition_penalty,
+                               pad_token_id, eos_token_id, no_repeat_ngram_size, int(num_beams), length_penalty, early_stopping)
     sess = GenerationSession(model, max_new_tokens)
     logits = sess.prefill(input_ids, attention_mask, omic_ids, omic_info_list)
     B = input_ids.shape[0]
@@ -346,3 +363,35 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
             break
         logits = sess.step(nxt)
     return out
+
+
+def _generate_beams(model, input_ids, attention_mask, omic_ids, omic_info_list, max_new_tokens, do_sample, repetition_penalty, pad_token_id,
+                    eos_token_id, no_repeat_ngram_size, num_beams, length_penalty, early_stopping):
+    """`num_beams > 1` of the reference's generate signature (src/model/omics_one.py:199-200, 227 -> HF `_beam_search`): the prompt rows
+    repeated num_beams times through one prefill, then molly_amd.beam.beam_search over the decode session (logits from
+    `GenerationSession.step`, the KV cache gathered by `GenerationSession.reorder`).  Beam SAMPLING (do_sample=True with beams) draws from
+    torch's generator inside HF and is not built."""
+    if do_sample:
+        raise NotImplementedError("beam sampling (num_beams > 1 with do_sample=True) is not built; pass do_sample=False")
+    from .beam import beam_search
+    B, nb = input_ids.shape[0], num_beams
+    rep = lambda t: None if t is None else t.repeat_interleave(nb, 0)
+    rep_list = lambda l: None if l is None else [x for x in l for _ in range(nb)]
+    omic_rep = rep(omic_ids) if torch.is_tensor(omic_ids) else rep_list(omic_ids)
+    sess = GenerationSession(model, max_new_tokens)
+    logits = sess.prefill(rep(input_ids), rep(attention_mask), omic_rep, rep_list(omic_info_list))
+    eos = None if eos_token_id is None else [int(x) for x in torch.as_tensor(eos_token_id).reshape(-1).tolist()]
+
+    def processors(generated, lp):
+        # HF applies the processors to the log-probabilities in beam mode: repetition penalty, then the n-gram ban
+        if repetition_penalty and repetition_penalty != 1.0 and generated.shape[1] > 0:
+            lp = _process_logits(lp, generated, None, None, None, repetition_penalty)
+        if no_repeat_ngram_size and generated.shape[1] + 1 >= no_repeat_ngram_size:
+            ng = NoRepeatNGram(int(no_repeat_ngram_size), generated.shape[0])       # rows change beams every step: rebuilt, as HF does
+            for t in range(generated.shape[1]):
+                ng.push(generated[:, t].tolist())
+            lp = ng.apply(lp)
+        return lp
+    use_proc = (repetition_penalty and repetition_penalty != 1.0) or no_repeat_ngram_size
+    return beam_search(logits, sess.step, sess.reorder, B, nb, max_new_tokens, eos, pad_token_id, length_penalty, early_stopping,
+                       processors if use_proc else None)

@@ -650,8 +650,6 @@ class OmicsOne(_MetaSafe):
                  **generate_kwargs):
         """reference: src/model/omics_one.py:187-233 — same signature; returns the NEW tokens only.  `max_new_tokens`
         defaults to the reference's hard-coded 3072 (:223) and may be overridden through generate_kwargs."""
-        if num_beams not in (None, 1):
-            raise NotImplementedError("beam search is not used by the reference's scripts and not built")
         if omic_ids is not None:
             for i in range(len(omic_ids)):
                 assert len(omic_ids[i]) == len(omic_info_list[i]), f"Mismatch in omic count vs info count at index {i}"
@@ -661,7 +659,8 @@ class OmicsOne(_MetaSafe):
                     max_new_tokens=generate_kwargs.pop("max_new_tokens", 3072), do_sample=do_sample, temperature=temperature,
                     top_p=top_p, top_k=top_k, repetition_penalty=generate_kwargs.pop("repetition_penalty", None),
                     pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id, generator=generate_kwargs.pop("generator", None),
-                    no_repeat_ngram_size=no_repeat_ngram_size)
+                    no_repeat_ngram_size=no_repeat_ngram_size, num_beams=num_beams or 1,
+                    length_penalty=generate_kwargs.pop("length_penalty", 1.0), early_stopping=generate_kwargs.pop("early_stopping", False))
 
 
 class _GradHandOff(torch.autograd.Function):

@@ -315,5 +315,51 @@ def test_generate_with_no_repeat_ngram(tiny_meta):
     for row in out.tolist():
         grams = list(zip(row[:-1], row[1:]))
         assert len(grams) == len(set(grams)), row
+
+
+def test_session_reorder_gathers_the_cache_rows(tiny_meta):
+    """Beam search moves beams between rows: after `reorder(perm)` row i must continue exactly as row perm[i] would have (KV cache,
+    position ids, visible-key bounds).  Twin sessions on one batch, one of them reordered after the first step."""
+    from molly_amd.generate import GenerationSession
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)          # two rows with different valid lengths
+    a, b = GenerationSession(m, 6), GenerationSession(m, 6)
+    la, lb = a.prefill(ids, mask, omic, info), b.prefill(ids, mask, omic, info)
+    assert torch.equal(la, lb)
+    t1 = la.argmax(-1)
+    la, lb = a.step(t1).clone(), b.step(t1).clone()
+    perm = torch.tensor([1, 0], device=la.device)
+    a.reorder(perm)
+    t2 = lb.argmax(-1)
+    for _ in range(3):                                             # through the eager step, the capture and a replay
+        la, lb = a.step(t2[perm]).clone(), b.step(t2).clone()
+        assert torch.allclose(la, lb[perm], rtol=0, atol=2e-2 * float(lb.abs().max())), float((la - lb[perm]).abs().max())
+        t2 = lb.argmax(-1)
+
+
+def test_generate_beam_search_through_the_reference_signature(tiny_meta):
+    """`num_beams` of the reference's generate (src/model/omics_one.py:199-200, 227).  The procedure itself is pinned to HuggingFace's
+    beam search token for token on CPU (tests/test_beam_search.py); here it runs on the HIP decode session: deterministic, the best
+    hypothesis scores at least as high under the model as the greedy continuation, one beam equals greedy, beam sampling refuses."""
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)
+    greedy = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6)
+    one = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, num_beams=1)
+    assert torch.equal(greedy, one)
+    beams = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, num_beams=3)
+    assert beams.shape == (2, 6) and beams.dtype == torch.int64
+    assert torch.equal(beams, m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, num_beams=3))
+
+    def seq_logprob(tokens):                                       # sum of log-probabilities of `tokens` under teacher forcing
+        from molly_amd.generate import GenerationSession
+        s = GenerationSession(m, 6)
+        lg = s.prefill(ids, mask, omic, info)
+        tot = torch.zeros(2, device=lg.device)
+        for t in range(tokens.shape[1]):
+            tot += torch.log_softmax(lg.float(), -1).gather(1, tokens[:, t:t + 1].to(lg.device)).squeeze(1)
+            if t + 1 < tokens.shape[1]:
+                lg = s.step(tokens[:, t].to(lg.device))
+        return tot
+    assert bool((seq_logprob(beams) >= seq_logprob(greedy) - 5e-2).all())
     with pytest.raises(NotImplementedError):
-        m.generate(ids, mask, omic, info, num_beams=4)
+        m.generate(ids, mask, omic, info, num_beams=4, do_sample=True)
