@@ -1,4 +1,4 @@
-"""Beam search for `OmicsOne.generate(num_beams > 1, do_sample=False)`.
+"""Beam search (and beam sampling) for `OmicsOne.generate(num_beams > 1)`.
 
 The reference forwards `num_beams` to HuggingFace's `generate` (reference src/model/omics_one.py:199-200, 227: `self.model.generate(
 inputs_embeds=..., num_beams=num_beams, ...)`), i.e. to `GenerationMixin._beam_search` (HF:generation/utils.py) with an EMPTY
@@ -41,11 +41,14 @@ def _gather(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 def beam_search(first_logits: torch.Tensor, step: Callable[[torch.Tensor], torch.Tensor], reorder: Callable[[torch.Tensor], None],
                 batch: int, num_beams: int, max_new_tokens: int, eos_token_id: Optional[Sequence[int]] = None,
                 pad_token_id: Optional[int] = None, length_penalty: float = 1.0, early_stopping=False,
-                process_log_probs: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None) -> torch.Tensor:
+                process_log_probs: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None, do_sample: bool = False,
+                generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """first_logits: [batch * num_beams, V] logits of the first new position (rows b * num_beams + k all hold row b's prompt).
     step(tokens [batch * num_beams] int64) -> logits of the next position; reorder(row_idx [batch * num_beams] int64): row i of the
     cache becomes what row row_idx[i] was.  process_log_probs(generated [batch * num_beams, t], log_probs) -> log_probs: the logits
-    processors (repetition penalty, n-gram ban), applied as HF applies them in beam mode.  Returns [batch, n_new] int64."""
+    processors (repetition penalty, n-gram ban; with do_sample the warpers: temperature, top-k, top-p), applied as HF applies them in
+    beam mode.  do_sample: beam SAMPLING — the K continuations of step 2 are drawn without replacement from softmax(accumulated
+    scores) instead of being the K best (HF `_get_top_k_continuations`); everything else is unchanged.  Returns [batch, n_new] int64."""
     dev = first_logits.device
     B, nb, L = batch, num_beams, max_new_tokens
     V = first_logits.shape[-1]
@@ -73,7 +76,11 @@ def beam_search(first_logits: torch.Tensor, step: Callable[[torch.Tensor], torch
         if process_log_probs is not None:
             lp = process_log_probs(run_seq.reshape(B * nb, L)[:, :cur], lp)
         acc = (lp.view(B, nb, V) + run_score[:, :, None]).reshape(B, nb * V)
-        top_score, top_idx = torch.topk(acc, K)
+        if do_sample:
+            top_idx = torch.multinomial(torch.softmax(acc, dim=-1), K, generator=generator)
+            top_score = torch.gather(acc, 1, top_idx)
+        else:
+            top_score, top_idx = torch.topk(acc, K)
         src_beam, tok = top_idx // V, top_idx % V
         cand_seq = _gather(run_seq, src_beam)
         cand_seq[:, :, cur] = tok

@@ -316,7 +316,8 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
     """Returns the NEW tokens only, int64 [B, n_new] (what HF returns when called with inputs_embeds and no input_ids)."""
     if num_beams and num_beams > 1:
         return _generate_beams(model, input_ids, attention_mask, omic_ids, omic_info_list, max_new_tokens, do_sample, repetition_penalty,
-                               pad_token_id, eos_token_id, no_repeat_ngram_size, int(num_beams), length_penalty, early_stopping)
+                               pad_token_id, eos_token_id, no_repeat_ngram_size, int(num_beams), length_penalty, early_stopping,
+                               temperature, top_k, top_p, generator)
     sess = GenerationSession(model, max_new_tokens)
     logits = sess.prefill(input_ids, attention_mask, omic_ids, omic_info_list)
     B = input_ids.shape[0]
@@ -366,13 +367,13 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
 
 
 def _generate_beams(model, input_ids, attention_mask, omic_ids, omic_info_list, max_new_tokens, do_sample, repetition_penalty, pad_token_id,
-                    eos_token_id, no_repeat_ngram_size, num_beams, length_penalty, early_stopping):
+                    eos_token_id, no_repeat_ngram_size, num_beams, length_penalty, early_stopping, temperature=None, top_k=None, top_p=None,
+                    generator=None):
     """`num_beams > 1` of the reference's generate signature (src/model/omics_one.py:199-200, 227 -> HF `_beam_search`): the prompt rows
     repeated num_beams times through one prefill, then molly_amd.beam.beam_search over the decode session (logits from
-    `GenerationSession.step`, the KV cache gathered by `GenerationSession.reorder`).  Beam SAMPLING (do_sample=True with beams) draws from
-    torch's generator inside HF and is not built."""
-    if do_sample:
-        raise NotImplementedError("beam sampling (num_beams > 1 with do_sample=True) is not built; pass do_sample=False")
+    `GenerationSession.step`, the KV cache gathered by `GenerationSession.reorder`).  With do_sample=True this is HF's beam sampling:
+    the warpers (temperature, top-k, top-p) act on the log-probabilities and the continuations are drawn by torch.multinomial — the
+    same procedure; the random stream is the caller's generator on the GPU, so draws differ from a CPU run of HF."""
     from .beam import beam_search
     B, nb = input_ids.shape[0], num_beams
     rep = lambda t: None if t is None else t.repeat_interleave(nb, 0)
@@ -391,7 +392,12 @@ def _generate_beams(model, input_ids, attention_mask, omic_ids, omic_info_list, 
             for t in range(generated.shape[1]):
                 ng.push(generated[:, t].tolist())
             lp = ng.apply(lp)
+        if do_sample:
+            lp = _process_logits(lp, generated, temperature, top_k, top_p, None)
         return lp
-    use_proc = (repetition_penalty and repetition_penalty != 1.0) or no_repeat_ngram_size
+    use_proc = (repetition_penalty and repetition_penalty != 1.0) or no_repeat_ngram_size or do_sample
+    gen = generator
+    if do_sample and generator is not None and generator.device.type != logits.device.type:
+        gen = torch.Generator(device=logits.device).manual_seed(int(torch.randint(0, 1 << 62, (1,), generator=generator).item()))
     return beam_search(logits, sess.step, sess.reorder, B, nb, max_new_tokens, eos, pad_token_id, length_penalty, early_stopping,
-                       processors if use_proc else None)
+                       processors if use_proc else None, do_sample=bool(do_sample), generator=gen)

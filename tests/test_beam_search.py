@@ -88,3 +88,25 @@ def test_logits_processors_follow_huggingface_in_beam_mode():
     pr = _Provider(m, emb, mask, nb)
     got = beam_search(pr.logits(), pr.step, pr.reorder, B, nb, n_new, [9], 1, 1.0, False, proc)
     assert torch.equal(got, want), (got.tolist(), want.tolist())
+
+
+def test_beam_sampling_draws_equal_huggingface_under_one_seed():
+    """do_sample=True with beams: HF draws the K continuations with torch.multinomial from softmax(accumulated scores) after the warpers
+    acted on the log-probabilities.  On CPU, with the global generator seeded alike before each side, the same procedure consumes the
+    same random numbers: token-for-token equality again."""
+    from molly_amd.generate import _process_logits
+    m = _hf_model()
+    B, T, nb, n_new = 2, 5, 3, 9
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(B, T, 32, generator=g) * 0.5
+    mask = torch.ones(B, T, dtype=torch.long)
+    torch.manual_seed(11)
+    with torch.no_grad():
+        want = m.generate(inputs_embeds=emb, attention_mask=mask, num_beams=nb, do_sample=True, temperature=0.8, top_k=20, top_p=0.95,
+                          max_new_tokens=n_new, eos_token_id=[9], pad_token_id=1, use_cache=False)
+    pr = _Provider(m, emb, mask, nb)
+    first = pr.logits()
+    torch.manual_seed(11)
+    got = beam_search(first, pr.step, pr.reorder, B, nb, n_new, [9], 1, 1.0, False,
+                      lambda gen, lp: _process_logits(lp, gen, 0.8, 20, 0.95, None), do_sample=True)
+    assert torch.equal(got, want), (got.tolist(), want.tolist())

@@ -340,7 +340,8 @@ def test_session_reorder_gathers_the_cache_rows(tiny_meta):
 def test_generate_beam_search_through_the_reference_signature(tiny_meta):
     """`num_beams` of the reference's generate (src/model/omics_one.py:199-200, 227).  The procedure itself is pinned to HuggingFace's
     beam search token for token on CPU (tests/test_beam_search.py); here it runs on the HIP decode session: deterministic, the best
-    hypothesis scores at least as high under the model as the greedy continuation, one beam equals greedy, beam sampling refuses."""
+    hypothesis scores at least as high under the model as the greedy continuation, one beam equals greedy, beam sampling runs and is
+    reproducible under a seeded generator."""
     m = build_tiny(tiny_meta)
     ids, mask, omic, info = _left_padded_batch(tiny_meta)
     greedy = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6)
@@ -361,5 +362,9 @@ def test_generate_beam_search_through_the_reference_signature(tiny_meta):
                 lg = s.step(tokens[:, t].to(lg.device))
         return tot
     assert bool((seq_logprob(beams) >= seq_logprob(greedy) - 5e-2).all())
-    with pytest.raises(NotImplementedError):
-        m.generate(ids, mask, omic, info, num_beams=4, do_sample=True)
+    # beam sampling: the same procedure with drawn continuations; reproducible under the caller's generator
+    g = torch.Generator(device="cuda").manual_seed(5)
+    s1 = m.generate(ids, mask, omic, info, num_beams=3, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, max_new_tokens=6, generator=g)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    s2 = m.generate(ids, mask, omic, info, num_beams=3, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, max_new_tokens=6, generator=g)
+    assert s1.shape[0] == 2 and s1.shape[1] <= 6 and torch.equal(s1, s2)
