@@ -558,12 +558,15 @@ class OmicsOne(_MetaSafe):
         # everything the step needs from the batch — ids, shifted labels, scored rows, encoder ids, scatter indices, key ranges
         # and the sorted embedding-gradient index — through ONE pinned upload and the device-side assembly
         st = self._stage(input_ids, labels, attention_mask, omic_ids, omic_info_list, want_sort=rt.train_llm)
-        hs, saved = self._embed_and_inject(st, True, wait_embed, wait_proj)
-        rt.llm.forward(hs, B, T, st.kv_lo, st.kv_hi, labels_shifted=st.labels_shifted, training=True,
-                       scored_rows=st.scored_rows)
+        with ops.roctx("molly: encoders + projector + inject"):
+            hs, saved = self._embed_and_inject(st, True, wait_embed, wait_proj)
+        with ops.roctx("molly: decoder forward"):
+            rt.llm.forward(hs, B, T, st.kv_lo, st.kv_hi, labels_shifted=st.labels_shifted, training=True,
+                           scored_rows=st.scored_rows)
         if opt is not None:
             opt.wait_all_params()
-        d_hs = rt.llm.loss_and_backward(accumulate=accumulate, final_micro=final_micro)
+        with ops.roctx("molly: lm_head + CE + decoder backward"):
+            d_hs = rt.llm.loss_and_backward(accumulate=accumulate, final_micro=final_micro)
         # ---- gradient of the input embeddings: text rows -> embed_tokens, omic rows -> projector
         if rt.train_llm and not accumulate and not self.text_config.tie_word_embeddings:
             # untied head (Qwen3-8B): nothing else writes the embedding's gradient, and embed_bwd ADDS to it — start from zero

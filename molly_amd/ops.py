@@ -4,9 +4,12 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from ._lib import lib
+from .tracing import roctx  # noqa: F401  (ops.roctx)
 
 BF16 = torch.bfloat16
 GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_ACCUMULATE, GEMM_OUT_F32, GEMM_TRANS_OUT, GEMM_SWIGLU, GEMM_SWIGLU_BWD = 1, 2, 4, 8, 16, 32, 64, 128

@@ -34,6 +34,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from ..tracing import roctx
+
 
 def linear_warmup_lr(step: int, base_lr: float, warmup: int, total: int) -> float:
     """HF get_linear_schedule_with_warmup; `step` = scheduler steps already taken (0 for the first optimizer step)."""
@@ -418,8 +420,14 @@ class Zero2Optimizer:
             # the previous step's side-stream AdamW reads the clip coefficient this step is about to overwrite; in the training
             # loop it finished long ago (the backward waited for every parameter), this only orders back-to-back step() calls
             torch.cuda.current_stream().wait_stream(self.ustream)
-        self.reduce_scatter_grads()
-        self.grad_norm_and_clip()
+        with roctx("molly: gradient reduce-scatter (tail)"):
+            self.reduce_scatter_grads()
+        with roctx("molly: grad norm + clip"):
+            self.grad_norm_and_clip()
+        with roctx("molly: AdamW + all-gather"):
+            return self._update_and_publish(lr)
+
+    def _update_and_publish(self, lr: float):
         pos = 0
         whole = self.world == 1 or self.stage == 0               # this rank updates the whole buffer
         if whole and self.async_update and self.hooked:

@@ -272,3 +272,31 @@ def test_non_finite_gradient_skips_the_step_like_deepspeed():
     opt.step()
     torch.cuda.synchronize()
     assert torch.equal(P, before) and opt.skipped_steps() == 2
+
+
+def test_roctx_ranges_do_not_change_the_step(tiny_meta, tiny_gold, monkeypatch):
+    """MOLLY_ROCTX=1 brackets the step's phases with roctx ranges (molly_amd/tracing.py): same loss and gradient norm, bit for bit,
+    and every range opened is closed."""
+    from molly_amd import tracing
+    from molly_amd.trainer import Zero2Optimizer
+    depth = []
+    push, pop = torch.cuda.nvtx.range_push, torch.cuda.nvtx.range_pop
+    monkeypatch.setattr(torch.cuda.nvtx, "range_push", lambda name: (depth.append(name), push(name))[1])
+    monkeypatch.setattr(torch.cuda.nvtx, "range_pop", lambda: (depth.append(None), pop())[1])
+    got = []
+    for on in (False, True):
+        monkeypatch.setattr(tracing.roctx, "ON", on)
+        m = build_tiny(tiny_meta)
+        batch = tiny_batch(tiny_gold, tiny_meta)
+        loss = m.forward_backward(batch["input_ids"], batch["attention_mask"], batch["omic_ids"], batch["omic_info_list"],
+                                  batch["labels"])
+        opt = Zero2Optimizer(m._rt.P.flat, m._rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0)
+        gn = opt.step()
+        torch.cuda.synchronize()
+        got.append((float(loss), float(gn)))
+        if not on:
+            assert depth == []
+    assert got[0] == got[1], got
+    names = [d for d in depth if d is not None]
+    assert len(names) == 6 and len(depth) == 12, depth
+    assert names[1].endswith("decoder forward") and names[-1].endswith("AdamW + all-gather")
