@@ -134,6 +134,10 @@ int molly_gemm_rows_qkv_bf16_ctx(void* ctx, void* stream, const void* A, const v
                                  int ldw, const void* q_norm_w, const void* k_norm_w, const float* cos, const float* sin,
                                  const int* positions, float eps, int n_q_heads, int n_k_heads, int head_dim, void* dst, int ld_dst,
                                  void* kcache, void* vcache, const int* slot, int ld_cache);
+/* tail 4: no combine at all — A W^T left as n >= 2 fp32 K-slice slabs [n][M][N] in the context's scratch (their sum is the product) for a consumer
+ * that adds them itself (molly_attn_decode_qkv).  slabs_out[0] = device address of the slabs, slabs_out[1] = n; valid until the context's next launch. */
+int molly_gemm_rows_slabs_bf16_ctx(void* ctx, void* stream, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                                   long* slabs_out);
 int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res,
                                   int M, int N, int K, int lda, int ldb, int ldc, int ldres, int flags, int tail, const void* gain,
                                   float eps, void* tail_out, int ld_tail);
@@ -347,6 +351,16 @@ int molly_attn_decode_workspace(int B, int n_heads, int head_dim);
 int molly_attn_decode(void* stream, const void* q, const void* kcache, const void* vcache, void* out, const int* kv_lo,
                       const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim, int ldq, float scale,
                       int kv_len_hint, float* workspace, long workspace_floats);
+/* The same attention taken straight from the q | k | v projection's K-slice slabs (molly_gemm_rows_slabs_bf16_ctx): row b of the projection is
+ * the sum of qkv_slabs[s][b][:] ([n_slabs][B][(n_heads + 2 n_kv_heads) * head_dim] fp32) rounded to bf16; its q and k heads get q/k-norm (gains
+ * NULL: none) and rotary at positions[b] (cos NULL: none) — molly_norm_rope_cache_fwd's arithmetic; the new key and value are appended at cache
+ * row slot[b] (of the B * Tmax rows; HF DynamicCache.update) and the query heads attend to the cache keys kv_lo[b] <= key < kv_hi[b] - 1 and to
+ * the new one: kv_hi counts the new token, as it does for molly_attn_decode after molly_gemm_rows_qkv_bf16_ctx, whose caches this call
+ * reproduces bit for bit.  One launch where the step had three (slab combine + norm + rope + append | attention | merge of the splits). */
+int molly_attn_decode_qkv(void* stream, const float* qkv_slabs, int n_slabs, const void* q_norm_w, const void* k_norm_w, const float* cos,
+                          const float* sin, const int* positions, float eps, void* kcache, void* vcache, const int* slot, void* out,
+                          const int* kv_lo, const int* kv_hi, int B, int Tmax, int n_heads, int n_kv_heads, int head_dim, float scale,
+                          int kv_len_hint, float* workspace, long workspace_floats);
 
 /* ------------------------------------------------------------------------------------------------
  * LoRA branch  y = W x + (alpha/r) * B (A dropout(x))  — PEFT lora.Linear.forward as the reference configures it

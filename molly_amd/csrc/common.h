@@ -96,6 +96,45 @@ __device__ __forceinline__ float dpp_row_sum(float d) {
     return d;
 }
 
+// One head's q/k-norm and rotary on the 4 + 4 elements a thread owns (i .. i+3 and their rotary partners i+half ..): the arithmetic that
+// norm_rope_fwd_kernel, rows_tail_qkv_kernel and the decode attention's prologue (decode.hip) share, written once and with the contraction
+// pinned — the KV-cache rows the three append must agree bit for bit, and under -ffp-contract=fast hipcc fused x1 c - x2 s into an fma for
+// some elements and left mul + sub for others, differently per kernel (one cache element in 10^5 came out an ulp apart).
+__device__ __forceinline__ float head_sumsq8(const float x1[4], const float x2[4]) {
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = __builtin_fmaf(x2[e], x2[e], x1[e] * x1[e]);
+        ss = e ? ss + t : t;
+    }
+    return ss;
+}
+// sum over the tph lanes (a power of two <= 64, aligned) that hold one head
+__device__ __forceinline__ float head_lanes_sum(float ss, int tph) {
+    if (tph == 16) return dpp_row_sum<16>(ss);
+    if (tph == 8) return dpp_row_sum<8>(ss);
+    for (int o = tph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    return ss;
+}
+__device__ __forceinline__ void head_norm8(float x1[4], float x2[4], float rstd, const bf16_t* w, int i, int half) {
+    const u32x2 wa = *reinterpret_cast<const u32x2*>(w + i), wb = *reinterpret_cast<const u32x2*>(w + i + half);
+    const float w1[4] = {bflo(wa[0]), bfhi(wa[0]), bflo(wa[1]), bfhi(wa[1])};
+    const float w2[4] = {bflo(wb[0]), bfhi(wb[0]), bflo(wb[1]), bfhi(wb[1])};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x1[e] = bf2f(f2bf(bf2f(f2bf(x1[e] * rstd)) * w1[e]));      // HF: bf16(x * rstd) then * gain (bf16)
+        x2[e] = bf2f(f2bf(bf2f(f2bf(x2[e] * rstd)) * w2[e]));
+    }
+}
+__device__ __forceinline__ void head_rope8(const float x1[4], const float x2[4], const f32x4 c, const f32x4 sn, float y1[4], float y2[4]) {
+    // (explicit fmas: under -ffp-contract=fast the backend fuses whatever it likes, a contract(off) pragma notwithstanding)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        y1[e] = __builtin_fmaf(x1[e], c[e], -(x2[e] * sn[e]));
+        y2[e] = __builtin_fmaf(x2[e], c[e], x1[e] * sn[e]);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

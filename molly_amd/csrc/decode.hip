@@ -39,22 +39,35 @@ struct DecodeArgs {
     float* part;                        // [B][n_heads][splits][HD + 2] fp32: acc[HD], m, l   (splits > 1)
     int Tmax, nh, nkv, ldq, splits;
     float qscale;                       // softmax scale * log2(e): scores live in the exp2 domain
+    // FUSED (molly_attn_decode_qkv): q, and the step's new key / value, come from the K-slice slabs of the q | k | v projection
+    const float* slabs; int n_slabs, ldn;                  // [n_slabs][B][ldn] fp32, ldn = (nh + 2 nkv) * HD
+    const bf16_t* qw; const bf16_t* kw; const float* cos; const float* sin; const int* pos; const int* slot;
+    bf16_t* kc_w; bf16_t* vc_w;                            // the caches again, writable
+    float eps;
 };
 
-template <int HD, int G>
-__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
+// NW waves per block: 4 with the key range of a (sample, KV head) cut over `splits` blocks, or 16 where B * n_kv_heads blocks fill the chip by
+// themselves (one 1,024-thread block per CU keeps the same 16 waves and 8 loads per lane in flight as four 256-thread ones, and its 16
+// partials meet in LDS: no partials in HBM, no merge launch).
+// FUSED: the step's q | k | v projection arrives as the fp32 K-slice slabs the decode-row GEMM leaves (molly_gemm_rows_slabs_bf16_ctx); the
+// block adds the slices of its G query heads and its key / value head, applies q/k-norm and rotary (same arithmetic, in the same order, as
+// rows_tail_qkv_kernel / norm_rope_fwd_kernel), appends the new key and value to the caches and attends to them from LDS — the old keys
+// [lo, hi - 1) stream from the cache as before.  One launch where the step had three (slab combine + norm + rope + append, attention, merge).
+template <int HD, int G, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW) void attn_decode_kernel(DecodeArgs p) {
     constexpr int LPR = HD / 8;                       // lanes per key row (16 B each)
     constexpr int RPW = 64 / LPR;                     // rows per wave-instruction
-    constexpr int STEP = 4 * RPW;                     // rows per block step
+    constexpr int STEP = NW * RPW;                    // rows per block step
     constexpr int U = 4;                              // keys per lane per iteration
-    __shared__ float sm[4][G][HD + 2];
+    __shared__ float sm[NW][G][HD + 2];
+    __shared__ __attribute__((aligned(16))) bf16_t sq[FUSED ? G + 2 : 1][HD];      // FUSED: the G query heads, the new key, the new value
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane % LPR, rg = lane / LPR;
     int bid = blockIdx.x;
     const int s = bid % p.splits; bid /= p.splits;
     const int kvh = bid % p.nkv;
     const int b = bid / p.nkv;
-    const int lo = p.lo ? p.lo[b] : 0, hi = p.hi[b];
+    const int lo = p.lo ? p.lo[b] : 0, hi = p.hi[b] - (FUSED ? 1 : 0);           // FUSED: kv_hi counts the new token, which is not in the cache yet
     const int n = max(hi - lo, 0);
     int chunk = (n + p.splits - 1) / p.splits;
     chunk = (chunk + STEP * U - 1) / (STEP * U) * (STEP * U);
@@ -67,17 +80,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
     u32x4 qv[G];                                     // the lane's 8 q values of every head of the group, raw bf16 pairs
     f32x2 acc[G][4];
     float m[G], l[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        qv[g] = *reinterpret_cast<const u32x4*>(p.q + (size_t)b * p.ldq + (kvh * G + g) * HD + sub * 8);
-        m[g] = NEG_BIG; l[g] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[g][e] = f32x2{0.f, 0.f};
-    }
-
-    for (int key = k0 + wave * RPW + rg; key < k1; key += STEP * U) {
-        u32x4 kv[U], vv[U];
-        bool ok[U];
+    // the first keys' loads go out BEFORE q exists (FUSED: the slab combine, norm and rotary below run under their latency)
+    u32x4 kv[U], vv[U];
+    bool ok[U];
+    auto load_keys = [&](int key) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ku = key + u * STEP;
@@ -86,6 +92,61 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
             kv[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc_ * ldc);
             vv[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc_ * ldc);
         }
+    };
+    const int key_first = k0 + wave * RPW + rg;
+    if (FUSED && key_first < k1) load_keys(key_first);
+    if constexpr (FUSED) {
+        constexpr int TPH = HD / 8, half = HD / 2;   // a thread owns elements i .. i+3 and their rotary partners i+half .. of one head
+        constexpr int NPRO = ((G + 2) * TPH + 63) / 64 * 64;         // whole waves: the head's sum of squares is a DPP reduction
+        if (tid < NPRO) {
+            const bool live = tid < (G + 2) * TPH;
+            const int hh = live ? tid / TPH : G + 1, i = (tid % TPH) * 4;
+            const int col = (hh < G ? kvh * G + hh : hh == G ? p.nh + kvh : p.nh + p.nkv + kvh) * HD;
+            const float* src = p.slabs + (size_t)b * p.ldn + col + i;
+            const size_t MN = (size_t)(gridDim.x / (p.nkv * p.splits)) * p.ldn;
+            f32x4 a = *reinterpret_cast<const f32x4*>(src), c = *reinterpret_cast<const f32x4*>(src + half);
+            for (int s2 = 1; s2 < p.n_slabs; ++s2) {
+                a += *reinterpret_cast<const f32x4*>(src + s2 * MN);
+                c += *reinterpret_cast<const f32x4*>(src + s2 * MN + half);
+            }
+            float x1[4], x2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x1[e] = bf2f(f2bf(a[e])); x2[e] = bf2f(f2bf(c[e])); }      // the projection's bf16 output
+            const bf16_t* w = hh < G ? p.qw : p.kw;
+            const float ss = head_lanes_sum(head_sumsq8(x1, x2), TPH);      // (every lane of the wave: the v head's sum is not used)
+            if (hh <= G && w) head_norm8(x1, x2, rsqrtf(ss / (float)HD + p.eps), w, i, half);
+            float y1[4], y2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+            if (hh <= G && p.cos) {
+                const int pos = p.pos ? p.pos[b] : 0;
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(p.cos + (size_t)pos * half + i);
+                const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sin + (size_t)pos * half + i);
+                head_rope8(x1, x2, cs, sn, y1, y2);
+            }
+            const u32x2 o1 = u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])}, o2 = u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
+            if (live) {
+                *reinterpret_cast<u32x2*>(&sq[hh][i]) = o1;
+                *reinterpret_cast<u32x2*>(&sq[hh][i + half]) = o2;
+            }
+            if (live && hh >= G && s == p.splits - 1) {        // the append (one block per (sample, KV head) does it)
+                bf16_t* d = (hh == G ? p.kc_w : p.vc_w) + (size_t)p.slot[b] * ldc + kvh * HD;
+                *reinterpret_cast<u32x2*>(d + i) = o1;
+                *reinterpret_cast<u32x2*>(d + i + half) = o2;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if constexpr (FUSED) qv[g] = *reinterpret_cast<const u32x4*>(&sq[g][sub * 8]);
+        else qv[g] = *reinterpret_cast<const u32x4*>(p.q + (size_t)b * p.ldq + (kvh * G + g) * HD + sub * 8);
+        m[g] = NEG_BIG; l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[g][e] = f32x2{0.f, 0.f};
+    }
+
+    auto attend = [&]() {
         f32x2 vf[U][4];                              // V converted once per key, used by every head of the group
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -125,9 +186,47 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
             }
             l[g] = lsum;
         }
+    };
+    int key = key_first;
+    if (FUSED && key < k1) {                         // (the iteration whose loads went out in front of the prologue)
+        attend();
+        key += STEP * U;
+    }
+#pragma unroll 1
+    for (; key < k1; key += STEP * U) {
+        load_keys(key);
+        attend();
     }
 
-    // merge the RPW row groups of the wave (butterfly over the lane bits above the row), then the 4 waves through LDS
+    if constexpr (FUSED) {
+        // the step's own key and value, from LDS: row group 0 of wave 0 in the block that holds the end of the key range
+        if (wave == 0 && s == p.splits - 1) {
+            const u32x4 kx4 = *reinterpret_cast<const u32x4*>(&sq[G][sub * 8]), vx4 = *reinterpret_cast<const u32x4*>(&sq[G + 1][sub * 8]);
+            f32x2 vn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vn[e] = f32x2{bflo(vx4[e]), bfhi(vx4[e])};
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned kx = kx4[e], qx = qv[g][e];
+                    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, kx), __builtin_bit_cast(bf16x2_t, qx), d, false);
+                }
+                d = row_sum<LPR>(d);
+                const float sc = rg == 0 ? d * p.qscale : NEG_BIG;
+                const float mx = fmaxf(m[g], sc);
+                const float c = __builtin_amdgcn_exp2f(m[g] - mx);
+                const float pe = rg == 0 ? __builtin_amdgcn_exp2f(sc - mx) : 0.f;
+                m[g] = mx;
+                l[g] = l[g] * c + pe;
+                const f32x2 c2 = f32x2{c, c}, pe2 = f32x2{pe, pe};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[g][e] = __builtin_elementwise_fma(pe2, vn[e], acc[g][e] * c2);
+            }
+        }
+    }
+    // merge the RPW row groups of the wave (butterfly over the lane bits above the row), then the NW waves through LDS
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -150,14 +249,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs p) {
         }
     }
     __syncthreads();
-    for (int t = tid; t < G * HD; t += 256) {
+    for (int t = tid; t < G * HD; t += 64 * NW) {
         const int g = t / HD, d = t % HD;
         float mn = NEG_BIG;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) mn = fmaxf(mn, sm[w][g][HD]);
+        for (int w = 0; w < NW; ++w) mn = fmaxf(mn, sm[w][g][HD]);
         float a = 0.f, ls = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float c = __builtin_amdgcn_exp2f(sm[w][g][HD] - mn);
             a += sm[w][g][d] * c;
             ls += sm[w][g][HD + 1] * c;
@@ -189,11 +288,51 @@ __global__ void attn_decode_merge_kernel(const float* __restrict__ part, bf16_t*
     out[(size_t)blockIdx.x * HD + d] = f2bf(ls > 0.f ? a / ls : 0.f);
 }
 
-template <int HD, int G>
-void launch(hipStream_t st, const DecodeArgs& p, int B) {
-    hipLaunchKernelGGL((attn_decode_kernel<HD, G>), dim3(B * p.nkv * p.splits), dim3(256), 0, st, p);
+template <int HD, int G, bool FUSED>
+void launch(hipStream_t st, const DecodeArgs& p, int B, int nw) {
+    if (nw == 16) hipLaunchKernelGGL((attn_decode_kernel<HD, G, 16, FUSED>), dim3(B * p.nkv * p.splits), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((attn_decode_kernel<HD, G, 4, FUSED>), dim3(B * p.nkv * p.splits), dim3(256), 0, st, p);
     if (p.splits > 1)
         hipLaunchKernelGGL(attn_decode_merge_kernel<HD>, dim3(B * p.nh), dim3(HD), 0, st, p.part, p.out, p.splits);
+}
+
+// blocks of 16 waves, one per (sample, KV head), where those fill the chip (>= 3/4 of the 256 CUs) and every one has at least 16 x 64 keys;
+// otherwise blocks of 4 waves and the key range cut so that ~4 per CU exist, >= 256 keys each (kv_len_hint = upper bound of the valid
+// length, 0 = Tmax).  MOLLY_DECODE_NW = 4 | 16, MOLLY_DECODE_BLOCKS, MOLLY_DECODE_MIN_KEYS override (A/B).
+void pick_shape(int B, int n_kv_heads, int len, bool have_ws, int* nw, int* splits) {
+    static const int target = [] { const char* e = getenv("MOLLY_DECODE_BLOCKS"); return e ? atoi(e) : 1024; }();
+    static const int min_keys = [] { const char* e = getenv("MOLLY_DECODE_MIN_KEYS"); return e ? atoi(e) : 256; }();
+    static const int force_nw = [] { const char* e = getenv("MOLLY_DECODE_NW"); return e ? atoi(e) : 0; }();
+    const int pairs = B * n_kv_heads;
+    *nw = force_nw == 4 || force_nw == 16 ? force_nw : (pairs >= 192 && len >= 1024 ? 16 : 4);
+    if (*nw == 16 && (pairs >= 192 || !have_ws)) { *splits = 1; return; }
+    const int per = *nw == 16 ? 256 : target;
+    int sp = (per + pairs - 1) / pairs;
+    sp = sp < 1 ? 1 : sp;
+    if (sp > len / min_keys) sp = len / min_keys > 0 ? len / min_keys : 1;
+    if (sp > MAX_SPLITS) sp = MAX_SPLITS;
+    if (!have_ws) sp = 1;
+    *splits = sp;
+}
+
+template <bool FUSED>
+int dispatch(hipStream_t st, DecodeArgs& p, int B, int head_dim, int kv_len_hint, float* workspace, long workspace_floats) {
+    const int G = p.nh / p.nkv;
+    const int len = kv_len_hint > 0 ? kv_len_hint : p.Tmax;
+    int nw, splits;
+    pick_shape(B, p.nkv, len, workspace != nullptr, &nw, &splits);
+    if (splits > 1 && workspace_floats < (long)B * p.nh * splits * (head_dim + 2)) splits = 1;
+    p.splits = splits;
+#define MOLLY_DEC(HD_, G_) else if (head_dim == HD_ && G == G_) launch<HD_, G_, FUSED>(st, p, B, nw)
+    if (false) {}
+    MOLLY_DEC(128, 1); MOLLY_DEC(128, 2); MOLLY_DEC(128, 4); MOLLY_DEC(128, 8);
+    MOLLY_DEC(64, 1); MOLLY_DEC(64, 2); MOLLY_DEC(64, 4); MOLLY_DEC(64, 8);
+    else {
+        molly_set_error("attn_decode: n_heads / n_kv_heads = %d (built for 1, 2, 4, 8)", G);
+        return 1;
+    }
+#undef MOLLY_DEC
+    return 0;
 }
 
 }  // namespace
@@ -211,32 +350,42 @@ extern "C" int molly_attn_decode(void* stream, const void* q, const void* kcache
     MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_decode: n_heads=%d not a multiple of n_kv_heads=%d", n_heads, n_kv_heads);
     MOLLY_CHECK(ldq % 8 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)kcache % 16) == 0 && ((uintptr_t)vcache % 16) == 0,
                 "attn_decode: q / caches must be 16-byte aligned, ldq %% 8 == 0");
-    const int G = n_heads / n_kv_heads;
-    DecodeArgs p;
+    DecodeArgs p{};
     p.q = (const bf16_t*)q; p.kc = (const bf16_t*)kcache; p.vc = (const bf16_t*)vcache; p.out = (bf16_t*)out;
     p.lo = kv_lo; p.hi = kv_hi; p.part = workspace;
     p.Tmax = Tmax; p.nh = n_heads; p.nkv = n_kv_heads; p.ldq = ldq;
     p.qscale = scale * 1.44269504088896341f;
-    // enough blocks for ~4 per CU, but keep >= 256 keys per split (kv_len_hint = upper bound of the valid length, 0 = Tmax)
-    const int len = kv_len_hint > 0 ? kv_len_hint : Tmax;
-    static const int target = [] { const char* e = getenv("MOLLY_DECODE_BLOCKS"); return e ? atoi(e) : 1024; }();
-    static const int min_keys = [] { const char* e = getenv("MOLLY_DECODE_MIN_KEYS"); return e ? atoi(e) : 256; }();
-    int splits = (target + B * n_kv_heads - 1) / (B * n_kv_heads);
-    splits = splits < 1 ? 1 : splits;
-    if (splits > len / min_keys) splits = len / min_keys > 0 ? len / min_keys : 1;
-    if (splits > MAX_SPLITS) splits = MAX_SPLITS;
-    if (splits > 1 && (workspace == nullptr || workspace_floats < (long)B * n_heads * splits * (head_dim + 2))) splits = 1;
-    p.splits = splits;
-    hipStream_t st = (hipStream_t)stream;
-#define MOLLY_DEC(HD_, G_) else if (head_dim == HD_ && G == G_) launch<HD_, G_>(st, p, B)
-    if (false) {}
-    MOLLY_DEC(128, 1); MOLLY_DEC(128, 2); MOLLY_DEC(128, 4); MOLLY_DEC(128, 8);
-    MOLLY_DEC(64, 1); MOLLY_DEC(64, 2); MOLLY_DEC(64, 4); MOLLY_DEC(64, 8);
-    else {
-        molly_set_error("attn_decode: n_heads / n_kv_heads = %d (built for 1, 2, 4, 8)", G);
-        return 1;
-    }
-#undef MOLLY_DEC
+    if (int rc = dispatch<false>((hipStream_t)stream, p, B, head_dim, kv_len_hint, workspace, workspace_floats)) return rc;
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+// The decode step's attention taken straight from the q | k | v projection's K-slice slabs (molly_gemm_rows_slabs_bf16_ctx): row b of the
+// projection is the sum of qkv_slabs[s][b][:] over the n_slabs slices, rounded to bf16; its q and k heads get q/k-norm (gains NULL: none) and
+// rotary at positions[b] (cos NULL: none); the new key and value go to cache row slot[b] (of the [B * Tmax] rows) and the n_heads query heads
+// attend to the cache keys [kv_lo[b], kv_hi[b] - 1) and to the new one — kv_hi counts the new token, as it does for molly_attn_decode after
+// molly_gemm_rows_qkv_bf16_ctx, whose results this call reproduces (the caches bit for bit).  out [B][n_heads * head_dim] bf16.
+extern "C" int molly_attn_decode_qkv(void* stream, const float* qkv_slabs, int n_slabs, const void* q_norm_w, const void* k_norm_w,
+                                     const float* cos, const float* sin, const int* positions, float eps, void* kcache, void* vcache,
+                                     const int* slot, void* out, const int* kv_lo, const int* kv_hi, int B, int Tmax, int n_heads,
+                                     int n_kv_heads, int head_dim, float scale, int kv_len_hint, float* workspace, long workspace_floats) {
+    MOLLY_ENTER();
+    MOLLY_CHECK(head_dim == 64 || head_dim == 128, "attn_decode_qkv: head_dim=%d (built for 64 and 128)", head_dim);
+    MOLLY_CHECK(B > 0 && Tmax > 0 && kv_hi && slot && qkv_slabs && n_slabs >= 1 && out, "attn_decode_qkv: kv_hi, slot, slabs, out required, B=%d Tmax=%d",
+                B, Tmax);
+    MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_decode_qkv: n_heads=%d not a multiple of n_kv_heads=%d", n_heads, n_kv_heads);
+    MOLLY_CHECK((q_norm_w == nullptr) == (k_norm_w == nullptr) && (cos == nullptr) == (sin == nullptr), "attn_decode_qkv: norm gains / cos, sin in pairs");
+    MOLLY_CHECK(((uintptr_t)qkv_slabs % 16) == 0 && ((uintptr_t)kcache % 16) == 0 && ((uintptr_t)vcache % 16) == 0,
+                "attn_decode_qkv: slabs / caches must be 16-byte aligned");
+    DecodeArgs p{};
+    p.kc = (const bf16_t*)kcache; p.vc = (const bf16_t*)vcache; p.out = (bf16_t*)out;
+    p.kc_w = (bf16_t*)kcache; p.vc_w = (bf16_t*)vcache;
+    p.lo = kv_lo; p.hi = kv_hi; p.part = workspace;
+    p.Tmax = Tmax; p.nh = n_heads; p.nkv = n_kv_heads; p.ldq = 0;
+    p.qscale = scale * 1.44269504088896341f;
+    p.slabs = qkv_slabs; p.n_slabs = n_slabs; p.ldn = (n_heads + 2 * n_kv_heads) * head_dim;
+    p.qw = (const bf16_t*)q_norm_w; p.kw = (const bf16_t*)k_norm_w; p.cos = cos; p.sin = sin; p.pos = positions; p.slot = slot; p.eps = eps;
+    if (int rc = dispatch<true>((hipStream_t)stream, p, B, head_dim, kv_len_hint, workspace, workspace_floats)) return rc;
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -272,22 +272,8 @@ __global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
     const bool isq = head < p.nq;
     const bf16_t* w = isq ? p.qw : p.kw;
     if (w) {
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
-        if (tph == 16) ss = dpp_row_sum<16>(ss);             // (VALU-only cross-lane adds: common.h)
-        else if (tph == 8) ss = dpp_row_sum<8>(ss);
-        else
-            for (int o = tph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float rstd = rsqrtf(ss / (float)p.hd + p.eps);
-        const u32x2 wa = *reinterpret_cast<const u32x2*>(w + i), wb = *reinterpret_cast<const u32x2*>(w + i + half);
-        const float w1[4] = {bflo(wa[0]), bfhi(wa[0]), bflo(wa[1]), bfhi(wa[1])};
-        const float w2[4] = {bflo(wb[0]), bfhi(wb[0]), bflo(wb[1]), bfhi(wb[1])};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x1[e] = bf2f(f2bf(bf2f(f2bf(x1[e] * rstd)) * w1[e]));      // HF: bf16(x*rstd) then * gain (bf16)
-            x2[e] = bf2f(f2bf(bf2f(f2bf(x2[e] * rstd)) * w2[e]));
-        }
+        const float ss = head_lanes_sum(head_sumsq8(x1, x2), tph);        // (common.h: shared with the decode step's kernels, contraction pinned)
+        head_norm8(x1, x2, rsqrtf(ss / (float)p.hd + p.eps), w, i, half);
     }
     if (isq && p.q_scale != 1.0f) {
 #pragma unroll
@@ -303,11 +289,7 @@ __global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
         const int pos = p.pos ? p.pos[m] : (m % p.T);
         const f32x4 c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)pos * half + i);
         const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sin + (size_t)pos * half + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            y1[e] = x1[e] * c[e] - x2[e] * sn[e];
-            y2[e] = x2[e] * c[e] + x1[e] * sn[e];
-        }
+        head_rope8(x1, x2, c, sn, y1, y2);
     }
     if (live) {
         bf16_t* d = p.dst + (size_t)m * p.ld_dst + head * p.hd;

@@ -1780,19 +1780,8 @@ __global__ __launch_bounds__(256) void rows_tail_qkv_kernel(const float* __restr
     const bool isq = head < t.nq;
     const bf16_t* w = isq ? t.qw : t.kw;
     if (w) {
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ss += x1[e] * x1[e] + x2[e] * x2[e];
-        for (int o = tph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float rstd = rsqrtf(ss / (float)t.hd + t.eps);
-        const u32x2 wa = *reinterpret_cast<const u32x2*>(w + i), wb = *reinterpret_cast<const u32x2*>(w + i + half);
-        const float w1[4] = {bflo(wa[0]), bfhi(wa[0]), bflo(wa[1]), bfhi(wa[1])};
-        const float w2[4] = {bflo(wb[0]), bfhi(wb[0]), bflo(wb[1]), bfhi(wb[1])};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            x1[e] = bf2f(f2bf(bf2f(f2bf(x1[e] * rstd)) * w1[e]));
-            x2[e] = bf2f(f2bf(bf2f(f2bf(x2[e] * rstd)) * w2[e]));
-        }
+        const float ss = head_lanes_sum(head_sumsq8(x1, x2), tph);        // (common.h: norm_rope_fwd_kernel's arithmetic)
+        head_norm8(x1, x2, rsqrtf(ss / (float)t.hd + t.eps), w, i, half);
     }
     float y1[4], y2[4];
 #pragma unroll
@@ -1801,11 +1790,7 @@ __global__ __launch_bounds__(256) void rows_tail_qkv_kernel(const float* __restr
         const int pos = t.pos ? t.pos[m] : 0;
         const f32x4 c = *reinterpret_cast<const f32x4*>(t.cos + (size_t)pos * half + i);
         const f32x4 sn = *reinterpret_cast<const f32x4*>(t.sin + (size_t)pos * half + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            y1[e] = x1[e] * c[e] - x2[e] * sn[e];
-            y2[e] = x2[e] * c[e] + x1[e] * sn[e];
-        }
+        head_rope8(x1, x2, c, sn, y1, y2);
     }
     if (live) {
         const u32x2 o1 = u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])}, o2 = u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])};
@@ -2130,6 +2115,8 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
         const long total = (long)M * (N / 8);
         hipLaunchKernelGGL(rows_tail_swiglu_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, st, q.ws, splits, M, N,
                            (bf16_t*)C, ldc, bp, (bf16_t*)tail_out, ld_tail);
+    } else if (tail == 4) {
+        // (the slabs are the result)
     } else if (splits > 1) {
         const long MN = (long)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, q.ws,
@@ -2384,7 +2371,7 @@ extern "C" int molly_gemm_bf16_ctx(void* ctx, void* stream, const void* A, const
 // norm; tail 2: SwiGLU of a gate|up output), in the launch that combines the K slices
 extern "C" int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, int tail) {
     const GemmCtx& c = ctx_of(ctx);
-    if (!(tail >= 1 && tail <= 3) || !rows_applicable(c, M, N, K, 0) || !c.ws) return 0;
+    if (!(tail >= 1 && tail <= 4) || !rows_applicable(c, M, N, K, 0) || !c.ws) return 0;
     if (tail == 1 && N > 8192) return 0;
     if (tail == 2 && N % 8 != 0) return 0;
     if (streaming_rows(c, M, N, K, 0)) return 0;          // a streaming-kernel shape stays there: its one launch is cheaper than slices + tail
@@ -2405,6 +2392,23 @@ extern "C" int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void
     MOLLY_CHECK(!(flags & MOLLY_GEMM_RESIDUAL) || (res && ldres % 4 == 0), "gemm rows tail: bad residual");
     const int rc = launch_rows(c, (hipStream_t)stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, tail, gain, eps, tail_out, ld_tail);
     if (rc) return rc;
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+// decode rows, the K slices left as they are: A W^T as n fp32 slabs [n][M][N] in the context's scratch (n >= 2; their sum is the product), for a
+// consumer that combines them itself (molly_attn_decode_qkv).  slabs_out[0] = device address, [1] = n; valid until this context's next launch.
+extern "C" int molly_gemm_rows_slabs_bf16_ctx(void* ctx, void* stream, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                                              long* slabs_out) {
+    MOLLY_ENTER();
+    GemmCtx& c = ctx_of(ctx);
+    MOLLY_CHECK(molly_gemm_rows_tail_supported(ctx, M, N, K, 4), "gemm rows slabs: M=%d N=%d K=%d is not a shape of the tiled decode-row "
+                "kernel (ask molly_gemm_rows_tail_supported first)", M, N, K);
+    MOLLY_CHECK(slabs_out && lda % 8 == 0 && ldw % 8 == 0, "gemm rows slabs: pointers / strides");
+    const int rc = launch_rows(c, (hipStream_t)stream, A, W, nullptr, nullptr, nullptr, M, N, K, lda, ldw, 0, 0, 0, 4, nullptr, 0.f, nullptr, 0);
+    if (rc) return rc;
+    slabs_out[0] = (long)(uintptr_t)ws_slabs(c);
+    slabs_out[1] = c.last_cfg / 1000;
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -141,6 +141,7 @@ class GenerationSession:
         fuse = e.lora is None and os.environ.get("MOLLY_DECODE_FUSE", "1") != "0"
         H = x.shape[1]
         f_qkv = fuse and ops.gemm_rows_tail_supported(B, nq + 2 * nkvd, H, "qkv")
+        f_att = f_qkv and e.hd in (64, 128) and os.environ.get("MOLLY_DECODE_FUSE_ATTN", "1") != "0"
         f_o = fuse and ops.gemm_rows_tail_supported(B, H, nq, "norm")
         f_gu = fuse and ops.gemm_rows_tail_supported(B, 2 * e.ff, H, "swiglu")
         f_dn = fuse and ops.gemm_rows_tail_supported(B, H, e.ff, "norm")
@@ -150,7 +151,12 @@ class GenerationSession:
             if not normed:
                 ops.rmsnorm_fwd(x, w["ln1"], eps, out=s["xn"])
             kc_i, vc_i = self.kc[i].view(B * self.Tmax, nkvd), self.vc[i].view(B * self.Tmax, nkvd)
-            if f_qkv:                                   # projection + q/k-norm + rotary + cache append: GEMM and one tail launch
+            if f_att:                                   # projection as K-slice slabs; everything up to the attention output in ONE launch
+                slabs, n_slabs = ops.gemm_rows_slabs(s["xn"], w["qkv"])
+                ops.attn_decode_qkv(slabs, n_slabs, w["qn"], w["kn"], self.cos, self.sin, self.pos, eps, self.kc[i], self.vc[i], self.slot,
+                                    s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd, e.hd ** -0.5, kv_len_hint=self.Tmax,
+                                    workspace=self.dec_ws)
+            elif f_qkv:                                 # projection + q/k-norm + rotary + cache append: GEMM and one tail launch
                 ops.gemm_rows_qkv(s["xn"], w["qkv"], s["qk"], e.nh, e.nkv, e.hd, w["qn"], w["kn"], self.cos, self.sin, self.pos, eps,
                                   kc_i, vc_i, self.slot)
             else:
@@ -166,8 +172,9 @@ class GenerationSession:
                                       positions=self.pos, eps=eps)
                     ops.copy_rows(s["qk"][:, nq:], kc_i, B, dst_idx32=self.slot)
                     ops.copy_rows(s["qkv"][:, e.nqk:], vc_i, B, dst_idx32=self.slot)
-            ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
-                            e.hd ** -0.5, kv_len_hint=self.Tmax, workspace=self.dec_ws)
+            if not f_att:
+                ops.attn_decode(s["qk"], self.kc[i], self.vc[i], s["attn"], self.lo, self.hi, B, self.Tmax, e.nh, e.nkv, e.hd,
+                                e.hd ** -0.5, kv_len_hint=self.Tmax, workspace=self.dec_ws)
             if f_o:
                 ops.gemm_rows_norm(s["attn"], w["o"], s["x2"], w["ln2"], eps, s["xn2"], res=x)
             else:

@@ -567,6 +567,27 @@ def attn_decode(q, kcache, vcache, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, scal
     return out
 
 
+def gemm_rows_slabs(x, w):
+    """Decode rows: x w^T left as K-slice slabs in the context's scratch -> (device address of float [n][M][N], n).  Valid until the
+    context's next launch; consumed by attn_decode_qkv."""
+    import ctypes
+    M, K = x.shape
+    N = w.shape[0]
+    out = (ctypes.c_long * 2)()
+    lib().call("molly_gemm_rows_slabs_bf16_ctx", _ctx(), _stream(), x, w, M, N, K, x.stride(0), w.stride(0), ctypes.addressof(out))
+    return int(out[0]), int(out[1])
+
+
+def attn_decode_qkv(slabs, n_slabs, qw, kw, cos, sin, positions, eps, kcache, vcache, slot, out, kv_lo, kv_hi, B, Tmax, nh, nkv, hd, scale,
+                    kv_len_hint=0, workspace=None):
+    """The decode step's attention from the q | k | v projection's K-slice slabs (a device address from gemm_rows_slabs, or a float32
+    tensor [n][B][(nh + 2 nkv) hd]): slab combine + q/k-norm + rotary + KV-cache append + attention (+ the new key) in one launch."""
+    lib().call("molly_attn_decode_qkv", _stream(), slabs, int(n_slabs), qw, kw, cos, sin, positions, float(eps), kcache, vcache, slot, out,
+               kv_lo, kv_hi, B, Tmax, nh, nkv, hd, float(scale), int(kv_len_hint), workspace,
+               workspace.numel() if workspace is not None else 0)
+    return out
+
+
 def dropout(x, p: float, seed: int, out=None, accumulate=False):
     """out (+)= x * keep / (1-p), keep a pure function of (seed, element index)."""
     _chk(x, BF16, "x")

@@ -805,6 +805,96 @@ def test_gemm_decode_rows_qkv_tail_equals_the_separate_launches():
     assert kc1.abs().sum().item() > 0 and vc1.abs().sum().item() > 0
 
 
+def _decode_qkv_case(B, nh, nkv, hd, H, Tmax, n_keys, seed, ragged=True):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    nq, nkvd = nh * hd, nkv * hd
+    rnd = lambda *s, sc=1.0: ((torch.rand(*s, device="cuda", generator=g) * 2 - 1) * sc).to(BF)
+    x, w = rnd(B, H), rnd(nq + 2 * nkvd, H, sc=H ** -0.5 * 4)
+    qn, kn = (rnd(hd) * 0.5 + 1.0).to(BF), (rnd(hd) * 0.5 + 1.0).to(BF)
+    cos = torch.rand(Tmax, hd // 2, device="cuda", generator=g)
+    sin = torch.rand(Tmax, hd // 2, device="cuda", generator=g)
+    kc = rnd(B, Tmax, nkvd); vc = rnd(B, Tmax, nkvd)
+    cg = torch.Generator().manual_seed(seed)
+    # the new token sits at cache position n_keys (hi = n_keys + 1); left padding: the first lo keys of a row are not attended
+    lo = (torch.randint(0, max(1, n_keys // 2), (B,), generator=cg) if ragged else torch.zeros(B, dtype=torch.long)).int().cuda()
+    lo[0] = 0
+    if ragged and B > 1:
+        lo[1] = n_keys                                   # a row whose ONLY key is the new one
+    hi = torch.full((B,), n_keys + 1, dtype=torch.int32, device="cuda")
+    pos = (hi - 1 - lo).int()
+    slot = (torch.arange(B, device="cuda", dtype=torch.int32) * Tmax + n_keys).int()
+    return x, w, qn, kn, cos, sin, kc, vc, lo, hi, pos, slot
+
+
+@pytest.mark.parametrize("B,nh,nkv,hd,H,n_keys,nw", [(32, 32, 8, 128, 4096, 1500, 0), (32, 32, 8, 128, 4096, 1500, 4), (8, 16, 8, 128, 2048, 700, 0),
+                                                    (24, 16, 8, 64, 1024, 300, 0), (32, 32, 8, 128, 4096, 37, 16), (4, 8, 8, 128, 1024, 1100, 16)])
+def test_attn_decode_from_the_projection_slabs_equals_the_three_launches(B, nh, nkv, hd, H, n_keys, nw, monkeypatch):
+    """molly_attn_decode_qkv (slab combine + q/k-norm + rotary + cache append + attention over the old keys and the new one, ONE
+    launch; blocks of 16 waves without key splits where B * n_kv_heads fills the chip) against molly_gemm_rows_qkv_bf16_ctx +
+    molly_attn_decode: the appended cache rows bit for bit, the attention output within the fp32 reassociation of the softmax sums
+    (the new key enters last instead of in cache order), and both against an fp32 torch attention on the same bf16 q | k | v."""
+    import subprocess, sys, os, json
+    if nw:                                               # the block shape is read once per process: a forced shape runs in a child
+        code = ("import os, sys, torch; sys.path.insert(0, 'tests'); import test_gpu_kernels as t; "
+                f"t._attn_decode_qkv_check({B}, {nh}, {nkv}, {hd}, {H}, {n_keys}); print('ok')")
+        env = dict(os.environ, MOLLY_DECODE_NW=str(nw))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+    else:
+        _attn_decode_qkv_check(B, nh, nkv, hd, H, n_keys)
+
+
+def _attn_decode_qkv_check(B, nh, nkv, hd, H, n_keys):
+    Tmax = n_keys + 8
+    x, w, qn, kn, cos, sin, kc, vc, lo, hi, pos, slot = _decode_qkv_case(B, nh, nkv, hd, H, Tmax, n_keys, seed=21)
+    nq, nkvd = nh * hd, nkv * hd
+    c = ops.GemmContext()
+    c.ensure_workspace(64 << 20)
+    ws = ops.attn_decode_workspace(B, nh, hd, "cuda")
+    with ops.use_gemm_context(c):
+        kc0, vc0 = kc.clone(), vc.clone()
+        kc1, vc1 = kc.clone(), vc.clone()
+        qk0 = torch.empty(B, nq + nkvd, dtype=BF, device="cuda")
+        out0 = torch.empty(B, nq, dtype=BF, device="cuda")
+        out1 = torch.full((B, nq), float("nan"), dtype=BF, device="cuda")
+        if ops.gemm_rows_tail_supported(B, nq + 2 * nkvd, H, "qkv"):
+            # the decode step's own pair of launches on either side: the GEMM's K slices through its tail | left as slabs
+            ops.gemm_rows_qkv(x, w, qk0, nh, nkv, hd, qn, kn, cos, sin, pos, 1e-6, kc0.view(B * Tmax, nkvd), vc0.view(B * Tmax, nkvd), slot)
+            slabs, n_slabs = ops.gemm_rows_slabs(x, w)
+            assert n_slabs >= 2
+        else:
+            # (a shape the streaming decode-row kernel takes: slabs made here — three K slices in fp32 — combined in the kernel's order)
+            ks = [0, H // 4, H // 2 + 64, H]
+            slabs = torch.stack([x[:, a:b].float() @ w[:, a:b].float().t() for a, b in zip(ks[:-1], ks[1:])]).contiguous()
+            n_slabs = 3
+            acc = slabs[0].clone()
+            acc += slabs[1]
+            acc += slabs[2]
+            ops.norm_rope_fwd(acc.to(BF), qk0, nh, nkv, hd, 1, qn, kn, cos, sin, positions=pos, eps=1e-6, kcache=kc0.view(B * Tmax, nkvd),
+                              vcache=vc0.view(B * Tmax, nkvd), slot=slot)
+        ops.attn_decode(qk0, kc0, vc0, out0, lo, hi, B, Tmax, nh, nkv, hd, hd ** -0.5, kv_len_hint=Tmax, workspace=ws)
+        ops.attn_decode_qkv(slabs, n_slabs, qn, kn, cos, sin, pos, 1e-6, kc1, vc1, slot, out1, lo, hi, B, Tmax, nh, nkv, hd, hd ** -0.5,
+                            kv_len_hint=Tmax, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(kc0, kc1) and torch.equal(vc0, vc1)
+    assert not torch.equal(kc1, kc)                      # the append happened
+    # fp32 reference on the bf16 q and caches the separate launches produced
+    q = qk0[:, :nq].float().view(B, nkv, nh // nkv, hd)
+    K = kc0.float().view(B, Tmax, nkv, hd).permute(0, 2, 1, 3)
+    V = vc0.float().view(B, Tmax, nkv, hd).permute(0, 2, 1, 3)
+    sc = torch.einsum("bkgd,bktd->bkgt", q, K) * hd ** -0.5
+    t = torch.arange(Tmax, device="cuda")[None, :]
+    vis = (t >= lo[:, None]) & (t < hi[:, None])
+    sc = sc.masked_fill(~vis[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bkgt,bktd->bkgd", torch.softmax(sc, -1), V).reshape(B, nq)
+    scale = ref.abs().max().item()
+    for out in (out0, out1):
+        assert torch.isfinite(out.float()).all()
+        assert (out.float() - ref).abs().max().item() <= 1.2e-2 * scale
+    assert (out1.float() - out0.float()).abs().max().item() <= 8e-3 * scale
+    assert (out1 != out0).float().mean().item() < 0.2
+
+
 def test_gelu_epilogue_erf_accuracy_over_the_whole_range():
     """The GELU epilogue / kernels use a 1.5e-7-accurate erf (A&S 7.1.26): against torch's erf-GELU on a dense sweep of
     pre-activations (exact zeros, tiny, moderate, saturated tails, both signs) the bf16 results differ by at most one ulp."""
