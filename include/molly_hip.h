@@ -118,13 +118,17 @@ enum {
                                              launch of more than one round) */
     MOLLY_GEMM_KEY_ROWS_MAX_M = 14,       /* largest M (64..8192) for which a forward GEMM whose 128x128 grid has at most 192 blocks runs as 64-row
                                              tiles of the tiled decode-row kernel (the encoders' projections at 512 / 1024 rows) */
+    MOLLY_GEMM_KEY_ROWS_GU = 15,          /* decode rows of gate | up with SwiGLU (molly_gemm_rows_tail_bf16_ctx, tail 2, M <= 32): 1 (default) = the one-slice kernel
+                                             that forms silu(gate) * up from its accumulators (no slabs, no combine launch), tile chosen by the launcher;
+                                             64 | 128 = that many W rows per tile; 0 = K slices + the combine launch */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
 /* decode rows (M <= 64, the plain forward form) on the tiled decode-row kernel, with the kernel the decode step would launch next
  * folded into the launch that combines the K slices.  tail 1: C = A B^T (+ bias) (+ res) [M][N] and tail_out = RMSNorm(C) * gain
  * [M][N] (the next block's input norm, HF:models/qwen3/modeling_qwen3.py:50-63, 262-276); tail 2: C = [gate | up] [M][N] and
- * tail_out = silu(gate) * up [M][N / 2] (HF:models/qwen3/modeling_qwen3.py:76-83).  Same roundings as the separate kernels.
+ * tail_out = silu(gate) * up [M][N / 2] (HF:models/qwen3/modeling_qwen3.py:76-83; C may be NULL: gate | up itself is not kept).  Same roundings as
+ * the separate kernels.
  * molly_gemm_rows_tail_supported: 1 when this context would run M x N x K that way (else use the GEMM and the kernel). */
 int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, int tail);
 /* tail 3 (a projection of its own because of its arguments): A W^T (+ bias) = the q | k | v row of one decode step -> q/k-norm + rotary

@@ -1488,39 +1488,50 @@ struct RowsArgs {
     int tiles_m;               // 16 MT-row tiles of x (1 for decode rows; > 1: small grids of the encoders at one sample per GPU)
 };
 
-template <int MT, int NSTAGE>
+// BN: W rows per tile (128: a wave owns 32 output columns; 64: 16).  GU (decode rows of the gate | up projection, one K slice): the tile is BN / 2
+// gate rows and the BN / 2 up rows of the SAME columns (rows ff apart in W, interleaved by the staging's source addresses), so silu(gate) * up is
+// formed from the accumulators — no slabs, no combine launch.  BN = 128: a wave's two column blocks are gate | up of one 16-column block;
+// BN = 64: waves 2, 3 hold the up halves of waves 0, 1's columns and hand them over through LDS after the K loop.
+template <int MT, int NSTAGE, int BN = 128, bool GU = false>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
-    constexpr int BM = 16 * MT, BK = 64, A_ELEMS = BM * BK, B_ELEMS = 128 * BK, STAGE = A_ELEMS + B_ELEMS;
-    constexpr int NLOAD = 4 + BM * BK * 2 / 1024 / 4;          // LDS-DMA instructions per wave per stage: 4 of W, 1-2 of x
+    constexpr int BM = 16 * MT, BK = 64, A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
+    constexpr int NLOAD = BN * BK * 2 / 1024 / 4 + BM * BK * 2 / 1024 / 4;          // LDS-DMA instructions per wave per stage: 2-4 of W, 1-2 of x
+    constexpr int NJ = BN / 64;                                   // 16-column blocks per wave
     static_assert(MT == 2 || MT == 4, "16 MT rows: 32 or 64");
+    static_assert(BN == 128 || BN == 64, "W rows per tile");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);          // [stage][x tile | W tile]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (column tile fastest, then row tile, then K slice: neighbours in the launch order share the x tile and stream different W tiles)
     const int tn = blockIdx.x % p.tiles_n, tm = (blockIdx.x / p.tiles_n) % p.tiles_m, sp = blockIdx.x / (p.tiles_n * p.tiles_m);
-    const int n0 = tn * 128, m0 = tm * BM;
+    const int n0 = tn * (GU ? BN / 2 : BN), m0 = tm * BM;       // GU: first of the tile's BN / 2 columns of [0, ff)
+    const int ff = p.N >> 1;
     const int nk_all = p.K / BK;
     const int kt0 = (int)((long)nk_all * sp / p.splits), nk = (int)((long)nk_all * (sp + 1) / p.splits) - kt0;
 
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][NJ];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto stage = [&](int t, int slot) {
         bf16_t* dst = smem + slot * STAGE;
         stage_kc<BM, 4, BK, true>(p.X, p.ldx, m0, p.M, (kt0 + t) * BK, dst, wave, lane);
-        stage_kc<128, 4, BK, true>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane);
+        // GU: tile rows in groups of 32 — gate, up, (gate, up) — of columns n0 .. (stage_kc's remap: the training step's fused SwiGLU uses it too)
+        stage_kc<BN, 4, BK, true>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane, GU ? ff : 0);
     };
     // s_waitcnt vmcnt(k * NLOAD): everything but the k youngest stages has landed (k = 0 .. NSTAGE - 2)
     auto wait_younger = [&](int k) {
-        if (k >= 2 && NSTAGE >= 4) { if constexpr (NLOAD == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-        else if (k == 1) { if constexpr (NLOAD == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        if (k >= 2 && NSTAGE >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
+        else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     const int fr = lane & 15, fq = lane >> 4;
+    // the wave's column blocks as rows of the W tile.  GU, BN = 128: block j = 0 gate, j = 1 up of columns n0 + 32 (wave >> 1) + 16 (wave & 1) ..
+    const int wrow0 = GU && BN == 128 ? (wave >> 1) * 64 + (wave & 1) * 16 : wave * (BN / 4);
+    constexpr int WROW_J = GU && BN == 128 ? 32 : 16;
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nk) stage(s, s);
@@ -1532,13 +1543,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
         if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
         const bf16_t* sA = smem + slot * STAGE;
         const bf16_t* sB = sA + A_ELEMS;
-        bf16x8 xf[2][MT], wf[2][2];
+        bf16x8 xf[2][MT], wf[2][NJ];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) xf[kk][i] = frag_kc<BK>(sA, i * 16 + fr, kk * 4 + fq);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wf[kk][j] = frag_kc<BK>(sB, wave * 32 + j * 16 + fr, kk * 4 + fq);
+            for (int j = 0; j < NJ; ++j) wf[kk][j] = frag_kc<BK>(sB, wrow0 + j * WROW_J + fr, kk * 4 + fq);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1546,9 +1557,53 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
         slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+    }
+    if constexpr (GU) {
+        // ---- silu(gate) * up from the accumulators (rows_tail_swiglu_kernel's roundings: gate and up to bf16 first).  p.C (may be NULL): gate | up
+        // [M][2 ff]; p.res: the activation [M][ldres]
+        bf16_t* act = const_cast<bf16_t*>(p.res);
+        bf16_t* gu = reinterpret_cast<bf16_t*>(p.C);
+        if constexpr (BN == 64) {
+            __syncthreads();                                   // every wave is done with the ring: its first bytes carry the up halves
+            float* xch = reinterpret_cast<float*>(smem_raw);   // [2 waves][MT][64 lanes][4]
+            if (wave >= 2) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(xch + (((wave - 2) * MT + i) * 64 + lane) * 4) = acc[i][0];
+            }
+            __syncthreads();
+            if (wave >= 2) return;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + i * 16 + fr;
+            f32x4 g = acc[i][0], u;
+            int n;
+            if constexpr (BN == 128) { u = acc[i][1]; n = n0 + (wave >> 1) * 32 + (wave & 1) * 16 + fq * 4; }
+            else { u = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem_raw) + ((wave * MT + i) * 64 + lane) * 4); n = n0 + wave * 16 + fq * 4; }
+            if (m >= p.M) continue;
+            if (p.bias) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n), b2 = *reinterpret_cast<const u32x2*>(p.bias + ff + n);
+                g[0] += bflo(b[0]); g[1] += bfhi(b[0]); g[2] += bflo(b[1]); g[3] += bfhi(b[1]);
+                u[0] += bflo(b2[0]); u[1] += bfhi(b2[0]); u[2] += bflo(b2[1]); u[3] += bfhi(b2[1]);
+            }
+            const u32x2 gq = u32x2{pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3])}, uq = u32x2{pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3])};
+            if (gu) {
+                *reinterpret_cast<u32x2*>(gu + (size_t)m * p.ldc + n) = gq;
+                *reinterpret_cast<u32x2*>(gu + (size_t)m * p.ldc + ff + n) = uq;
+            }
+            u32x2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ga = bflo(gq[e]), gb = bfhi(gq[e]);
+                const float sa = bf2f(f2bf(ga * sigmoid_fast(ga))), sb = bf2f(f2bf(gb * sigmoid_fast(gb)));
+                o[e] = pack_bf2(sa * bflo(uq[e]), sb * bfhi(uq[e]));
+            }
+            *reinterpret_cast<u32x2*>(act + (size_t)m * p.ldres + n) = o;
+        }
+        return;
     }
     // ---- lane owns C[m = 16 i + fr][n = n0 + 32 wave + 16 j + 4 fq + 0..3]
 #pragma unroll
@@ -1556,8 +1611,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
         const int m = m0 + i * 16 + fr;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wave * 32 + j * 16 + fq * 4;
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wave * (BN / 4) + j * 16 + fq * 4;
             if (n >= p.N) continue;                       // N % 4 == 0 (host check)
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.splits > 1) {
@@ -1721,8 +1776,10 @@ __global__ __launch_bounds__(256) void rows_tail_swiglu_kernel(const float* __re
             u[0] += bflo(b2[0]); u[1] += bfhi(b2[0]); u[2] += bflo(b2[1]); u[3] += bfhi(b2[1]);
         }
         const u32x2 gq = u32x2{pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3])}, uq = u32x2{pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3])};
-        *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + n) = gq;
-        *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + ff + n) = uq;
+        if (C) {
+            *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + n) = gq;
+            *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + ff + n) = uq;
+        }
         u32x2 o;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -1819,6 +1876,9 @@ struct GemmCtx {
     int small3 = 0;                // 1 = 128x128 grids of at most one tile per CU on the 3-stage ring; 0 (default): the 2-stage loop — measured equal
                                    // (tools/bench_esm_gemm.py: 22.4 / 24.4 / 27.5 us against 21.8 / 22.7 / 27.5 at M = 1024): these launches are not
                                    // bound by the LDS-DMA drain
+    int rows_gu = 1;               // decode rows of gate | up with SwiGLU (tail 2, M <= 32): the ONE-slice kernel that forms the activation from its
+                                   // accumulators — 1: on, W rows per tile chosen by the launcher; 64 | 128: that tile; 0 = K slices through slabs + the
+                                   // combine launch (round 3's path; A/B)
     int rows_max_m = 1024;         // largest M the tiled decode-row kernel takes (64-row tiles; > 64 only where the 128x128 grid has <= 192 blocks:
                                    // 512 rows: 20.8 -> 15.8 us qkv, 30.0 -> 24.4 ffn2; at 2048 rows it loses to split-K: tools/bench_esm_gemm.py)
     int rows_tiled = 1;            // 1 = M <= 64 forward GEMMs the weight-streaming kernel does not take run on the tiled decode-row kernel; 0 = split-K
@@ -2076,6 +2136,25 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
                 const QkvTail* qt = nullptr) {
     RowsArgs q{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)res, nullptr,
                M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1, M <= 64 ? 1 : cdiv(M, 64)};
+    if (tail == 2 && c.rows_gu && M <= 32 && (N / 2) % 64 == 0) {
+        // gate | up with SwiGLU, one K slice: the activation from the accumulators, no slabs and no combine launch (gemm_rows_kernel<.., GU>)
+        // 128 W rows per tile where that still makes >= 128 workgroups, else 64 (tools/r04/bench_rows_gu.py, M = 32, us at 64 | 128: Qwen3-8B 45.7 | 45.9
+        // (M = 24: 45.4 | 43.4), 4B 27.6 | 24.8, 1.7B 13.2 | 16.3; K slices + combine launch: 50.9, 25.6, 17.2)
+        const int bn = c.rows_gu > 1 ? c.rows_gu : ((N / 2) / 64 >= 128 ? 128 : 64);
+        q.tiles_n = (N / 2) / (bn / 2);
+        q.res = (const bf16_t*)tail_out; q.ldres = ld_tail;
+        q.bias = (flags & MOLLY_GEMM_BIAS) ? (const bf16_t*)bias : nullptr;
+        static bool gu_attr = false;
+        if (!gu_attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<2, 4, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32 + 128) * 64 * 2);
+            (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<2, 4, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32 + 64) * 64 * 2);
+            gu_attr = true;
+        }
+        if (bn == 128) hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 128, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
+        else hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 64, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 64) * 64 * 2, st, q);
+        c.last_cfg = 32 + 1000 + 100 * (bn / 64);       // (one slice; + 100 / 200: the SwiGLU form at 64 / 128 W rows per tile)
+        return 0;
+    }
     const int ntile = q.tiles_n * q.tiles_m;
     // K slices, priced in K-tile times of one workgroup (~0.75 us with two workgroups per CU): whole rounds of the 512 slots x
     // (slice length + ring fill) + the reduce launch and its slab traffic; slices of >= 4 K-tiles, within the scratch
@@ -2313,6 +2392,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v >= 64 && v <= 8192, "gemm rows_max_m: %ld not in 64..8192", v);
         c.rows_max_m = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_ROWS_GU:
+        MOLLY_CHECK(v == 0 || v == 1 || v == 64 || v == 128, "gemm rows_gu: %ld not in {0, 1, 64, 128}", v);
+        c.rows_gu = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK:
         MOLLY_CHECK(v >= 257 && v <= (1 << 30), "gemm dynamic_min_work: %ld < 257", v);
         c.dynamic_min_work = (int)v;
@@ -2386,7 +2469,7 @@ extern "C" int molly_gemm_rows_tail_bf16_ctx(void* ctx, void* stream, const void
                 "decode-row kernel (ask molly_gemm_rows_tail_supported first)", M, N, K, tail);
     MOLLY_CHECK(!(flags & ~(MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL)) && (tail == 1 || !(flags & MOLLY_GEMM_RESIDUAL)),
                 "gemm rows tail: flags %d (bias, and a residual in front of the norm, are what a tail takes)", flags);
-    MOLLY_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ld_tail % 4 == 0 && tail_out && C && (tail == 2 || gain),
+    MOLLY_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ld_tail % 4 == 0 && tail_out && (C || tail == 2) && (tail == 2 || gain),
                 "gemm rows tail: strides / pointers");
     MOLLY_CHECK(!(flags & MOLLY_GEMM_BIAS) || bias, "gemm rows tail: MOLLY_GEMM_BIAS without bias pointer");
     MOLLY_CHECK(!(flags & MOLLY_GEMM_RESIDUAL) || (res && ldres % 4 == 0), "gemm rows tail: bad residual");
@@ -2473,6 +2556,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_ROWS_TILED: return c.rows_tiled;
     case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK: return c.dynamic_min_work;
     case MOLLY_GEMM_KEY_ROWS_MAX_M: return c.rows_max_m;
+    case MOLLY_GEMM_KEY_ROWS_GU: return c.rows_gu;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

@@ -182,7 +182,7 @@ class GenerationSession:
                 self._lora(i, "o_proj", s["attn"], s["x2"])
                 ops.rmsnorm_fwd(s["x2"], w["ln2"], eps, out=s["xn2"])
             if f_gu:
-                ops.gemm_rows_swiglu(s["xn2"], w["gu"], s["gu"], s["act"])
+                ops.gemm_rows_swiglu(s["xn2"], w["gu"], None, s["act"])          # (gate | up itself is not needed again)
             else:
                 ops.gemm_nt(s["xn2"], w["gu"], out=s["gu"])
                 self._lora(i, "gate_proj", s["xn2"], s["gu"][:, :e.ff])

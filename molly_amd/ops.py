@@ -60,7 +60,7 @@ def _chk(t: torch.Tensor, dtype=None, name="tensor"):
 # thread's default context of the library is used (tools, kernel tests).  A model owns one (OmicsOne.prepare), so an optimizer
 # that wants another launch shape at N > 1 changes ITS model's context and nothing else in the process.
 GEMM_KEYS = {"persistent_blocks": 1, "schedule": 2, "force_tile": 3, "group_m": 4, "small_grid_tile": 5, "min_ktiles": 6,
-             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "small_split": 11, "rows_tiled": 12, "dynamic_min_work": 13, "rows_max_m": 14, "last_config": 100}
+             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "small_split": 11, "rows_tiled": 12, "dynamic_min_work": 13, "rows_max_m": 14, "rows_gu": 15, "last_config": 100}
 STREAMK_SCRATCH = (64 + 8192 * 64 + 8 * 64) + 256 * 2 * 262144   # header (a counter line per tile) + two 256 KiB accumulator images per block of a 256-block launch
 
 
@@ -180,11 +180,12 @@ def gemm_rows_norm(x, w, out, norm_w, eps, norm_out, res=None, bias=None):
 
 
 def gemm_rows_swiglu(x, w, gu, act, bias=None):
-    """gu[M, 2ff] = x w^T (+bias) and act[M, ff] = silu(gate) * up in the launch that combines the K slices (decode rows)."""
+    """gu[M, 2ff] = x w^T (+bias) (gu None: not kept) and act[M, ff] = silu(gate) * up — from the accumulators of a one-slice launch (M <= 32,
+    context key rows_gu) or in the launch that combines the K slices (decode rows)."""
     M, K = x.shape
     N = w.shape[0]
-    lib().call("molly_gemm_rows_tail_bf16_ctx", _ctx(), _stream(), x, w, gu, bias, None, M, N, K, x.stride(0), w.stride(0), gu.stride(0),
-               0, GEMM_BIAS if bias is not None else 0, 2, None, 0.0, act, act.stride(0))
+    lib().call("molly_gemm_rows_tail_bf16_ctx", _ctx(), _stream(), x, w, gu, bias, None, M, N, K, x.stride(0), w.stride(0),
+               gu.stride(0) if gu is not None else 0, 0, GEMM_BIAS if bias is not None else 0, 2, None, 0.0, act, act.stride(0))
     return gu, act
 
 

@@ -696,8 +696,17 @@ def test_gemm_decode_rows_tails_at_other_model_widths(H, FF):
             gu0 = ops.gemm_nt(x2, w2)
             a0 = ops.swiglu_fwd(gu0)
             gu1, a1 = torch.empty_like(gu0), torch.empty_like(a0)
+            c.set("rows_gu", 0)                              # K slices + the combine launch
             ops.gemm_rows_swiglu(x2, w2, gu1, a1)
             assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+            for mode in (1, 64, 128):                        # one slice, the activation from the accumulators (1: the launcher picks the tile)
+                c.set("rows_gu", mode)
+                gu2, a2 = torch.full_like(gu0, float("nan")), torch.full_like(a0, float("nan"))
+                ops.gemm_rows_swiglu(x2, w2, gu2, a2)
+                assert c.get("last_config") in (1132, 1232)
+                d = (gu2.float() - gu0.float()).abs()
+                assert d.max().item() <= 2 ** -7 * gu0.float().abs().max().item() and (d > 0).float().mean().item() < 0.03
+                assert torch.equal(a2, ops.swiglu_fwd(gu2))
             checked += 1
     assert checked >= 1
 
@@ -730,8 +739,22 @@ def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
         gu0 = ops.gemm_nt(x2, w2)
         a0 = ops.swiglu_fwd(gu0)
         gu1, a1 = torch.empty_like(gu0), torch.empty_like(a0)
+        c.set("rows_gu", 0)                                  # K slices + the combine launch: the same sums as the plain GEMM
         ops.gemm_rows_swiglu(x2, w2, gu1, a1)
         assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+        for bn in (64, 128):
+            # M <= 32: ONE K slice, the activation formed from the accumulators (no slabs): gate | up differ from the sliced sums by the
+            # fp32 order only, and the activation is exactly SwiGLU of the gate | up the launch stored; without a gate | up output: the same
+            c.set("rows_gu", bn)
+            gu2, a2, a3 = torch.full_like(gu0, float("nan")), torch.full_like(a0, float("nan")), torch.full_like(a0, float("nan"))
+            ops.gemm_rows_swiglu(x2, w2, gu2, a2)
+            ops.gemm_rows_swiglu(x2, w2, None, a3)
+            assert c.get("last_config") == (1032 + 100 * (bn // 64) if M <= 32 else 2032) or M > 32
+            d = (gu2.float() - gu0.float()).abs()
+            assert d.max().item() <= 2 ** -7 * gu0.float().abs().max().item() and (d > 0).float().mean().item() < 0.03
+            assert torch.equal(a2, ops.swiglu_fwd(gu2)) and torch.equal(a2, a3)
+            if M > 32:
+                assert torch.equal(gu2, gu0)
         # with a bias in front of either tail
         bias, bias2 = rnd(H), rnd(2 * 6144)
         yb0 = ops.gemm_nt(x, w, bias=bias, res=res)
@@ -742,8 +765,13 @@ def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
         gub0 = ops.gemm_nt(x2, w2, bias=bias2)
         ab0 = ops.swiglu_fwd(gub0)
         gub1, ab1 = torch.empty_like(gub0), torch.empty_like(ab0)
+        c.set("rows_gu", 0)
         ops.gemm_rows_swiglu(x2, w2, gub1, ab1, bias=bias2)
         assert torch.equal(gub0, gub1) and torch.equal(ab0, ab1)
+        c.set("rows_gu", 64)
+        ops.gemm_rows_swiglu(x2, w2, gub1, ab1, bias=bias2)
+        assert (gub1.float() - gub0.float()).abs().max().item() <= 2 ** -7 * gub0.float().abs().max().item()
+        assert torch.equal(ab1, ops.swiglu_fwd(gub1))
         assert not ops.gemm_rows_tail_supported(8, 4096, 4096, "norm")        # a streaming-kernel shape keeps its one launch
         assert not ops.gemm_rows_tail_supported(M, 151936, 4096, "norm")      # the lm_head is not a decode-row-kernel shape
 
