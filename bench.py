@@ -186,7 +186,7 @@ def _c5_worker():
     3072-token left-aligned prompts with one 1024-residue protein span, greedy decode over the KV cache.  Prefill is priced
     against the MFMA roof, the decode step against HBM (it streams every weight and the whole KV cache once per token)."""
     import molly_amd
-    from molly_amd import config as C
+    from molly_amd import config as C, ops
     from molly_amd.generate import GenerationSession
     from molly_amd.synth import synth_batch
     dev = torch.device("cuda", 0)
@@ -206,10 +206,10 @@ def _c5_worker():
         logits = sess.prefill(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"])
         e1.record()
         for _ in range(8):                                 # eager step + graph capture + first replays: not timed
-            logits = sess.step(logits.argmax(-1))
+            logits = sess.step(ops.argmax(logits))
         e2.record()
         for _ in range(NEW - 8):
-            logits = sess.step(logits.argmax(-1))
+            logits = sess.step(ops.argmax(logits))
         e3.record()
         torch.cuda.synchronize()
         res = (e0.elapsed_time(e1), e2.elapsed_time(e3) / (NEW - 8))

@@ -113,9 +113,12 @@ class GenerationSession:
                       xn2=z(B, e.h), gu=z(B, 2 * e.ff), act=z(B, e.ff), hn=z(B, e.h))
         # static per-step state (device): token ids, position ids, cache slot and visible-key bound of the step's token
         self.tok = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.pos = self.n_valid.clone()                                        # position id = number of valid tokens so far
-        self.slot = torch.arange(B, device=dev, dtype=torch.int32) * self.Tmax + self.cur_len
-        self.hi = torch.full((B,), self.cur_len + 1, dtype=torch.int32, device=dev)
+        # (three rows of ONE tensor: the step advances them with one launch)
+        self.state = torch.empty(3, B, dtype=torch.int32, device=dev)
+        self.pos, self.slot, self.hi = self.state[0], self.state[1], self.state[2]
+        self.pos.copy_(self.n_valid)                                           # position id = number of valid tokens so far
+        self.slot.copy_(torch.arange(B, device=dev, dtype=torch.int32) * self.Tmax + self.cur_len)
+        self.hi.fill_(self.cur_len + 1)
         self.logits = torch.empty(B, e.V, dtype=torch.float32, device=dev)
         self._graph, self._graph_ws, self._graph_ws_ptr, self._steps_done = None, None, 0, 0
         self.dec_ws = ops.attn_decode_workspace(B, e.nh, e.hd, dev)
@@ -201,9 +204,7 @@ class GenerationSession:
             ops.rmsnorm_fwd(x, e.norm_w, eps, out=s["hn"])
         ops.gemm_nt(s["hn"], e.head, out=self.logits)
         # advance the per-sample position / cache slot / visible-key bound for the next step (device-side, graph-replayable)
-        self.pos += 1
-        self.slot += 1
-        self.hi += 1
+        self.state += 1
         return self.logits
 
     @torch.no_grad()

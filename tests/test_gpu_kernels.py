@@ -1106,3 +1106,23 @@ def test_gemm_decode_row_kernel(M, N, K):
         o0 = ops.gemm_nt(xr, wr, out_dtype=torch.float32)
         assert off.get("last_config") != 1016
     _close(o1, o0, atol=2e-3 * math.sqrt(K), rtol=1e-4, what="decode-row kernel vs split-K path")
+
+
+@pytest.mark.parametrize("rows,V,ld", [(32, 151936, 151936), (3, 1001, 1004), (5, 4096, 4100), (1, 7, 7), (4, 50000, 50000)])
+def test_argmax_rows_first_maximal_index(rows, V, ld):
+    """Greedy token choice (HF generate, do_sample=False): molly_argmax_f32 against numpy's argmax on the same fp32 rows — ties go to the
+    FIRST maximal index, a NaN counts as the maximum; 16-byte loads where the row stride allows, scalar ones elsewhere."""
+    g = torch.Generator(device="cuda").manual_seed(rows * 7 + V)
+    buf = torch.randn(rows, ld, device="cuda", generator=g)
+    x = buf[:, :V]
+    x[0, V // 3] = 50.0
+    x[0, V - 1] = 50.0                                       # a tie: the earlier index wins
+    if rows > 1:
+        x[1, :] = -3.0                                       # a constant row: index 0
+    if rows > 2:
+        x[2, V // 2] = float("nan")                          # NaN counts as the maximum
+        x[2, 1] = 99.0
+    got = ops.argmax(x).cpu().numpy()
+    ref = x.cpu().numpy().argmax(-1)
+    assert (got == ref).all(), (got, ref)
+    assert got[0] == V // 3

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--new", type=int, default=64)
     args = ap.parse_args()
     import molly_amd
-    from molly_amd import config as C
+    from molly_amd import config as C, ops
     from molly_amd.generate import GenerationSession
     from molly_amd.synth import synth_batch
     dev = torch.device("cuda", 0)
@@ -41,7 +41,7 @@ def main():
         logits = sess.prefill(b["input_ids"], b["attention_mask"], b["omic_ids"], b["omic_info_list"])
         e1.record()
         for _ in range(args.new):
-            logits = sess.step(logits.argmax(-1))
+            logits = sess.step(ops.argmax(logits))
         e2.record()
         torch.cuda.synchronize()
         res = {"model": args.model, "batch": B, "prompt_len": T, "k_protein": args.k_protein, "new_tokens": args.new,
