@@ -94,7 +94,11 @@ int main(int argc, char** argv) {
         (void)molly_gemm_ctx_get(ctx, MOLLY_GEMM_KEY_LAST_CONFIG);
         if (it % 4 == 0) seen(molly_gemm_nt_bf16(st, A, B, C, nullptr, nullptr, M, N, K, K, K, N, N, 0), "gemm_nt_bf16");
         if (it % 6 == 0) {
-            for (int tail = 1; tail <= 3; ++tail) (void)molly_gemm_rows_tail_supported(ctx, M, N, K, tail);
+            for (int tail = 1; tail <= 4; ++tail) (void)molly_gemm_rows_tail_supported(ctx, M, N, K, tail);
+            long slabs[2] = {0, 0};
+            seen(molly_gemm_rows_slabs_bf16_ctx(ctx, st, A, B, M, N, K, K, K, slabs), "gemm_rows_slabs");
+            seen(molly_gemm_rows_tail_bf16_ctx(ctx, st, A, B, nullptr, nullptr, nullptr, M, N, K, K, K, 0, 0, 0, 2, nullptr, 0.f, fake(8), N / 2),
+                 "gemm_rows_tail (no gate|up output)");
             seen(molly_gemm_rows_tail_bf16_ctx(ctx, st, A, B, C, nullptr, (it & 8) ? res : nullptr, M, N, K, K, K, N, N, (it & 8) ? MOLLY_GEMM_RESIDUAL : 0,
                                                1 + it % 2, fake(7), 1e-6f, fake(8), N), "gemm_rows_tail");
             seen(molly_gemm_rows_qkv_bf16_ctx(ctx, st, A, B, nullptr, M, N, K, K, K, fake(7), fake(8), (const float*)fake(9), (const float*)fake(10),
@@ -140,6 +144,10 @@ int main(int argc, char** argv) {
             const int dw = molly_attn_decode_workspace(Bn, nh, hd);
             seen(molly_attn_decode(st, A, B, C, fake(9), lo, (const int*)fake(21), Bn, T, nh, nkv, hd, nh * hd, 0.125f, it % 2 ? T : 0,
                                    (it & 4) ? (float*)fake(17) : nullptr, dw), "attn_decode");
+            seen(molly_attn_decode_qkv(st, (const float*)fake(18), 1 + it % 12, (it & 8) ? fake(7) : nullptr, (it & 8) ? fake(8) : nullptr,
+                                       (it & 16) ? (const float*)fake(9) : nullptr, (it & 16) ? (const float*)fake(10) : nullptr, (const int*)fake(11),
+                                       1e-6f, B, C, (const int*)fake(14), fake(9), lo, (const int*)fake(21), Bn, T, nh, nkv, hd, 0.125f,
+                                       it % 2 ? T : 0, (it & 4) ? (float*)fake(17) : nullptr, dw), "attn_decode_qkv");
         }
     }
 
