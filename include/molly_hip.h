@@ -121,6 +121,7 @@ enum {
     MOLLY_GEMM_KEY_ROWS_GU = 15,          /* decode rows of gate | up with SwiGLU (molly_gemm_rows_tail_bf16_ctx, tail 2, M <= 32): 1 (default) = the one-slice kernel
                                              that forms silu(gate) * up from its accumulators (no slabs, no combine launch), tile chosen by the launcher;
                                              64 | 128 = that many W rows per tile; 0 = K slices + the combine launch */
+    MOLLY_GEMM_KEY_ROWS_BN = 16,          /* W rows per tile of the tiled decode-row kernel at M <= 32: 64 (default) | 128 */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
@@ -238,6 +239,10 @@ int molly_cls_loss_fwd_bwd(void* stream, void* logits, const int64_t* labels, co
 /* greedy token selection of generate(do_sample=False) — HF:generation/utils.py `next_tokens = torch.argmax(scores, -1)`
  * (reference src/model/omics_one.py:220-232 passes do_sample through): first maximal index per row of fp32 logits [rows][ld]. */
 int molly_argmax_f32(void* stream, const float* x, int64_t* out, int rows, int V, int ld);
+/* the same with every row cut over up to 8 workgroups + a merge launch (few rows of a wide vocabulary: 32 rows alone keep 32 of the 256 CUs busy);
+ * workspace: molly_argmax_workspace(rows) bytes, NULL or too small = the one-launch form */
+int molly_argmax_workspace(int rows);
+int molly_argmax_f32_ws(void* stream, const float* x, int64_t* out, int rows, int V, int ld, void* workspace, long workspace_bytes);
 /* sampling of generate(do_sample=True) — the reference's inference settings (src/inference_lora.py:293-298: temperature 0.8,
  * top_p 0.95, top_k 20, repetition_penalty 1.1) through HF's processors in HF's order (HF:generation/logits_process.py:
  * RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper; softmax + multinomial in

@@ -1879,6 +1879,10 @@ struct GemmCtx {
     int rows_gu = 1;               // decode rows of gate | up with SwiGLU (tail 2, M <= 32): the ONE-slice kernel that forms the activation from its
                                    // accumulators — 1: on, W rows per tile chosen by the launcher; 64 | 128: that tile; 0 = K slices through slabs + the
                                    // combine launch (round 3's path; A/B)
+    int rows_bn = 64;              // W rows per tile of the tiled decode-row kernel at M <= 32: 64 (48 KB of LDS: three workgroups per CU, twice the column
+                                   // tiles, fewer K slices and slabs) | 128 (round 3).  M = 32, us at 128 | 64 (tools/bench_decode_gemm.py, profiles/r04_logs/
+                                   // rows_bn_bench.log): 8B qkv 17.8 | 16.6, o 15.6 | 13.6, down 27.9 | 26.4; 4B down 21.7 | 19.6; 1.7B gate|up 17.6 | 16.5;
+                                   // decode step 8B B = 32 6.76-6.81 | 6.63-6.65 ms, B = 20 6.52 | 6.29, 4B 5.55 | 5.42, 1.7B 3.81 | 3.76
     int rows_max_m = 1024;         // largest M the tiled decode-row kernel takes (64-row tiles; > 64 only where the 128x128 grid has <= 192 blocks:
                                    // 512 rows: 20.8 -> 15.8 us qkv, 30.0 -> 24.4 ffn2; at 2048 rows it loses to split-K: tools/bench_esm_gemm.py)
     int rows_tiled = 1;            // 1 = M <= 64 forward GEMMs the weight-streaming kernel does not take run on the tiled decode-row kernel; 0 = split-K
@@ -2155,6 +2159,9 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
         c.last_cfg = 32 + 1000 + 100 * (bn / 64);       // (one slice; + 100 / 200: the SwiGLU form at 64 / 128 W rows per tile)
         return 0;
     }
+    const int bn = M <= 32 ? c.rows_bn : 128;
+    const int slots = bn == 64 ? 768 : 512;              // resident workgroups: 48 KB of LDS each at 64 W rows per tile (three per CU), 80 KB at 128
+    q.tiles_n = cdiv(N, bn);
     const int ntile = q.tiles_n * q.tiles_m;
     // K slices, priced in K-tile times of one workgroup (~0.75 us with two workgroups per CU): whole rounds of the 512 slots x
     // (slice length + ring fill) + the reduce launch and its slab traffic; slices of >= 4 K-tiles, within the scratch
@@ -2163,7 +2170,7 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
     double best_cost = 1e30;
     for (int sp = tail ? 2 : 1; sp <= 32 && (nk / sp >= 4 || (tail && sp == 2)); ++sp) {
         if (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_slab_bytes(c)) break;
-        const double cost = cdiv(ntile * sp, 512) * ((double)nk / sp + 3.0) +
+        const double cost = cdiv(ntile * sp, slots) * ((double)nk / sp + 3.0) * (bn == 64 ? 0.75 : 1.0) +
                             (sp > 1 ? (5.0 + 8.0 * sp * M * N / 5e6) / 0.75 : 0.0);
         if (cost < best_cost) { best_cost = cost; splits = sp; }
     }
@@ -2179,7 +2186,14 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
         (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * 64 * 2);
         rows_attr = true;
     }
-    if (M <= 32) hipLaunchKernelGGL((gemm_rows_kernel<2, 4>), dim3(ntile * splits), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
+    if (M <= 32 && bn == 64) {
+        static bool bn_attr = false;
+        if (!bn_attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_rows_kernel<2, 4, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (32 + 64) * 64 * 2);
+            bn_attr = true;
+        }
+        hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 64, false>), dim3(ntile * splits), dim3(256), 4 * (32 + 64) * 64 * 2, st, q);
+    } else if (M <= 32) hipLaunchKernelGGL((gemm_rows_kernel<2, 4>), dim3(ntile * splits), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
     else hipLaunchKernelGGL((gemm_rows_kernel<4, 3>), dim3(ntile * splits), dim3(256), 3 * (64 + 128) * 64 * 2, st, q);
     const bf16_t* bp = (flags & MOLLY_GEMM_BIAS) ? (const bf16_t*)bias : nullptr;
     const bf16_t* rp = (flags & MOLLY_GEMM_RESIDUAL) ? (const bf16_t*)res : nullptr;
@@ -2392,6 +2406,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v >= 64 && v <= 8192, "gemm rows_max_m: %ld not in 64..8192", v);
         c.rows_max_m = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_ROWS_BN:
+        MOLLY_CHECK(v == 64 || v == 128, "gemm rows_bn: %ld not in {64, 128}", v);
+        c.rows_bn = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_ROWS_GU:
         MOLLY_CHECK(v == 0 || v == 1 || v == 64 || v == 128, "gemm rows_gu: %ld not in {0, 1, 64, 128}", v);
         c.rows_gu = (int)v;
@@ -2557,6 +2575,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK: return c.dynamic_min_work;
     case MOLLY_GEMM_KEY_ROWS_MAX_M: return c.rows_max_m;
     case MOLLY_GEMM_KEY_ROWS_GU: return c.rows_gu;
+    case MOLLY_GEMM_KEY_ROWS_BN: return c.rows_bn;
     case MOLLY_GEMM_KEY_LAST_CONFIG: return c.last_cfg;
     default: return -1;
     }

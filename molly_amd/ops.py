@@ -60,7 +60,7 @@ def _chk(t: torch.Tensor, dtype=None, name="tensor"):
 # thread's default context of the library is used (tools, kernel tests).  A model owns one (OmicsOne.prepare), so an optimizer
 # that wants another launch shape at N > 1 changes ITS model's context and nothing else in the process.
 GEMM_KEYS = {"persistent_blocks": 1, "schedule": 2, "force_tile": 3, "group_m": 4, "small_grid_tile": 5, "min_ktiles": 6,
-             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "small_split": 11, "rows_tiled": 12, "dynamic_min_work": 13, "rows_max_m": 14, "rows_gu": 15, "last_config": 100}
+             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "small_split": 11, "rows_tiled": 12, "dynamic_min_work": 13, "rows_max_m": 14, "rows_gu": 15, "rows_bn": 16, "last_config": 100}
 STREAMK_SCRATCH = (64 + 8192 * 64 + 8 * 64) + 256 * 2 * 262144   # header (a counter line per tile) + two 256 KiB accumulator images per block of a 256-block launch
 
 
@@ -466,13 +466,20 @@ def cls_loss_fwd_bwd(logits, V, row_loss, scale, labels=None, targets=None, igno
                0 if labels is not None else 1, ignore_index, int(write_grad))
 
 
+_ARGMAX_WS = {}
+
+
 def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row-wise argmax of fp32 logits [rows, V] (first maximal index, like torch.argmax) -> int64 [rows]."""
     assert logits.dtype == torch.float32 and logits.stride(1) == 1
     rows, V = logits.shape
     if out is None:
         out = torch.empty(rows, dtype=torch.int64, device=logits.device)
-    lib().call("molly_argmax_f32", _stream(), logits, out, rows, V, logits.stride(0))
+    key = (logits.device, rows)
+    ws = _ARGMAX_WS.get(key)
+    if ws is None:
+        ws = _ARGMAX_WS[key] = torch.empty(lib().query("molly_argmax_workspace", rows), dtype=torch.uint8, device=logits.device)
+    lib().call("molly_argmax_f32_ws", _stream(), logits, out, rows, V, logits.stride(0), ws, ws.numel())
     return out
 
 

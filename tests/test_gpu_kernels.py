@@ -694,11 +694,17 @@ def test_gemm_decode_rows_tails_at_other_model_widths(H, FF):
         if ops.gemm_rows_tail_supported(M, 2 * FF, H, "swiglu"):
             x2, w2 = rnd(M, H), rnd(2 * FF, H, sc=H ** -0.5)
             gu0 = ops.gemm_nt(x2, w2)
+            cfg0 = c.get("last_config")
             a0 = ops.swiglu_fwd(gu0)
             gu1, a1 = torch.empty_like(gu0), torch.empty_like(a0)
             c.set("rows_gu", 0)                              # K slices + the combine launch
             ops.gemm_rows_swiglu(x2, w2, gu1, a1)
-            assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+            if c.get("last_config") == cfg0:                 # the same K slices as the plain GEMM took: the same sums
+                assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+            else:                                            # (a tail needs >= 2 slices; the plain GEMM of a wide matrix may take one)
+                d = (gu1.float() - gu0.float()).abs()
+                assert d.max().item() <= 2 ** -7 * gu0.float().abs().max().item() and (d > 0).float().mean().item() < 0.03
+                assert torch.equal(a1, ops.swiglu_fwd(gu1))
             for mode in (1, 64, 128):                        # one slice, the activation from the accumulators (1: the launcher picks the tile)
                 c.set("rows_gu", mode)
                 gu2, a2 = torch.full_like(gu0, float("nan")), torch.full_like(a0, float("nan"))

@@ -170,6 +170,7 @@ int main(int argc, char** argv) {
             seen(molly_colsum_bf16(st, A, rows, H, H, C, rows & 1, 0, (float*)fake(9)), "colsum");
             seen(molly_ce_fwd_bwd(st, A, (const int64_t*)B, (float*)C, (const float*)fake(9), rows, H, H, -100, 1), "ce_fwd_bwd");
             seen(molly_argmax_f32(st, (const float*)A, (int64_t*)C, rows, H, H), "argmax");
+            seen(molly_argmax_f32_ws(st, (const float*)A, (int64_t*)C, rows, H, H, (H & 64) ? fake(17) : nullptr, molly_argmax_workspace(rows)), "argmax_ws");
         }
     for (long n : ns) {
         seen(molly_sqnorm_bf16(st, A, n, (float*)fake(9), (float*)C, 0), "sqnorm");

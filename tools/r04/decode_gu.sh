@@ -1,7 +1,7 @@
 O=$GRAFT_REPO_ROOT/gpurun_out/r04; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_generate.py tests/test_gpu_config5.py -q 2>&1 | tail -8 > $O/decode_gu_tests.log
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_generate.py tests/test_gpu_config5.py tests/test_gpu_fuzz.py tests/test_gpu_edge_cases.py -q 2>&1 | tail -8 > $O/decode_gu_tests.log
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_dec -- python3 $R/bench.py --secondary-worker c5 > $O/decode_trace_run.log 2>&1
 f=$(ls /tmp/p_dec/*/*kernel_trace.csv | head -1)
