@@ -120,7 +120,7 @@ enum {
                                              tiles of the tiled decode-row kernel (the encoders' projections at 512 / 1024 rows) */
     MOLLY_GEMM_KEY_ROWS_GU = 15,          /* decode rows of gate | up with SwiGLU (molly_gemm_rows_tail_bf16_ctx, tail 2, M <= 32): 1 (default) = the one-slice kernel
                                              that forms silu(gate) * up from its accumulators (no slabs, no combine launch), tile chosen by the launcher;
-                                             64 | 128 = that many W rows per tile; 0 = K slices + the combine launch */
+                                             32 | 64 | 128 = that many W rows per tile; 0 = K slices + the combine launch */
     MOLLY_GEMM_KEY_ROWS_BN = 16,          /* W rows per tile of the tiled decode-row kernel at M <= 32: 64 (default) | 128 */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */

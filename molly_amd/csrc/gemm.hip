@@ -95,7 +95,7 @@ __device__ __forceinline__ void dma16_lane(const char* src, bf16_t* lds_dst) {  
 // gate and the up projection of the SAME 32 activation columns, so its epilogue holds both values of every element it owns.
 template <int ROWS, int NW, int BK, bool HIDE = false>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, int row0, int rows_total, int k0,
-                                         bf16_t* lds_tile, int wave, int lane, int remap_ff = 0) {
+                                         bf16_t* lds_tile, int wave, int lane, int remap_ff = 0, int remap_shift = 5) {
     constexpr int CPR = BK / 8;                   // chunks per row (8: 128-B rows, 4: 64-B rows)
     constexpr int RPI = 64 / CPR;                 // rows per wave-instruction
     constexpr int PER = ROWS / RPI / NW;
@@ -111,7 +111,8 @@ __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, i
     for (int i = 0; i < PER; ++i) {
         const int inst = wave * PER + i;
         int rel = inst * RPI + r_in;
-        if (remap_ff) rel = ((rel >> 5) & 1) * remap_ff + row0 + (rel >> 6) * 32 + (rel & 31);   // ff % 128 == 0: no ragged tile
+        // (groups of 1 << remap_shift rows: gate, up, gate, up ..; ff a multiple of the tile's columns: no ragged tile)
+        if (remap_ff) rel = ((rel >> remap_shift) & 1) * remap_ff + row0 + ((rel >> (remap_shift + 1)) << remap_shift) + (rel & ((1 << remap_shift) - 1));
         else rel = rel < last ? rel : last;
         const unsigned off = ((unsigned)rel * (unsigned)ld + (unsigned)(c_src * 8)) * 2u;
         dma16<HIDE>(base, off, lds_tile + inst * 512);
@@ -1496,9 +1497,9 @@ template <int MT, int NSTAGE, int BN = 128, bool GU = false>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
     constexpr int BM = 16 * MT, BK = 64, A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
     constexpr int NLOAD = BN * BK * 2 / 1024 / 4 + BM * BK * 2 / 1024 / 4;          // LDS-DMA instructions per wave per stage: 2-4 of W, 1-2 of x
-    constexpr int NJ = BN / 64;                                   // 16-column blocks per wave
+    constexpr int NJ = BN >= 64 ? BN / 64 : 1;                    // 16-column blocks per wave (BN = 32: one block, HALF of every K-tile — below)
     static_assert(MT == 2 || MT == 4, "16 MT rows: 32 or 64");
-    static_assert(BN == 128 || BN == 64, "W rows per tile");
+    static_assert(BN == 128 || BN == 64 || (BN == 32 && GU && MT == 2), "W rows per tile");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);          // [stage][x tile | W tile]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1520,7 +1521,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
         bf16_t* dst = smem + slot * STAGE;
         stage_kc<BM, 4, BK, true>(p.X, p.ldx, m0, p.M, (kt0 + t) * BK, dst, wave, lane);
         // GU: tile rows in groups of 32 — gate, up, (gate, up) — of columns n0 .. (stage_kc's remap: the training step's fused SwiGLU uses it too)
-        stage_kc<BN, 4, BK, true>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane, GU ? ff : 0);
+        stage_kc<BN, 4, BK, true>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane, GU ? ff : 0, BN == 32 ? 4 : 5);
     };
     // s_waitcnt vmcnt(k * NLOAD): everything but the k youngest stages has landed (k = 0 .. NSTAGE - 2)
     auto wait_younger = [&](int k) {
@@ -1543,6 +1544,19 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
         if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, slot == 0 ? NSTAGE - 1 : slot - 1);
         const bf16_t* sA = smem + slot * STAGE;
         const bf16_t* sB = sA + A_ELEMS;
+        if constexpr (BN == 32) {
+            // 16 gate + 16 up rows of the same 16 columns: wave = (block: gate | up) x (half of the K-tile); the halves and the pair meet after the loop
+            const int kk = wave >> 1;
+            bf16x8 xh[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xh[i] = frag_kc<BK>(sA, i * 16 + fr, kk * 4 + fq);
+            const bf16x8 wh = frag_kc<BK>(sB, (wave & 1) * 16 + fr, kk * 4 + fq);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[i], acc[i][0], 0, 0, 0);
+            slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+            continue;
+        }
         bf16x8 xf[2][MT], wf[2][NJ];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1566,6 +1580,39 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
         // [M][2 ff]; p.res: the activation [M][ldres]
         bf16_t* act = const_cast<bf16_t*>(p.res);
         bf16_t* gu = reinterpret_cast<bf16_t*>(p.C);
+        if constexpr (BN == 32) {
+            __syncthreads();                                   // every wave is done with the ring: its first 8 KB carry the four partial blocks
+            float* xch = reinterpret_cast<float*>(smem_raw);   // [4 waves][MT][64 lanes][4]
+#pragma unroll
+            for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(xch + ((wave * MT + i) * 64 + lane) * 4) = acc[i][0];
+            __syncthreads();
+            if (wave >= MT) return;
+            const int i = wave;                                // wave i finishes row block i
+            auto part = [&](int w) { return *reinterpret_cast<const f32x4*>(xch + ((w * MT + i) * 64 + lane) * 4); };
+            f32x4 g = part(0), u = part(1);
+            g += part(2); u += part(3);                        // K-tile halves, first + second
+            const int m = m0 + i * 16 + fr, n = n0 + fq * 4;
+            if (m >= p.M) return;
+            if (p.bias) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n), b2 = *reinterpret_cast<const u32x2*>(p.bias + ff + n);
+                g[0] += bflo(b[0]); g[1] += bfhi(b[0]); g[2] += bflo(b[1]); g[3] += bfhi(b[1]);
+                u[0] += bflo(b2[0]); u[1] += bfhi(b2[0]); u[2] += bflo(b2[1]); u[3] += bfhi(b2[1]);
+            }
+            const u32x2 gq = u32x2{pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3])}, uq = u32x2{pack_bf2(u[0], u[1]), pack_bf2(u[2], u[3])};
+            if (gu) {
+                *reinterpret_cast<u32x2*>(gu + (size_t)m * p.ldc + n) = gq;
+                *reinterpret_cast<u32x2*>(gu + (size_t)m * p.ldc + ff + n) = uq;
+            }
+            u32x2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ga = bflo(gq[e]), gb = bfhi(gq[e]);
+                const float sa = bf2f(f2bf(ga * sigmoid_fast(ga))), sb = bf2f(f2bf(gb * sigmoid_fast(gb)));
+                o[e] = pack_bf2(sa * bflo(uq[e]), sb * bfhi(uq[e]));
+            }
+            *reinterpret_cast<u32x2*>(act + (size_t)m * p.ldres + n) = o;
+            return;
+        }
         if constexpr (BN == 64) {
             __syncthreads();                                   // every wave is done with the ring: its first bytes carry the up halves
             float* xch = reinterpret_cast<float*>(smem_raw);   // [2 waves][MT][64 lanes][4]
@@ -1877,8 +1924,8 @@ struct GemmCtx {
                                    // (tools/bench_esm_gemm.py: 22.4 / 24.4 / 27.5 us against 21.8 / 22.7 / 27.5 at M = 1024): these launches are not
                                    // bound by the LDS-DMA drain
     int rows_gu = 1;               // decode rows of gate | up with SwiGLU (tail 2, M <= 32): the ONE-slice kernel that forms the activation from its
-                                   // accumulators — 1: on, W rows per tile chosen by the launcher; 64 | 128: that tile; 0 = K slices through slabs + the
-                                   // combine launch (round 3's path; A/B)
+                                   // accumulators — 1: on, W rows per tile chosen by the launcher; 32 | 64 | 128: that tile; 0 = K slices through slabs +
+                                   // the combine launch (round 3's path; A/B)
     int rows_bn = 64;              // W rows per tile of the tiled decode-row kernel at M <= 32: 64 (48 KB of LDS: three workgroups per CU, twice the column
                                    // tiles, fewer K slices and slabs) | 128 (round 3).  M = 32, us at 128 | 64 (tools/bench_decode_gemm.py, profiles/r04_logs/
                                    // rows_bn_bench.log): 8B qkv 17.8 | 16.6, o 15.6 | 13.6, down 27.9 | 26.4; 4B down 21.7 | 19.6; 1.7B gate|up 17.6 | 16.5;
@@ -2142,9 +2189,12 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
                M, N, K, lda, ldb, ldc, ldres, flags, cdiv(N, 128), 1, M <= 64 ? 1 : cdiv(M, 64)};
     if (tail == 2 && c.rows_gu && M <= 32 && (N / 2) % 64 == 0) {
         // gate | up with SwiGLU, one K slice: the activation from the accumulators, no slabs and no combine launch (gemm_rows_kernel<.., GU>)
-        // 128 W rows per tile where that still makes >= 128 workgroups, else 64 (tools/r04/bench_rows_gu.py, M = 32, us at 64 | 128: Qwen3-8B 45.7 | 45.9
-        // (M = 24: 45.4 | 43.4), 4B 27.6 | 24.8, 1.7B 13.2 | 16.3; K slices + combine launch: 50.9, 25.6, 17.2)
-        const int bn = c.rows_gu > 1 ? c.rows_gu : ((N / 2) / 64 >= 128 ? 128 : 64);
+        // W rows per tile (tools/r04/bench_rows_gu.py, profiles/r04_logs/rows_gu_bench2.log; M = 32, us at 32 | 64 | 128, K slices + combine launch last):
+        // Qwen3-8B (201 MB) 41.6 | 47.5 | 45.5, 47.5; ff 16,384 x 4,096 (268 MB) 55.0 | 52.7 | 60.6, 63.6; ff 24,576 (403 MB) 79.0 | 84.4 | 86.9, 89.2;
+        // Qwen3-4B (100 MB) 26.9 | 27.8 | 24.9, 27.3; 1.7B (50 MB) 14.6 | 13.3 | 16.3, 16.4 — the 150 MB+ matrices want the most workgroups (768+ of
+        // 32 KB: up to five per CU), the smaller ones the fewest that still cover the chip
+        const int bn = c.rows_gu > 1 ? c.rows_gu : ((long)N * K * 2 >= 150000000L && (N / 2) % 16 == 0 ? 32 : (N / 2) / 64 >= 128 ? 128 : 64);
+        if (bn == 32 && (N / 2) % 16 != 0) { molly_set_error("gemm rows gate|up: ff=%d is no multiple of 16", N / 2); return 1; }
         q.tiles_n = (N / 2) / (bn / 2);
         q.res = (const bf16_t*)tail_out; q.ldres = ld_tail;
         q.bias = (flags & MOLLY_GEMM_BIAS) ? (const bf16_t*)bias : nullptr;
@@ -2155,8 +2205,9 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
             gu_attr = true;
         }
         if (bn == 128) hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 128, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
-        else hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 64, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 64) * 64 * 2, st, q);
-        c.last_cfg = 32 + 1000 + 100 * (bn / 64);       // (one slice; + 100 / 200: the SwiGLU form at 64 / 128 W rows per tile)
+        else if (bn == 64) hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 64, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 64) * 64 * 2, st, q);
+        else hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 32, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 32) * 64 * 2, st, q);
+        c.last_cfg = 32 + 1000 + (bn == 32 ? 300 : 100 * (bn / 64));       // (one slice; + 100 / 200 / 300: the SwiGLU form at 64 / 128 / 32 W rows per tile)
         return 0;
     }
     const int bn = M <= 32 ? c.rows_bn : 128;
@@ -2411,7 +2462,7 @@ int ctx_set(GemmCtx& c, int key, long v) {
         c.rows_bn = (int)v;
         return 0;
     case MOLLY_GEMM_KEY_ROWS_GU:
-        MOLLY_CHECK(v == 0 || v == 1 || v == 64 || v == 128, "gemm rows_gu: %ld not in {0, 1, 64, 128}", v);
+        MOLLY_CHECK(v == 0 || v == 1 || v == 32 || v == 64 || v == 128, "gemm rows_gu: %ld not in {0, 1, 32, 64, 128}", v);
         c.rows_gu = (int)v;
         return 0;
     case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK:

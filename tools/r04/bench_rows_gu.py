@@ -9,13 +9,13 @@ from molly_amd import ops  # noqa: E402
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
-for name, ff, k in (("8b", 12288, 4096), ("4b", 9728, 2560), ("1.7b", 6144, 2048)):
-    for m in (32, 24):
+for name, ff, k in (("8b", 12288, 4096), ("256t", 16384, 4096), ("384t", 24576, 4096), ("4b", 9728, 2560), ("1.7b", 6144, 2048)):
+    for m in (32,):
         x = rnd(m, k)
         ws = [rnd(2 * ff, k) * k ** -0.5 for _ in range(6)]
         act = torch.empty(m, ff, dtype=torch.bfloat16, device=dev)
         out = []
-        for mode in (0, 64, 128):
+        for mode in (0, 32, 64, 128):
             c = ops.GemmContext(); c.ensure_workspace(256 << 20); c.set("rows_gu", mode)
             with ops.use_gemm_context(c):
                 if not ops.gemm_rows_tail_supported(m, 2 * ff, k, "swiglu"):
