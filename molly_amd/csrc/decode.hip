@@ -296,15 +296,17 @@ void launch(hipStream_t st, const DecodeArgs& p, int B, int nw) {
         hipLaunchKernelGGL(attn_decode_merge_kernel<HD>, dim3(B * p.nh), dim3(HD), 0, st, p.part, p.out, p.splits);
 }
 
-// blocks of 16 waves, one per (sample, KV head), where those fill the chip (>= 3/4 of the 256 CUs) and every one has at least 16 x 64 keys;
-// otherwise blocks of 4 waves and the key range cut so that ~4 per CU exist, >= 256 keys each (kv_len_hint = upper bound of the valid
-// length, 0 = Tmax).  MOLLY_DECODE_NW = 4 | 16, MOLLY_DECODE_BLOCKS, MOLLY_DECODE_MIN_KEYS override (A/B).
+// blocks of 16 waves (caches of >= 512 keys): one per (sample, KV head) where those cover >= 3/4 of the 256 CUs, else the key range cut so that ~256
+// blocks exist; short caches: blocks of 4 waves and the key range cut so that ~4 per CU exist; >= 256 keys per block either way (kv_len_hint =
+// upper bound of the valid length, 0 = Tmax).  MOLLY_DECODE_NW = 4 | 16, MOLLY_DECODE_BLOCKS, MOLLY_DECODE_MIN_KEYS override (A/B).
 void pick_shape(int B, int n_kv_heads, int len, bool have_ws, int* nw, int* splits) {
     static const int target = [] { const char* e = getenv("MOLLY_DECODE_BLOCKS"); return e ? atoi(e) : 1024; }();
     static const int min_keys = [] { const char* e = getenv("MOLLY_DECODE_MIN_KEYS"); return e ? atoi(e) : 256; }();
     static const int force_nw = [] { const char* e = getenv("MOLLY_DECODE_NW"); return e ? atoi(e) : 0; }();
     const int pairs = B * n_kv_heads;
-    *nw = force_nw == 4 || force_nw == 16 ? force_nw : (pairs >= 192 && len >= 1024 ? 16 : 4);
+    // (16 waves at every batch: Qwen3-8B decode step, 3,100 keys, ms at 4 | 16 waves: B = 4 4.98 | 4.85, 8 5.33 | 5.18, 16 6.16 | 5.99, 24 6.62 | 6.01,
+    // 28 7.02 | 6.32 — the 192 / 224 blocks of B = 24 / 28 leave CUs empty and still win; profiles/r04_logs/decode_nw.log)
+    *nw = force_nw == 4 || force_nw == 16 ? force_nw : (len >= 512 ? 16 : 4);
     if (*nw == 16 && (pairs >= 192 || !have_ws)) { *splits = 1; return; }
     const int per = *nw == 16 ? 256 : target;
     int sp = (per + pairs - 1) / pairs;
