@@ -1,3 +1,4 @@
 mkdir -p gpurun_out/r04
 python -m pytest tests -x -q -m gpu > gpurun_out/r04/final_gpu_suite.log 2>&1; tail -3 gpurun_out/r04/final_gpu_suite.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+python bench.py > gpurun_out/r04/t3_bench.json 2> gpurun_out/r04/t3_bench.err; tail -c 600 gpurun_out/r04/t3_bench.json
