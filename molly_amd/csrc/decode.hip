@@ -89,8 +89,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(DecodeArgs p) {
             const int ku = key + u * STEP;
             ok[u] = ku < k1;
             const int kc_ = ok[u] ? ku : key;                     // clamp: a valid row, masked below
-            kv[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)kc_ * ldc);
-            vv[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)kc_ * ldc);
+            // (non-temporal: every cache byte is read once per step, by one block)
+            kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)kc_ * ldc));
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)kc_ * ldc));
         }
     };
     const int key_first = k0 + wave * RPW + rg;

@@ -67,9 +67,14 @@ struct GemmArgs {
 __device__ __forceinline__ void lds_put(void* p, unsigned v) { *reinterpret_cast<volatile __attribute__((address_space(3))) unsigned*>(LDS_PTR(p)) = v; }
 __device__ __forceinline__ unsigned lds_get(void* p) { return *reinterpret_cast<volatile __attribute__((address_space(3))) unsigned*>(LDS_PTR(p)); }
 
-template <bool HIDE>
+template <bool HIDE, bool NT = false>
 __device__ __forceinline__ void dma16(const char* base, unsigned off, bf16_t* lds_dst) {
-    if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
+    if constexpr (HIDE && MOLLY_GEMM_ASM_DMA && NT) {
+        // non-temporal: bytes ONE workgroup reads ONCE (the weight stream of a decode-row launch) do not displace what the chip re-reads
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(off), "s"(base), "s"(lds_addr)
+                     : "memory", "m0");
+    } else if constexpr (HIDE && MOLLY_GEMM_ASM_DMA) {
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(lds_dst));
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr)
                      : "memory", "m0");
@@ -93,7 +98,7 @@ __device__ __forceinline__ void dma16_lane(const char* src, bf16_t* lds_dst) {  
 // rows but, in 32-row groups, [gate c..c+31 | up c..c+31 | gate c+32..c+63 | up c+32..c+63] with c = row0 (an index into the
 // `ff` activation columns; up rows live `remap_ff` rows below their gate rows).  A wave's two 32-column n-halves are then the
 // gate and the up projection of the SAME 32 activation columns, so its epilogue holds both values of every element it owns.
-template <int ROWS, int NW, int BK, bool HIDE = false>
+template <int ROWS, int NW, int BK, bool HIDE = false, bool NT = false>
 __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, int row0, int rows_total, int k0,
                                          bf16_t* lds_tile, int wave, int lane, int remap_ff = 0, int remap_shift = 5) {
     constexpr int CPR = BK / 8;                   // chunks per row (8: 128-B rows, 4: 64-B rows)
@@ -115,7 +120,7 @@ __device__ __forceinline__ void stage_kc(const bf16_t* __restrict__ g, int ld, i
         if (remap_ff) rel = ((rel >> remap_shift) & 1) * remap_ff + row0 + ((rel >> (remap_shift + 1)) << remap_shift) + (rel & ((1 << remap_shift) - 1));
         else rel = rel < last ? rel : last;
         const unsigned off = ((unsigned)rel * (unsigned)ld + (unsigned)(c_src * 8)) * 2u;
-        dma16<HIDE>(base, off, lds_tile + inst * 512);
+        dma16<HIDE, NT>(base, off, lds_tile + inst * 512);
     }
 }
 
@@ -1483,6 +1488,9 @@ __global__ __launch_bounds__(64 * KW) void gemm_skinny_kernel(SkinnyArgs p) {
 //     built and measured 1-3 us SLOWER per launch than the reduce launch it saves: 19.7 / 16.9 / 29.1 against 17.8 / 14.2 / 28.0 us
 //     on Qwen3-8B qkv / o / down at M = 32; a dependent launch in the same stream overlaps the tail the hand-off serialises.)
 // ================================================================================================
+#ifndef MOLLY_ROWS_W_NT
+#define MOLLY_ROWS_W_NT 1
+#endif
 struct RowsArgs {
     const bf16_t* X; const bf16_t* W; void* C; const bf16_t* bias; const bf16_t* res; float* ws;
     int M, N, K, ldx, ldw, ldc, ldres, flags, tiles_n, splits;
@@ -1521,7 +1529,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
         bf16_t* dst = smem + slot * STAGE;
         stage_kc<BM, 4, BK, true>(p.X, p.ldx, m0, p.M, (kt0 + t) * BK, dst, wave, lane);
         // GU: tile rows in groups of 32 — gate, up, (gate, up) — of columns n0 .. (stage_kc's remap: the training step's fused SwiGLU uses it too)
-        stage_kc<BN, 4, BK, true>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane, GU ? ff : 0, BN == 32 ? 4 : 5);
+        // (W non-temporal at decode rows — MT = 2: one row tile, every W byte read once by one workgroup; x, which every workgroup re-reads, default)
+        stage_kc<BN, 4, BK, true, MT == 2 && MOLLY_ROWS_W_NT>(p.W, p.ldw, n0, p.N, (kt0 + t) * BK, dst + A_ELEMS, wave, lane, GU ? ff : 0, BN == 32 ? 4 : 5);
     };
     // s_waitcnt vmcnt(k * NLOAD): everything but the k youngest stages has landed (k = 0 .. NSTAGE - 2)
     auto wait_younger = [&](int k) {

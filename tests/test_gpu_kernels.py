@@ -861,7 +861,8 @@ def _decode_qkv_case(B, nh, nkv, hd, H, Tmax, n_keys, seed, ragged=True):
 
 
 @pytest.mark.parametrize("B,nh,nkv,hd,H,n_keys,nw", [(32, 32, 8, 128, 4096, 1500, 0), (32, 32, 8, 128, 4096, 1500, 4), (8, 16, 8, 128, 2048, 700, 0),
-                                                    (24, 16, 8, 64, 1024, 300, 0), (32, 32, 8, 128, 4096, 37, 16), (4, 8, 8, 128, 1024, 1100, 16)])
+                                                    (24, 16, 8, 64, 1024, 300, 0), (32, 32, 8, 128, 4096, 37, 16), (4, 8, 8, 128, 1024, 1100, 16), (2, 16, 2, 128, 1024, 600, 0),
+                                                    (3, 8, 1, 64, 512, 90, 4)])
 def test_attn_decode_from_the_projection_slabs_equals_the_three_launches(B, nh, nkv, hd, H, n_keys, nw, monkeypatch):
     """molly_attn_decode_qkv (slab combine + q/k-norm + rotary + cache append + attention over the old keys and the new one, ONE
     launch; blocks of 16 waves without key splits where B * n_kv_heads fills the chip) against molly_gemm_rows_qkv_bf16_ctx +
