@@ -79,7 +79,7 @@ __device__ __forceinline__ void dma16(const char* base, unsigned off, bf16_t* ld
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr)
                      : "memory", "m0");
     } else {
-        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(lds_dst), 16, 0, NT ? 2 : 0);       // (aux 2 = nt)
     }
 }
 template <bool HIDE>
@@ -232,7 +232,9 @@ __device__ __forceinline__ bf16x8 frag_km(const bf16_t* lds_tile, int kk, int co
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
 
-template <bool AT, bool BT, int BM, int NSTAGE, int BK>
+// NTB: the k-contiguous B operand (a weight matrix) loaded non-temporal — launches of ONE row tile, where every weight byte is read once by one
+// workgroup (the lm_head of a decode step: 1.2 GB)
+template <bool AT, bool BT, int BM, int NSTAGE, int BK, bool NTB = false>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
     constexpr int NW = BM / 32;                       // waves: (BM/64) x 2, each 64x64
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(GemmArgs p) {
         if (AT) stage_km<BM, NW, BK, HIDE>(p.A, p.lda, m0, p.M, t * BK, p.K, p.zeros, dst, wave, lane);
         else stage_kc<BM, NW, BK, HIDE>(p.A, p.lda, m0, p.M, t * BK, dst, wave, lane);
         if (BT) stage_km<BN, NW, BK, HIDE>(p.B, p.ldb, n0, p.N, t * BK, p.K, p.zeros, dst + A_ELEMS, wave, lane);
-        else stage_kc<BN, NW, BK, HIDE>(p.B, p.ldb, n0, p.N, t * BK, dst + A_ELEMS, wave, lane);
+        else stage_kc<BN, NW, BK, HIDE, NTB>(p.B, p.ldb, n0, p.N, t * BK, dst + A_ELEMS, wave, lane);
     };
     const int fr = lane & 15, fq = lane >> 4;
     auto read_frags = [&](const bf16_t* sA, int kk, bf16x8 (&af)[4], bf16x8 (&bfr)[4]) {
@@ -2149,7 +2151,17 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
         if (c.small3 && nk >= 3 && p.tiles_m * p.tiles_n <= 256)
             hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 3, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
                                3 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
-        else
+        else if (!AT && !BT && p.tiles_m == 1 && p.tiles_n >= 512) {
+            // one row tile against a wide weight matrix (the lm_head at decode rows): the weights non-temporal
+            static bool nt_attr = false;
+            if (!nt_attr) {
+                (void)hipFuncSetAttribute((const void*)gemm_kernel<AT, BT, 128, 2, 64, !AT && !BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          2 * (128 + BN) * 64 * 2);
+                nt_attr = true;
+            }
+            hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 64, !AT && !BT>), dim3(p.tiles_m * p.tiles_n), dim3(256),
+                               2 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
+        } else
             hipLaunchKernelGGL((gemm_kernel<AT, BT, 128, 2, 64>), dim3(p.tiles_m * p.tiles_n), dim3(256),
                                2 * (128 + BN) * 64 * sizeof(bf16_t), st, p);
     }

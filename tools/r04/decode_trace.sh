@@ -4,4 +4,3 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_dec -- python3 $R/bench.py --secondary-worker c5 > $O/decode_trace_run.log 2>&1
 f=$(ls /tmp/p_dec/*/*kernel_trace.csv | head -1)
 python3 $R/tools/r04/decode_trace.py $f | tee $O/decode_trace.log
-cd $R && timeout 900 python -m pytest tests/test_gpu_train.py -x -q -k roctx 2>&1 | tail -3 | tee $O/roctx_test.log
