@@ -2246,6 +2246,20 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
                             (sp > 1 ? (5.0 + 8.0 * sp * M * N / 5e6) / 0.75 : 0.0);
         if (cost < best_cost) { best_cost = cost; splits = sp; }
     }
+    if (M <= 32 && bn == 64) {
+        // decode rows on 64-row tiles with non-temporal weights: as many K slices as keep the launch within ONE workgroup per CU (the largest count with
+        // tiles x slices <= 256), slices of >= 4 K-tiles.  us of GEMM + combine at M = 32 by slice count (tools/r04/bench_rows_splits.py,
+        // profiles/r04_logs/rows_splits.log): 8B o (64 tiles) 3: 12.0, 4: 11.2, 5: 13.3, 8: 13.6, 12: 15.6; 8B down 3: 26.1, 4: 22.4, 5: 29.9, 8: 24.2,
+        // 12: 26.5; 8B qkv (96 tiles) 2: 15.9, 4: 15.8, 5: 15.4, 8: 16.8; 4B o (40 tiles) 4: 10.6, 5: 10.2, 6: 10.4, 8: 11.9, 16: 14.8; 4B down 4: 17.3,
+        // 6: 15.2, 8: 18.2, 19: 20.2; 4B qkv 2: 11.8, 4: 13.2, 8: 14.7 — the priced model above (rounds of 768 resident workgroups) took 8-19 slices
+        int sp = ntile > 0 ? 256 / ntile : 1;
+        sp = sp > nk / 4 ? nk / 4 : sp;
+        sp = sp < (tail ? 2 : 1) ? (tail ? 2 : 1) : sp;
+        while (sp > 1 && (size_t)sp * M * N * sizeof(float) > ws_slab_bytes(c)) --sp;
+        splits = sp;
+    }
+    static const int force_sp = [] { const char* e = getenv("MOLLY_ROWS_FORCE_SPLITS"); return e ? atoi(e) : 0; }();     // (A/B)
+    if (force_sp > 0 && nk / force_sp >= 1 && (size_t)force_sp * M * N * sizeof(float) <= ws_slab_bytes(c)) splits = force_sp;
     if (tail && (splits < 2 || (size_t)splits * M * N * sizeof(float) > ws_slab_bytes(c))) {
         molly_set_error("gemm rows tail: the context has no scratch for %d x %d x %d slabs", splits, M, N);
         return 1;

@@ -619,7 +619,10 @@ def test_gemm_decode_rows_tiled_kernel(M, N, K):
         out = ops.gemm_nt(x, w, out_dtype=torch.float32)
         cfg = c.get("last_config")
         assert cfg % 1000 == 32, cfg
-        assert (cfg // 1000 == 1) == (N == 40000 or K == 256), cfg           # one slice only where the column tiles alone fill the chip
+        if M <= 32:      # 64-row tiles: as many K slices as keep tiles x slices <= 256 (one workgroup per CU), slices of >= 4 K-tiles
+            assert cfg // 1000 == max(1, min(256 // -(-N // 64), (K // 64) // 4)), cfg
+        else:            # 128-row tiles, priced rounds: one slice only where the column tiles alone fill the chip
+            assert (cfg // 1000 == 1) == (N == 40000 or K == 256), cfg
         out_again = ops.gemm_nt(x, w, out_dtype=torch.float32)               # the tile counters were left at zero
         assert torch.equal(out_again, ref)
         assert torch.equal(out, ref)
@@ -743,11 +746,17 @@ def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
         x2, w2 = rnd(M, H), rnd(2 * 6144, H, sc=H ** -0.5)
         assert ops.gemm_rows_tail_supported(M, 2 * 6144, H, "swiglu")
         gu0 = ops.gemm_nt(x2, w2)
+        cfg0 = c.get("last_config")
         a0 = ops.swiglu_fwd(gu0)
         gu1, a1 = torch.empty_like(gu0), torch.empty_like(a0)
-        c.set("rows_gu", 0)                                  # K slices + the combine launch: the same sums as the plain GEMM
+        c.set("rows_gu", 0)                                  # K slices + the combine launch
         ops.gemm_rows_swiglu(x2, w2, gu1, a1)
-        assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+        if c.get("last_config") == cfg0:                     # the same K slices as the plain GEMM took: the same sums
+            assert torch.equal(gu0, gu1) and torch.equal(a0, a1)
+        else:                                                # (a tail needs >= 2 slices; the plain GEMM of a wide matrix takes one)
+            d = (gu1.float() - gu0.float()).abs()
+            assert d.max().item() <= 2 ** -7 * gu0.float().abs().max().item() and (d > 0).float().mean().item() < 0.03
+            assert torch.equal(a1, ops.swiglu_fwd(gu1))
         for bn in (32, 64, 128):
             # M <= 32: ONE K slice, the activation formed from the accumulators (no slabs): gate | up differ from the sliced sums by the
             # fp32 order only, and the activation is exactly SwiGLU of the gate | up the launch stored; without a gate | up output: the same
@@ -769,11 +778,16 @@ def test_gemm_decode_rows_tails_equal_the_separate_kernels(M):
         ops.gemm_rows_norm(x, w, yb1, gain, 1e-6, nb1, res=res, bias=bias)
         assert torch.equal(yb0, yb1) and (nb0.float() - nb1.float()).abs().max().item() <= 2 ** -7 * nb0.float().abs().max().item()
         gub0 = ops.gemm_nt(x2, w2, bias=bias2)
+        cfgb = c.get("last_config")
         ab0 = ops.swiglu_fwd(gub0)
         gub1, ab1 = torch.empty_like(gub0), torch.empty_like(ab0)
         c.set("rows_gu", 0)
         ops.gemm_rows_swiglu(x2, w2, gub1, ab1, bias=bias2)
-        assert torch.equal(gub0, gub1) and torch.equal(ab0, ab1)
+        if c.get("last_config") == cfgb:
+            assert torch.equal(gub0, gub1) and torch.equal(ab0, ab1)
+        else:
+            assert (gub1.float() - gub0.float()).abs().max().item() <= 2 ** -7 * gub0.float().abs().max().item()
+            assert torch.equal(ab1, ops.swiglu_fwd(gub1))
         c.set("rows_gu", 64)
         ops.gemm_rows_swiglu(x2, w2, gub1, ab1, bias=bias2)
         assert (gub1.float() - gub0.float()).abs().max().item() <= 2 ** -7 * gub0.float().abs().max().item()
