@@ -611,6 +611,17 @@ def main(argv=None):
         n_launch = len(prof)
         timed = [(a.elapsed_time(b), f, kcfg, lay) for a, b, f, kcfg, lay in prof if a is not None]
         achieved = sum(f for _, f, *_ in timed) / (sum(t for t, *_ in timed) * 1e-3) / 1e12
+        if os.environ.get("MOLLY_GEMM_TABLE"):
+            # (diagnostic: every distinct (2MNK, launch config, layout) of the timed launches — where a step's GEMM time sits, shape by shape)
+            tab = {}
+            for t_ms, f, kcfg, lay in timed:
+                d = tab.setdefault((f, kcfg, lay), [0, 0.0])
+                d[0] += 1; d[1] += t_ms
+            tot = sum(v[1] for v in tab.values())
+            with open(os.environ["MOLLY_GEMM_TABLE"], "w") as fh:
+                fh.write(f"# {sum(v[0] for v in tab.values())} timed GEMM launches, {tot:.2f} ms in all; 2MNK GFLOP | cfg | layout (A k-major, B k-major) | launches | avg us | TFLOP/s | share\n")
+                for (f, kcfg, lay), v in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                    fh.write(f"{f / 1e9:10.2f} {kcfg:7d} {str(lay):15s} {v[0]:5d} {v[1] / v[0] * 1e3:9.1f} {f * v[0] / (v[1] * 1e-3) / 1e12:8.1f} {v[1] / tot:6.3f}\n")
         by_kernel = {}
         names = {(False, False): "NT gemm256_kernel<false,false>", (False, True): "NN gemm256_kernel<false,true>",
                  (True, True): "TN gemm256_kernel<true,true>"}

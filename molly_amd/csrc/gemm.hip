@@ -2070,6 +2070,13 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
                 p.ws = ws_slabs(c);
             } else {
                 force_tile = TO ? 512 : c.small_grid_tile;     // transposed output exists in the 256x256 kernel only
+                // a grid of 128..199 tiles whose contraction is too short to slice (Qwen3-4B's o_proj dgrad at one sample per GPU: 3,072 x 4,096 x
+                // 2,560 = 192 tiles x 40 K-tiles): ONE round of the 256x256 kernel on three quarters of the CUs beats 768 tiles of the 128x128
+                // kernel (109.7 us = 587 TFLOP/s measured there, profiles/r04_logs/c3_gemm_table.txt) — priced with the constants used below
+                static const int partial_round = [] { const char* e = getenv("MOLLY_GEMM_PARTIAL_ROUND"); return e ? atoi(e) : 1; }();
+                if (partial_round && force_tile == 128 && t256 >= 128 && t256 < 256 && p.M >= 256 && p.N >= 256 &&
+                    12.0 + 6.0 + 1.4 * nk < 5.0 + (t128 > 512 ? (t128 / 512.0 + 0.35) * 1.17 : 1.25) * nk)
+                    force_tile = 512;
             }
         }
         {
