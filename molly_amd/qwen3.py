@@ -328,9 +328,14 @@ class Qwen3Engine:
             self._pend.append((dyt, x, dw, False))
 
     def _wgrad_flush(self, accumulate: bool):
-        if self._pend:
-            ops.gemm_grouped(self._pend, accumulate=accumulate)
-            self._pend = []
+        if not self._pend:
+            return
+        probs, self._pend = self._pend, []
+        probs, carved = _carve_remainder(probs)
+        ops.gemm_grouped(probs, accumulate=accumulate)
+        if carved is not None:
+            a, b, out, to = carved
+            ops.gemm(a, b, out=out, accumulate=accumulate, b_kmajor=True, trans_out=to)
 
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
         """dw[N,K] (+)= dy[M,N]^T x[M,K], contraction over the M token rows.
@@ -469,3 +474,34 @@ class Qwen3Engine:
         if defer:
             ops.colsum_batched(self.ws_defer, accumulate=acc_n)                # all 4L + 1 gain gradients, one launch
         return dx
+
+
+def _carve_remainder(probs):
+    """The grouped weight-gradient launch walks its 256 x 256 tiles in rounds of 256 (one per CU).  A tile count a FEW past whole rounds —
+    Qwen3-4B at one sample per GPU: 240 + 160 + 760 + 380 = 1,540 = 6 rounds + 4 tiles — costs a seventh tile-time on four CUs (14 % of the
+    launch, 27 % of that step's GEMM time: profiles/r04_logs/c3_gemm_table.txt).  Then the last tile-row of one problem gives up its last R
+    tiles: the problem becomes (at most) two rectangles of the grouped launch, now whole rounds, and the R tiles run as a GEMM of their own behind
+    it, K split over the chip (~30 us against the ~85 us tile-time saved).  Every output element is still written by exactly one launch.
+    -> (problems for the grouped launch, carved problem | None).  MOLLY_WGRAD_CARVE=0: off."""
+    if os.environ.get("MOLLY_WGRAD_CARVE", "1") == "0" or len(probs) > 14:
+        return probs, None
+    tiles = [(-(-a.shape[0] // 256), -(-b.shape[1] // 256)) for a, b, _, _ in probs]
+    total = sum(gm * gn for gm, gn in tiles)
+    rem = total % 256
+    K = probs[0][0].shape[1]
+    if not (total > 256 and 0 < rem <= 16 and K >= 2048):
+        return probs, None
+    for idx in sorted(range(len(probs)), key=lambda i: -tiles[i][1]):
+        gm, gn = tiles[idx]
+        a, b, out, to = probs[idx]
+        if gn < rem or a.shape[0] % 256 or b.shape[1] % 256 or (gm == 1 and gn == rem):
+            continue
+        r0, c0 = (gm - 1) * 256, (gn - rem) * 256
+        new = []
+        if gm > 1:
+            new.append((a[:r0], b, out[:, :r0] if to else out[:r0], to))
+        if gn > rem:
+            new.append((a[r0:], b[:, :c0], out[:c0, r0:] if to else out[r0:, :c0], to))
+        carved = (a[r0:], b[:, c0:], out[c0:, r0:] if to else out[r0:, c0:], to)
+        return probs[:idx] + new + probs[idx + 1:], carved
+    return probs, None

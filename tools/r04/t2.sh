@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fuzz.py tests/test_gpu_edge_cases.py tests/test_gpu_streamk.py tests/test_gpu_small_split.py tests/test_gpu_dynamic_fetch.py tests/test_gpu_config4.py -q 2>&1 | tail -4
-B="--no-cpu-baseline --no-secondary --no-vendor-gemm"
-python bench.py $B 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('headline', d['ms_per_step'], d['value'], d['config'].get('batch8_reference',{}).get('step_ms_p50'))"
+B="--no-cpu-baseline --no-secondary --no-vendor-gemm --no-batch8-reference"
+MOLLY_GEMM_TABLE=gpurun_out/r04/c3_gemm_table3.txt python bench.py --steps 2 --warmup 2 --event-stride 1 $B --model 4b --batch 1 --seq 3072 --micro "dna:512,rna:512,protein:512;dna:512,rna:512,protein:512" 2>/dev/null | tail -1 | cut -c1-100
+head -3 gpurun_out/r04/c3_gemm_table3.txt; grep "^ *1\.61 \|^ *617\|^ *618\|^ *619" gpurun_out/r04/c3_gemm_table3.txt
