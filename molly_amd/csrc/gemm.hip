@@ -2192,7 +2192,7 @@ int resolve_zero_page(const bf16_t** out) {
 
 // ---- the tiled decode-row kernel's launcher.  tail: 0 none | 1 RMSNorm of the output rows (gain, eps -> tail_out [M][N]) | 2 SwiGLU
 // of an output that is [gate | up] (-> tail_out [M][N / 2]); a tail runs inside the slab combine, so it forces >= 2 K slices.
-// (not the lm_head: with >= 512 column tiles the 128x128 kernel streams it at 5.0 TB/s, this one at 4.8)
+// (round 3: not the lm_head — the 128x128 kernel streamed it at 5.0 TB/s, this one at 4.8; round 4, with 64-row tiles and non-temporal weights: rows_max_n())
 // which of the two decode-row kernels takes an M <= 64 forward GEMM: the register-streaming one wherever launches, not bytes, set the
 // time (matrices up to 9 M elements; M <= 16 on matrices of at most 4,096 rows), the tiled one everywhere else it applies
 // (tools/bench_decode_gemm.py, gpurun_out/r03/rows_bench3.log) — ONE rule for launch_gemm and molly_gemm_rows_tail_supported
@@ -2203,11 +2203,17 @@ inline bool streaming_rows(const GemmCtx& c, int M, int N, int K, int flags) {
     if (!rows_applicable(c, M, N, K, flags)) return M <= 16 || (long)N * K <= (32L << 20);     // (round 3's first rule, where the tiled kernel is off)
     return (long)N * K <= (9L << 20) || (M <= 16 && N <= 4096);
 }
+inline int rows_max_n() {
+    // (the lm_head of a decode step too since round 4: 64-row tiles + non-temporal weights stream its 1.2 GB at 5.25 TB/s, 237 us, against 4.85 TB/s,
+    // 257 us, on the 128x128 kernel — round 3 measured the opposite, 4.8 against 5.0, before those two; MOLLY_ROWS_MAX_N=65536 restores)
+    static const int v = [] { const char* e = getenv("MOLLY_ROWS_MAX_N"); return e ? atoi(e) : 1 << 20; }();
+    return v;
+}
 inline bool rows_applicable(const GemmCtx& c, int M, int N, int K, int flags) {
     // (M > 64, up to the context's rows_max_m: grids that leave most CUs with less than one 128x128 block — the encoders' projections
     // at one sample per GPU — as 64-row tiles of this kernel: four times the workgroups, two per CU)
     const bool small_m = M <= 64 || (M <= c.rows_max_m && (long)cdiv(M, 128) * cdiv(N, 128) <= 192);
-    return small_m && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < 65536 &&
+    return small_m && c.rows_tiled && c.force_tile == 0 && K % 64 == 0 && K >= 256 && N % 4 == 0 && N >= 128 && N < rows_max_n() &&
            !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD));
 }
 int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
