@@ -475,7 +475,7 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     rows, V = logits.shape
     if out is None:
         out = torch.empty(rows, dtype=torch.int64, device=logits.device)
-    key = (logits.device, rows)
+    key = (logits.device, rows, _stream())           # (per stream: two streams' launches must not share the partials)
     ws = _ARGMAX_WS.get(key)
     if ws is None:
         ws = _ARGMAX_WS[key] = torch.empty(lib().query("molly_argmax_workspace", rows), dtype=torch.uint8, device=logits.device)
