@@ -224,7 +224,7 @@ class GenerationSession:
     def step(self, token_ids: torch.Tensor) -> torch.Tensor:
         """token_ids int64 [B] (the tokens chosen from the previous logits).  Returns next-token logits [B, V] fp32 (a
         buffer that the next step overwrites).  The first step runs eagerly (it also sizes workspaces and sets kernel
-        attributes), the second is captured into a hipGraph, later steps replay it: ~340 launches become one."""
+        attributes), the second is captured into a hipGraph, later steps replay it: the step's launches (7 per layer with merged adapters: round 4) become one."""
         assert self.cur_len < self.Tmax, "generation budget exhausted"
         with ops.use_gemm_context(self.rt.gemm_ctx):
             return self._step(token_ids)
