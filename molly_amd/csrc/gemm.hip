@@ -2333,6 +2333,22 @@ int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, 
                 "gemm: operands must be 16-byte aligned");
     MOLLY_CHECK(!(flags & MOLLY_GEMM_BIAS) || bias, "gemm: MOLLY_GEMM_BIAS without bias pointer");
     MOLLY_CHECK(!(flags & MOLLY_GEMM_RESIDUAL) || (res && ldres % 4 == 0), "gemm: bad residual");
+    // ---- a grid a FEW 256 x 256 tiles past whole rounds of the chip (Qwen3-4B q | k | v at one sample per GPU: 3,072 x 6,144 x 2,560 = 288 tiles):
+    // the last tile columns are carved into a launch of their own (K-sliced by the rules below) and the rest is whole rounds — 102.6 us against 128.4 for
+    // stream-K on that shape (tools/r04/bench_cols_carve.py, profiles/r04_logs/cols_carve.log); every output column is still written by one launch
+    if (!(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD)) && M >= 256 && c.force_tile == 0) {
+        static const int carve = [] { const char* e = getenv("MOLLY_GEMM_CARVE"); return e ? atoi(e) : 1; }();
+        const long tm = cdiv(M, 256), tn = cdiv(N, 256), t = tm * tn, rem = t % 256;
+        const long cols = (rem + tm - 1) / tm;
+        if (carve && t > 256 && rem > 0 && rem <= 48 && cols < tn && N % 256 == 0) {
+            const int n0 = (int)(tn - cols) * 256;
+            const size_t esz = (flags & MOLLY_GEMM_OUT_F32) ? 4 : 2;
+            const char* Bs = (const char*)B + (bt ? (size_t)n0 : (size_t)n0 * ldb) * 2;
+            if (int rc = launch_gemm(ctx, stream, A, B, C, bias, res, M, n0, K, lda, ldb, ldc, ldres, flags, at, bt)) return rc;
+            return launch_gemm(ctx, stream, A, Bs, (char*)C + (size_t)n0 * esz, bias ? (const char*)bias + (size_t)n0 * 2 : nullptr,
+                               res ? (const char*)res + (size_t)n0 * 2 : nullptr, M, N - n0, K, lda, ldb, ldc, ldres, flags, at, bt);
+        }
+    }
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
     p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)res;

@@ -1147,3 +1147,29 @@ def test_argmax_rows_first_maximal_index(rows, V, ld):
     ref = x.cpu().numpy().argmax(-1)
     assert (got == ref).all(), (got, ref)
     assert got[0] == V // 3
+
+
+@pytest.mark.parametrize("M,N,K,kmajor_b", [(3072, 6144, 2560, False), (3072, 6144, 2560, True), (2816, 6400, 512, False)])
+def test_gemm_carves_the_tile_columns_past_whole_rounds(M, N, K, kmajor_b):
+    """A grid a few 256 x 256 tiles past whole rounds of the chip (Qwen3-4B q | k | v at one sample per GPU: 288 tiles) runs as two launches — whole
+    rounds + the last tile columns K-sliced (gemm.hip launch_gemm): exact on small integers with every epilogue, both B layouts, fp32 and bf16 outputs."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    ints = lambda *s: torch.randint(-3, 4, s, device="cuda", generator=g).to(BF)
+    x, w, bias, res = ints(M, K), ints(N, K), ints(N), ints(M, N)
+    ref = x.float() @ w.float().t()
+    b = w.t().contiguous() if kmajor_b else w
+    c = ops.GemmContext()
+    c.ensure_workspace(256 << 20)
+    with ops.use_gemm_context(c):
+        out = ops.gemm(x, b, out_dtype=torch.float32, b_kmajor=kmajor_b)
+        assert torch.equal(out, ref)
+        if K >= 2048:
+            assert c.get("last_config") // 1000 >= 2                   # the strip: K slices
+        out2 = ops.gemm(x, b, bias=bias, res=res, out_dtype=torch.float32, b_kmajor=kmajor_b)
+        assert torch.equal(out2, ref + bias.float() + res.float())
+        acc = torch.ones(M, N, dtype=torch.float32, device="cuda")
+        ops.gemm(x, b, out=acc, accumulate=True, b_kmajor=kmajor_b)
+        assert torch.equal(acc, ref + 1.0)
+        small = (x.float() * 0.25).to(BF)                              # bf16 output: values that stay exact
+        outb = ops.gemm(small, b, b_kmajor=kmajor_b)
+        assert torch.equal(outb.float(), (small.float() @ w.float().t()).to(BF).float())

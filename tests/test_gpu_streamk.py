@@ -70,7 +70,8 @@ def test_streamk_is_chosen_where_it_pays_and_only_there():
     g = torch.Generator(device="cuda").manual_seed(2)
     c = ops.GemmContext()
     c.ensure_workspace(1 << 30)
-    want = {(4096, 6144, 4096): True, (3072, 6144, 2560): True, (4096, 1280, 1280): False, (4096, 5120, 1280): False,
+    # (3,072 x 6,144 x 2,560 — 288 tiles, 32 past a round — was stream-K's until round 4 carved such remainders into a launch of their own)
+    want = {(4096, 6144, 4096): True, (3072, 6144, 2560): False, (4096, 1280, 1280): False, (4096, 5120, 1280): False,
             (16384, 4096, 2048): False}
     for (M, N, K), sk in want.items():
         a, b, _ = _operands("nt", M, N, K, g, ints=False)
