@@ -1536,7 +1536,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsArgs p) {
     };
     // s_waitcnt vmcnt(k * NLOAD): everything but the k youngest stages has landed (k = 0 .. NSTAGE - 2)
     auto wait_younger = [&](int k) {
-        if (k >= 2 && NSTAGE >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
+        if (NSTAGE >= 6 && k >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NLOAD) : "memory");
+        else if (NSTAGE >= 5 && k >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NLOAD) : "memory");
+        else if (NSTAGE >= 4 && k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
         else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -2240,7 +2242,9 @@ int launch_rows(GemmCtx& c, hipStream_t st, const void* A, const void* B, void* 
         }
         if (bn == 128) hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 128, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 128) * 64 * 2, st, q);
         else if (bn == 64) hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 64, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 64) * 64 * 2, st, q);
-        else hipLaunchKernelGGL((gemm_rows_kernel<2, 4, 32, true>), dim3(q.tiles_n), dim3(256), 4 * (32 + 32) * 64 * 2, st, q);
+        // (32-row tiles: a SIX-stage ring, 48 KB, still three workgroups per CU — 38.7 -> 37.3 us on Qwen3-8B's matrix against four stages; the 64-row
+        // K-sliced kernel measured within +-3 % at 4 / 6 / 8 stages and stays at four: profiles/r04_logs/rows_stages.log)
+        else hipLaunchKernelGGL((gemm_rows_kernel<2, 6, 32, true>), dim3(q.tiles_n), dim3(256), 6 * (32 + 32) * 64 * 2, st, q);
         c.last_cfg = 32 + 1000 + (bn == 32 ? 300 : 100 * (bn / 64));       // (one slice; + 100 / 200 / 300: the SwiGLU form at 64 / 128 / 32 W rows per tile)
         return 0;
     }
