@@ -308,9 +308,9 @@ void pick_shape(int B, int n_kv_heads, int len, bool have_ws, int* nw, int* spli
     // (16 waves at every batch: Qwen3-8B decode step, 3,100 keys, ms at 4 | 16 waves: B = 4 4.98 | 4.85, 8 5.33 | 5.18, 16 6.16 | 5.99, 24 6.62 | 6.01,
     // 28 7.02 | 6.32 — the 192 / 224 blocks of B = 24 / 28 leave CUs empty and still win; profiles/r04_logs/decode_nw.log)
     *nw = force_nw == 4 || force_nw == 16 ? force_nw : (len >= 512 ? 16 : 4);
-    if (*nw == 16 && (pairs >= 192 || !have_ws)) { *splits = 1; return; }
-    const int per = *nw == 16 ? 256 : target;
-    int sp = (per + pairs - 1) / pairs;
+    if (*nw == 16 && !have_ws) { *splits = 1; return; }
+    // (16-wave blocks: one per CU is resident, so never more than 256 of them — 160 pairs stay 160 blocks rather than 320 in two rounds)
+    int sp = *nw == 16 ? 256 / pairs : (target + pairs - 1) / pairs;
     sp = sp < 1 ? 1 : sp;
     if (sp > len / min_keys) sp = len / min_keys > 0 ? len / min_keys : 1;
     if (sp > MAX_SPLITS) sp = MAX_SPLITS;
