@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=3072)
     ap.add_argument("--k-protein", type=int, default=1024)
     ap.add_argument("--new", type=int, default=64)
+    ap.add_argument("--api", action="store_true", help="also time OmicsOne.generate(do_sample=True, ...) end to end")
     args = ap.parse_args()
     import molly_amd
     from molly_amd import config as C, ops
@@ -49,6 +50,19 @@ def main():
                "decode_ms_per_step": round(e1.elapsed_time(e2) / args.new, 3),
                "decode_tokens_per_s": round(B * args.new / e1.elapsed_time(e2) * 1e3, 1)}
         del sess
+    if args.api:
+        # the reference-facing call (OmicsOne.generate, reference src/model/omics_one.py:187-232) at the reference's inference settings
+        # (src/inference_lora.py:293-298), end to end: prefill + `new` sampled steps + everything the loop does on the host
+        import time
+        gen = torch.Generator(device="cpu").manual_seed(0)
+        kw = dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], omic_ids=b["omic_ids"], omic_info_list=b["omic_info_list"],
+                  max_new_tokens=args.new, do_sample=True, temperature=0.8, top_p=0.95, top_k=20, repetition_penalty=1.1, generator=gen)
+        m.generate(**kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = m.generate(**kw)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        res["api_sampled_total_ms"] = round((t1 - t0) * 1e3, 1)
+        res["api_sampled_ms_per_step_after_prefill"] = round(((t1 - t0) * 1e3 - res["prefill_ms"]) / out.shape[1], 3)
     n_par = sum(v.numel() for v in m._rt.base.views.values())
     res["weight_stream_GBps_decode"] = round(2 * n_par / (res["decode_ms_per_step"] * 1e-3) / 1e9, 1)
     print(json.dumps(res))
