@@ -509,6 +509,392 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
 
 // ================================================================================================
+// The forward as a SOFTWARE PIPELINE inside each wave (round 5; reference role: --attn_impl flash_attention_2, src/train.py:578-582).
+// Round 4's stamps (profiles/r04_logs/attn_stamp.log) showed a wave of attn_fwd_kernel running its half-step as a serial chain —
+// K fragment reads -> 8 S^T MFMAs -> softmax -> 8 P.V MFMAs, 2,078 cycles for 512 of MFMA — and a second wave per SIMD hiding 30 % of
+// it.  Here every consumer sits one phase behind its producer, so a wave's own matrix and vector instructions are independent and can
+// be interleaved in program order (an in-order wave overlaps nothing else):
+//   step s (32 keys), phase A:  S(s+1) = K(s+1) Q^T  [8 MFMAs]   beside   exp / row sum / pack of S(s) -> P(s);  V(s) fragment reads
+//                     phase B:  O^T += V(s)^T P(s)^T [8 MFMAs]   beside   row max of S(s+1), rescale decision;   K(s+2) fragment reads
+// S is double-buffered in registers (two named accumulators that swap roles every step).  The rare rescale (guide T13) is decided in
+// phase B from S(s+1) and applied after P.V(s) has been issued: O, l (which hold everything up to step s) are scaled once, P(s+1) is
+// then exponentiated against the new maximum.
+// K and V live in rings of their own: K(t+1) is first read in phase B of tile t's FIRST step and K(t) last read before tile t begins,
+// V(t) is read during tile t only — so ONE barrier per 64-key tile (between the phases of its second step) serves both with a K ring
+// of 3 tiles and a V ring of 2 (80 KiB): behind barrier Z_t the wave issues the LDS-DMA of K(t+3) and V(t+2), in front of Z_(t+1) it
+// waits for them.  NW = 4 (128 query rows, two workgroups per CU) or 8 (256 rows, one workgroup per CU, half the staging per wave).
+// Tiles whose two steps are interior for the wave (no mask, nothing past its causal diagonal) run the branch-free body; the first /
+// last tiles run the same phases under wave-uniform guards.
+template <int HD, int NW> struct PipeStage {
+    static constexpr int NP = BKV * HD * 2 / 1024 / NW;                 // 1-KiB LDS-DMA pieces per wave and tile: 4 (NW 4) / 2 (NW 8) at hd 128
+};
+template <int HD, int NW>
+__device__ __forceinline__ void pipe_lane_const(int wave, int lane, unsigned& row0, unsigned& colb) {
+    constexpr int NCB = HD / 16, NP = PipeStage<HD, NW>::NP;
+    const int P = wave * NP * 64 + lane;                  // piece 0 of this wave
+    const int blk = P >> 3, cin = P & 7;
+    const int rowblk = blk / NCB, cbs = blk % NCB;
+    const int b0 = rowblk & 1, b1 = (rowblk >> 1) & 1;
+    row0 = (unsigned)(rowblk * 4 + (cin >> 1));
+    colb = (unsigned)((((cbs ^ b0) << 4) + (((cin & 1) ^ b1) << 3)) * 2);
+}
+// hd 128 only: a piece = one 4-row block row of the image; piece i of wave w is instruction w * NP + i.  Rows past the end of the
+// sequence re-read row T - 1 (`last` = T - 1 - key0 >= 0; masked by index later): one v_min per piece, and no second code path.
+template <int HD, int NW>
+__device__ __forceinline__ void pipe_stage(const char* base, unsigned ldb, unsigned row0, unsigned colb, unsigned last, unsigned lds_addr, int wave) {
+    static_assert(HD == 128, "pipe_stage: hd 128");
+    constexpr int NP = PipeStage<HD, NW>::NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        // b0 = i & 1 always (w * NP is even); b1 = (i >> 1) & 1 when NP = 4 (w * NP a multiple of 4), a wave constant (in colb) when NP = 2
+        const unsigned cx = (unsigned)((((i & 1) << 4) ^ (NP == 4 ? (((i >> 1) & 1) << 3) : 0)) * 2);
+        const unsigned off = __umul24(min(row0 + 4u * i, last), ldb) + (colb ^ cx);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + (unsigned)((wave * NP + i) * 1024));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+    }
+}
+
+// one-instruction helpers (asm without `volatile`: pure, the scheduler may still move them inside their slot): a three-way
+// maximum on accumulator registers without hipcc's canonicalising v_max in front (the guide's 4-wave example notes the same)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#define SLOT_END() __builtin_amdgcn_sched_barrier(0)
+// MFMAs issued from asm with the register FILE of each operand chosen here.  With two waves per SIMD a wave has 256 registers, and
+// LLVM splits them 128 architected + 128 accumulation as soon as an `a` operand appears; left to itself at 256 architected registers
+// the allocator ping-ponged O between two register sets across the loop body's two steps (128 registers for 64) and spilled Q.
+// So everything that only MFMAs touch lives in the accumulation file — O^T (64), the Q fragments (32), and the K / V fragments on
+// their way from LDS to their MFMA (ds_read writes a-registers directly) — and the softmax's working set (S twice, P, the row
+// statistics) in the architected one.  hipcc does not see these as MFMAs, so the hazards its recognizer would pad are ours: a vector
+// instruction that reads an MFMA result needs the MFMA's passes + 3 wait states behind it — the fast path has >= 20 instructions
+// there by construction, the other paths call mfma_settle() — and back-to-back accumulation into the same registers is legal as is.
+#ifndef MOLLY_ATTN_PIPE_ASM_MFMA
+#define MOLLY_ATTN_PIPE_ASM_MFMA 0
+#endif
+#if MOLLY_ATTN_PIPE_ASM_MFMA
+__device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& bq) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(bq));
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& bq) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(bq));
+}
+#else
+__device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& bq) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, z, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& bq) {
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, d, 0, 0, 0);
+}
+#endif
+__device__ __forceinline__ void mfma_settle() {
+#if MOLLY_ATTN_PIPE_ASM_MFMA
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);        // [3 K tiles][3 V tiles]
+    constexpr int TILE = BKV * HD;
+    constexpr int NS = HD / 16, ND = HD / 32, BQW = NW * 32;
+    static_assert(NS == 8 && ND == 4, "attn_fwd_pipe_kernel: the slot schedule is written for hd 128");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);
+    const int qb = p.nblk - 1 - bi.blk;
+    const int b = bi.b, kvh = bi.kvh, head = kvh * (p.nh / p.nkv) + bi.g;
+    const int q0 = qb * BQW + wave * 32;
+    const int T = p.T;
+    // (readfirstlane: the loads are wave-uniform, but hipcc cannot prove it and would carry every loop counter that depends on them
+    // in vector registers)
+    const int lo = __builtin_amdgcn_readfirstlane(p.kv_lo ? p.kv_lo[b] : 0);
+    const int hi = __builtin_amdgcn_readfirstlane(p.kv_hi ? p.kv_hi[b] : T);
+    const bf16_t* Qb = p.Q + (size_t)b * T * p.ldq + head * HD;
+    const bf16_t* Kb = p.K + (size_t)b * T * p.ldk + kvh * HD;
+    const bf16_t* Vb = p.V + (size_t)b * T * p.ldv + kvh * HD;
+
+    bf16x8 qf[NS];
+    {
+        int qrow = q0 + r;
+        qrow = qrow < T ? qrow : T - 1;
+        const bf16_t* qp = Qb + (size_t)qrow * p.ldq + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) arrived(qf[s]);
+    }
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qi = q0 + r;
+
+    // tiles of the BLOCK [t_first, t_last]; steps (32 keys) of this WAVE [s_first, s_last]
+    const int blk_q_last = min(qb * BQW + BQW - 1, T - 1);
+    const int kv_end = p.causal ? min(blk_q_last + 1, hi) : hi;       // exclusive
+    const int t_first = lo / BKV;
+    const int t_last = kv_end > lo ? (kv_end - 1) / BKV : t_first - 1;
+    const int kv_end_w = p.causal ? min(q0 + 32, kv_end) : kv_end;
+    const int s_first = 2 * t_first;
+    const int s_last = kv_end_w > lo ? (kv_end_w - 1) / 32 : s_first - 1;
+
+    unsigned row0, colb;
+    pipe_lane_const<HD, NW>(wave, lane, row0, colb);
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));
+    // staging walks the rings with running slot counters (tiles are staged in order)
+    int kslot = 0, vslot = 0;
+    auto stage_k = [&](int t) {
+        const int key0 = t * BKV;
+        pipe_stage<HD, NW>(reinterpret_cast<const char*>(Kb + (size_t)key0 * p.ldk), (unsigned)p.ldk * 2u, row0, colb, (unsigned)(T - 1 - key0),
+                           smem_lds + (unsigned)(kslot * TILE * 2), wave);
+        kslot = kslot == 2 ? 0 : kslot + 1;
+    };
+    auto stage_v = [&](int t) {
+        const int key0 = t * BKV;
+        pipe_stage<HD, NW>(reinterpret_cast<const char*>(Vb + (size_t)key0 * p.ldv), (unsigned)p.ldv * 2u, row0, colb, (unsigned)(T - 1 - key0),
+                           smem_lds + (unsigned)((3 + vslot) * TILE * 2), wave);
+        vslot = vslot == 2 ? 0 : vslot + 1;
+    };
+    // barrier Z_t (between the phases of tile t's second step) and the staging behind it: K(t+3) into K(t)'s slot, V(t+2) into V(t-1)'s
+    auto tile_barrier = [&](int t) {
+        // own LDS-DMA pieces landed AND own fragment reads returned (the slots behind the barrier are overwritten by other waves' DMA)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 3 <= t_last) stage_k(t + 3);
+        if (t + 2 <= t_last) stage_v(t + 2);
+    };
+
+    // ---- shared state of the phases
+    bf16x8 kpre0, kpre1;              // fast path: fragments 0, 1 of the K half whose S^T comes next (read at the end of the phase before)
+    bf16x8 p0, p1;                    // P^T of the step whose P.V comes next
+    float m_new = 0.f;                // pending rescale (valid when `resc`)
+    bool resc = false;
+    int ks = 0, vs = 0;               // ring slots of the CURRENT tile's K and V (advance per tile)
+    auto k_tile = [&](int slot) { return smem + slot * TILE; };
+    auto v_tile = [&](int slot) { return smem + (3 + slot) * TILE; };
+    auto nxt3 = [](int x) { return x == 2 ? 0 : x + 1; };
+
+    // ---- unsliced pieces (prologue and the guarded steps): fragments read where they are used, two MFMAs per scheduling region
+    auto qk = [&](f32x16& sc, const bf16_t* sK, int sub) {      // (the caller settles before vector instructions read sc)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const bf16x8 f = row_frag<HD>(sK, 32 * sub + r, i, h);
+            if (i == 0) mfma_s0(sc, f, qf[0]); else mfma_s(sc, f, qf[i]);
+            if (i & 1) SLOT_END();
+        }
+    };
+    auto pv = [&](const bf16_t* sV, int sub) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            mfma_o(o[d], tr_frag<HD>(sV, 32 * sub, 0, d, lane), p0);
+            mfma_o(o[d], tr_frag<HD>(sV, 32 * sub, 1, d, lane), p1);
+            SLOT_END();
+        }
+    };
+    // row max of S(s) (masked where the step touches the diagonal or a range edge) and the rescale decision
+    auto start = [&](f32x16& sc, int s, auto MASKED) {
+        const int kbase = 32 * s;
+        float mx;
+        if (MASKED) {
+            mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
+                sc[e] = ok ? sc[e] : -INFINITY;
+                mx = fmaxf(mx, sc[e]);
+            }
+        } else {
+            mx = vmax2(vmax3(vmax3(sc[0], sc[1], sc[2]), vmax3(sc[3], sc[4], sc[5]), vmax3(sc[6], sc[7], sc[8])),
+                       vmax3(vmax3(sc[9], sc[10], sc[11]), vmax3(sc[12], sc[13], sc[14]), sc[15]));
+        }
+        mx = xhalf_max(mx) * p.scale_log2;
+        resc = !__all(mx - m_run <= RESCALE_THR);
+        m_new = fmaxf(m_run, mx);
+    };
+    auto apply_rescale = [&]() {      // after P.V of the step before has been issued: everything at the old maximum is scaled once
+        if (resc) {
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - m_use);               // m_run = -inf -> 0
+            l_run *= alpha;
+            m_run = m_new;
+            mfma_settle();                                              // the P.V MFMAs just issued write o (asm: no hazard padding by hipcc)
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+            mfma_settle();                                              // ... and the next MFMA reads what these moves write
+            resc = false;
+        }
+    };
+    // P(s) = 2^(scale S - m), row sum, bf16 fragments
+    auto finish = [&](f32x16& sc) {
+        const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = fast_exp2(sc[e] * p.scale_log2 - m_ref);
+        float rs[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) rs[g4] = (sc[4 * g4] + sc[4 * g4 + 1]) + (sc[4 * g4 + 2] + sc[4 * g4 + 3]);
+        l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);
+        p0 = acc_to_frag(sc, 0);
+        p1 = acc_to_frag(sc, 8);
+        asm volatile("" ::"v"(p0), "v"(p1), "v"(l_run));
+    };
+    auto need_mask = [&](int s) { return (p.causal && 32 * s + 31 > q0) || 32 * s < lo || 32 * s + 32 > hi; };
+
+    // ---- prologue: K(t0), V(t0), K(t0+1) -> barrier -> K(t0+2), V(t0+1) behind it
+    if (t_last >= t_first) {
+        stage_k(t_first);
+        stage_v(t_first);
+        if (t_first + 1 <= t_last) stage_k(t_first + 1);
+    }
+    dma_wait();
+    __syncthreads();
+    if (t_first + 2 <= t_last) stage_k(t_first + 2);
+    if (t_first + 1 <= t_last) stage_v(t_first + 1);
+
+    f32x16 sX, sY;                    // S of the current / the next step; the roles swap every step
+    if (s_last >= s_first) {
+        qk(sX, k_tile(0), 0);
+        mfma_settle();
+        if (need_mask(s_first)) start(sX, s_first, std::true_type{}); else start(sX, s_first, std::false_type{});
+        apply_rescale();
+    }
+
+    // one step under wave-uniform guards (first / last tiles of the wave, and its idle tiles behind the causal diagonal).
+    // Step s = (tile t, half sub); K(s+1) = tile t's half 1 (sub 0) or tile t+1's half 0 (sub 1).
+    auto step_guarded = [&](f32x16& cur, f32x16& nxt, int s) {
+        const int sub = s & 1;
+        const bool a_cur = s <= s_last, a_nxt = s + 1 <= s_last;
+        if (a_nxt) qk(nxt, sub ? k_tile(nxt3(ks)) : k_tile(ks), sub ^ 1);
+        if (a_cur) finish(cur);
+        if (sub) tile_barrier(s >> 1);
+        if (a_cur) pv(v_tile(vs), sub);
+        if (a_nxt) {
+            mfma_settle();                                              // S(s+1) is read by vector instructions next
+            if (need_mask(s + 1)) start(nxt, s + 1, std::true_type{}); else start(nxt, s + 1, std::false_type{});
+            apply_rescale();
+        }
+    };
+
+    // the branch-free step, placed by hand: 8 MFMA slots per phase, each closed by a sched_barrier so that hipcc keeps what was put
+    // beside each MFMA there (fragment reads two slots ahead of their MFMA, the softmax in slices)
+    auto step_fast = [&](f32x16& cur, f32x16& nxt, int s, auto SUB) {
+        constexpr int sub = decltype(SUB)::value;
+        // ---- phase A: S(s+1) = K(s+1) Q^T beside P(s) = 2^(scale S(s) - m)
+        const bf16_t* sKa = sub ? k_tile(nxt3(ks)) : k_tile(ks);           // K(s+1): tile t half 1 | tile t+1 half 0
+        constexpr int suba = sub ^ 1;
+        const bf16_t* sV = v_tile(vs);
+        const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
+        float tot = 0.f;
+        u32x4 w0, w1;
+        bf16x8 kfr[NS];
+        bf16x8 vfr[2 * ND];                                                // V^T fragments by P.V slot j = 2 d + sp
+        kfr[0] = kpre0;
+        kfr[1] = kpre1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (i + 2 < NS) kfr[i + 2] = row_frag<HD>(sKa, 32 * suba + r, i + 2, h);
+            else vfr[i + 2 - NS] = tr_frag<HD>(sV, 32 * sub, (i + 2 - NS) & 1, (i + 2 - NS) >> 1, lane);
+            if (i == 0) mfma_s0(nxt, kfr[0], qf[0]); else mfma_s(nxt, kfr[i], qf[i]);
+            cur[2 * i] = fast_exp2(cur[2 * i] * p.scale_log2 - m_ref);
+            cur[2 * i + 1] = fast_exp2(cur[2 * i + 1] * p.scale_log2 - m_ref);
+            if (i > 0) {
+                const int j = i - 1;
+                tot += cur[2 * j] + cur[2 * j + 1];
+                const unsigned pk = pack_bf2(cur[2 * j], cur[2 * j + 1]);
+                if (j < 4) w0[j] = pk; else w1[j - 4] = pk;
+            }
+            SLOT_END();
+        }
+        tot += cur[14] + cur[15];
+        w1[3] = pack_bf2(cur[14], cur[15]);
+        l_run += tot;
+        p0 = __builtin_bit_cast(bf16x8, w0);
+        p1 = __builtin_bit_cast(bf16x8, w1);
+        // "used here": without it LLVM sinks the whole exp / sum / pack chain below the barrier's branches to its first real use,
+        // i.e. out from beside the S^T MFMAs and in front of the P.V MFMAs that wait for it
+        asm volatile("" ::"v"(p0), "v"(p1), "v"(l_run));
+        SLOT_END();
+        if (sub) tile_barrier(s >> 1);
+        SLOT_END();
+        // ---- phase B: O^T += V(s)^T P(s)^T beside the row max of S(s+1); K(s+2) = tile t+1's half `sub`: fragments 0, 1 prefetched
+        const bf16_t* sKb = k_tile(nxt3(ks));
+        float ma = 0.f, mb = 0.f, mc = 0.f, md = 0.f, me = 0.f, mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2 * ND; ++j) {
+            if (j + 2 < 2 * ND) vfr[j + 2] = tr_frag<HD>(sV, 32 * sub, (j + 2) & 1, (j + 2) >> 1, lane);
+            else if (j == 6) kpre0 = row_frag<HD>(sKb, 32 * sub + r, 0, h);
+            else kpre1 = row_frag<HD>(sKb, 32 * sub + r, 1, h);
+            mfma_o(o[j >> 1], vfr[j], (j & 1) ? p1 : p0);
+            // S(s+1) is complete one MFMA latency behind phase A's last MFMA: nothing reads it in slots 0, 1
+            if (j == 2) { ma = vmax3(nxt[0], nxt[1], nxt[2]); mb = vmax3(nxt[3], nxt[4], nxt[5]); }
+            if (j == 3) { mc = vmax3(nxt[6], nxt[7], nxt[8]); md = vmax3(nxt[9], nxt[10], nxt[11]); }
+            if (j == 4) { me = vmax3(nxt[12], nxt[13], nxt[14]); ma = vmax3(ma, mb, mc); }
+            if (j == 5) { md = vmax3(md, me, nxt[15]); mx = vmax2(ma, md); }
+            if (j == 6) { mx = xhalf_max(mx) * p.scale_log2; }
+            if (j == 7) { resc = !__all(mx - m_run <= RESCALE_THR); m_new = fmaxf(m_run, mx); }
+            SLOT_END();
+        }
+        apply_rescale();
+        SLOT_END();
+    };
+    // interior for this wave: steps 2t, 2t+1 with S(2t+1), S(2t+2) unmasked and K(2t+3) still wanted
+    auto is_fast = [&](int t) { return 2 * t + 3 <= s_last && !need_mask(2 * t + 1) && !need_mask(2 * t + 2); };
+
+    // ONE loop over the tiles with the two bodies as the arms of a branch: guarded tiles (a range that starts inside a tile, the wave's
+    // causal diagonal, its idle tiles up to the block's last) and interior ones.  (Loops per kind — in sequence, or nested in an outer
+    // one — made hipcc keep a second copy of O and S, 96 registers, alive across the fast loop and spill Q into its MFMA slots.)
+    bool prev_fast = false;
+    for (int t = t_first; t <= t_last; ++t) {
+        if (is_fast(t)) {
+            if (!prev_fast) {         // entering a fast run at step 2t: fragments 0, 1 of K(2t+1) = tile t's half 1
+                kpre0 = row_frag<HD>(k_tile(ks), 32 + r, 0, h);
+                kpre1 = row_frag<HD>(k_tile(ks), 32 + r, 1, h);
+            }
+            step_fast(sX, sY, 2 * t, std::false_type{});
+            step_fast(sY, sX, 2 * t + 1, std::true_type{});
+            prev_fast = true;
+        } else {
+            step_guarded(sX, sY, 2 * t);
+            step_guarded(sY, sX, 2 * t + 1);
+            prev_fast = false;
+        }
+        ks = nxt3(ks);
+        vs = nxt3(vs);
+    }
+
+    // ---- epilogue: O[q][d] = o / l ; LSE2 = m + log2(l).  No wave reads K / V fragments behind the last tile barrier, so the slabs
+    // may overwrite the rings.
+    mfma_settle();
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    store_rows<HD, ND>(smem + wave * 32 * (HD + 8), o, inv, p.O + ((size_t)b * T + q0) * p.ldo + head * HD, p.ldo, T - q0, lane);
+    if (qi < T && p.LSE && h == 0)
+        p.LSE[((size_t)b * p.nh + head) * T + qi] = l_tot > 0.f ? m_run + log2f(l_tot) : -INFINITY;
+}
+
+// ================================================================================================
 // Small head dims (8 <= hd <= 64, hd % 8 == 0, not 64): the mini encoders of the reference's plumbing config (ESM2-t6-8M:
 // 320 hidden / 20 heads = 16).  Forward only, plain VALU: one thread per query row, K/V tiles of 64 keys staged in LDS as
 // fp32 (every thread reads the same key row: LDS broadcast), online softmax in the exp2 domain.  Not a performance path.
@@ -977,6 +1363,26 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
 #undef MOLLY_SMALL
         MOLLY_LAUNCH_CHECK();
         return 0;
+    }
+    // MOLLY_ATTN_FWD_PIPE = 4 | 8: the software-pipelined forward (attn_fwd_pipe_kernel) with that many waves per workgroup; 0: attn_fwd_kernel
+    {
+        const char* e = getenv("MOLLY_ATTN_FWD_PIPE");
+        const int nw = e ? atoi(e) : 0;
+        if (head_dim == 128 && (nw == 4 || nw == 8)) {
+            static bool pipe_attr = false;
+            if (!pipe_attr) {
+                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
+                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
+                pipe_attr = true;
+            }
+            p.nblk = cdiv(T, nw * 32);
+            const dim3 gp(n_heads * B * p.nblk);
+            const size_t ldsp = 6 * BKV * 128 * sizeof(bf16_t);
+            if (nw == 4) hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 4>), gp, dim3(256), ldsp, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 8>), gp, dim3(512), ldsp, (hipStream_t)stream, p);
+            MOLLY_LAUNCH_CHECK();
+            return 0;
+        }
     }
     dim3 grid(n_heads * B * cdiv(T, BQ));                  // 1-D: block_item() decodes it
     // MOLLY_ATTN_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, e.g. 40960 leaves room for ONE workgroup per CU — what the
