@@ -395,6 +395,10 @@ def main(argv=None):
     ap.add_argument("--rs-algo", choices=("rccl", "a2a"), default=None,
                     help="gradient reduce-scatter: the library's collective (default) or all_to_all_single + a local fp32 reduction "
                          "in rank order (SURVEY 5 option 2: every xGMI link carries one chunk at once, whatever RCCL would pick)")
+    ap.add_argument("--bucket-ab-steps", type=int, default=2,
+                    help="N > 1, neither --bucket-mib nor --rs-algo pinned: timed steps per (bucket size, reduce-scatter algorithm) candidate "
+                         "of the sweep before the warm-up (untimed region; the fastest is kept, the table lands in comm.bucket_ab); 0 = off")
+    ap.add_argument("--bucket-ab-mib", default="64,128,256,512,1024", help="bucket sizes (MiB of bf16) the sweep tries")
     ap.add_argument("--exposed-comm-steps", type=int, default=4,
                     help="N>1: extra steps after the timed region with the exchange NOT overlapped, to report the exposed "
                          "communication time (0 = skip)")
@@ -446,11 +450,26 @@ def main(argv=None):
     import datetime
     import torch.distributed as dist
     backend = None
+    def bring_up_failed(stage, e):
+        """A communication bring-up that fails ends the run HERE, from a fresh state: one JSON line with the error (rank 0), exit code 3.
+        Nothing is retried from this process — it has initialised the GPU, and re-exec'ing such a process takes the box down."""
+        if rank == 0:
+            print(json.dumps({"metric": f"training tokens/sec Molly-{args.model.upper()} bf16", "value": None, "unit": "tokens/s",
+                              "n_gpus": world, "error": f"{stage}: {type(e).__name__}: {str(e)[:500]}",
+                              "env": {k: os.environ[k] for k in ("MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")
+                                      if k in os.environ}}), flush=True)
+        sys.stderr.write(f"[bench rank {rank}] {stage} failed: {e!r}\n")
+        sys.stderr.flush()
+        os._exit(3)
+
     if world > 1:
         backend = os.environ.get("MOLLY_DIST_BACKEND", "nccl")
         # reference: src/train.py:606-610 (nccl, device_id, 30 min timeout)
-        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=30),
-                                **({"device_id": dev} if backend == "nccl" else {}))
+        try:
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=30),
+                                    **({"device_id": dev} if backend == "nccl" else {}))
+        except Exception as e:              # noqa: BLE001
+            bring_up_failed("init_process_group", e)
 
     def barrier():
         if world > 1:
@@ -462,7 +481,12 @@ def main(argv=None):
     from molly_amd.trainer import Zero2Optimizer
     from molly_amd.trainer.zero2 import preflight_collectives
 
-    comm_check = preflight_collectives(dev) if world > 1 else None   # tiny in-place RS/AG/AR with known answers: fail fast
+    comm_check = None
+    if world > 1:                            # tiny in-place RS/AG/AR with known answers: fail fast
+        try:
+            comm_check = preflight_collectives(dev)
+        except Exception as e:              # noqa: BLE001
+            bring_up_failed("preflight_collectives", e)
 
     micro = parse_micro(args.micro or f"protein:{args.k_protein}")
     GA = len(micro)
@@ -479,12 +503,15 @@ def main(argv=None):
         m.prepare(dev, random_init_seed=1234, train_llm=False, train_mlp=True,
                   lora=LoraConfig(r=64, lora_alpha=64, lora_dropout=0.05, seed=42) if args.train_mode == "lora" else None)
     rt = m._rt
-    opt_kw = {}
-    if args.bucket_mib > 0:
-        opt_kw["chunk_elems"] = max(8, int(args.bucket_mib * (1 << 20) / 2 / world) // 8 * 8)
-    opt = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0,
-                         stage=args.zero_stage, rs_algo=args.rs_algo, **opt_kw)
-    m.attach_optimizer(opt)
+    def make_opt(bucket_mib, rs_algo):
+        kw = {}
+        if bucket_mib and bucket_mib > 0:
+            kw["chunk_elems"] = max(8, int(bucket_mib * (1 << 20) / 2 / world) // 8 * 8)
+        o = Zero2Optimizer(rt.P.flat, rt.G.flat, m.n_decay, lr=3e-5, weight_decay=1e-2, max_grad_norm=1.0,
+                           stage=args.zero_stage, rs_algo=rs_algo, **kw)
+        m.attach_optimizer(o)
+        return o
+    opt = make_opt(args.bucket_mib, args.rs_algo)
 
     B, T, K = args.batch, args.seq, args.k_protein
     # 4 different steps' worth of data; a step = GA micro-batches (gradients summed over the window, one optimizer step)
@@ -519,6 +546,36 @@ def main(argv=None):
     # themselves before the warm-up (untimed region): one settling step + `--gemm-mode-ab-steps` timed steps per shape, max over
     # ranks, the fastest kept for the timed region.  Every shape computes bit-identical results (tests/test_gpu_dynamic_fetch.py),
     # so the choice is speed only.  MOLLY_GEMM_PERSISTENT_MULTI pins one shape and skips this.
+    # ---- N > 1: bucket size x reduce-scatter algorithm, measured on the job's own ranks before the warm-up (untimed region).  The
+    # reference's ds_z2_config.json:18-27 fixes both bucket sizes at 5e8 elements; xGMI is 7 point-to-point links per GPU, so what a
+    # bucket costs depends on how the library's algorithm spreads it over them — tuned HERE rather than guessed: every candidate
+    # rebuilds the optimizer with its layout (the fp32 masters restart from the current bf16 parameters — synthetic run, untimed
+    # region), runs one settling step + `--bucket-ab-steps` timed steps, the slowest rank's time counts, the fastest layout is kept.
+    bucket_ab = None
+    if (world > 1 and args.zero_stage == 2 and args.bucket_ab_steps > 0 and args.bucket_mib <= 0 and args.rs_algo is None
+            and "MOLLY_RS_ALGO" not in os.environ):
+        from molly_amd.trainer.zero2 import sweep_exchange
+        total_mib = rt.P.flat.numel() * 2 / (1 << 20)
+        sizes = sorted({min(float(x), total_mib) for x in args.bucket_ab_mib.split(",") if x.strip()})
+
+        def measure(mib, algo):
+            nonlocal opt
+            opt = None
+            m._rt.opt = None
+            torch.cuda.empty_cache()
+            opt = make_opt(mib, algo)
+            step(0)
+            dtm, _, _ = timed_steps(args.bucket_ab_steps, 1)
+            tm = torch.tensor([dtm], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            return float(tm.item()) / args.bucket_ab_steps * 1e3
+        bucket_ab = sweep_exchange([(mib, algo) for algo in ("rccl", "a2a") for mib in sizes], measure, args.bucket_ab_steps)
+        ch = bucket_ab["chosen"]
+        opt = None
+        m._rt.opt = None
+        torch.cuda.empty_cache()
+        opt = make_opt(ch["bucket_mib"], ch["rs_algo"])
+
     gemm_mode_ab = None
     if world > 1 and opt.overlap and args.gemm_mode_ab_steps > 0 and "MOLLY_GEMM_PERSISTENT_MULTI" not in os.environ:
         gemm_mode_ab = {}
@@ -573,7 +630,7 @@ def main(argv=None):
                 # own behaviour with bf16 gradients); the all-to-all variant sums the `world` copies in fp32 on the owner, once
                 "reduce_dtype": ("fp32 on the owning rank, rank order, one rounding (all_to_all + molly_reduce_rows)"
                                  if opt.rs_algo == "a2a" else "bf16 in the collective (RCCL reduce_scatter: one rounding per hop)"),
-                "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256), "gemm_mode_ab": gemm_mode_ab,
+                "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256), "gemm_mode_ab": gemm_mode_ab, "bucket_ab": bucket_ab,
                 # per bucket, HIP events on the communication stream around each collective of the timed region (overlapped: the
                 # time includes waiting for CUs beside the backward); us_per_bucket = the first timed step's buckets in launch order
                 "timings_us": comm_timings}
@@ -599,6 +656,17 @@ def main(argv=None):
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             comm["step_ms_p50_no_overlap"] = round(statistics.median(ms2), 2)
             comm["exposed_comm_ms_removed_by_overlap"] = round(statistics.median(ms2) - statistics.median(step_ms), 2)
+            # what the overlap does NOT hide, for the layout the timed region ran: the same steps with every collective a no-op
+            # (measurement only, last thing this process does with the optimizer: the replicas diverge from here on)
+            from molly_amd.trainer.zero2 import _NullComm
+            real_comm, opt.comm = opt.comm, _NullComm()
+            step(0)
+            dt3, ms3, _ = timed_steps(args.exposed_comm_steps, 1)
+            opt.comm = real_comm
+            t3 = torch.tensor([statistics.median(ms3)], device=dev, dtype=torch.float64)
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            comm["step_ms_p50_no_exchange"] = round(float(t3.item()), 2)
+            comm["exposed_comm_ms"] = round(statistics.median(step_ms) - float(t3.item()), 2)
 
     if rank == 0:
         tokens = world * B * T * GA * args.steps
@@ -686,6 +754,9 @@ def main(argv=None):
                        "note": "prompt = 75% of each sample with labels -100 (SURVEY 8d); lm_head+CE run on the scored rows only "
                                "(identical loss/gradients).  executed_* count the FLOPs the kernels ran; model_* credit the full "
                                "algorithmic count of SURVEY 8d (lm_head on every row)"},
+            # rounds 1-3 quoted this workload at 8 samples per GPU: the like-for-like figure of THIS process at that batch (also kept in
+            # config.batch8_reference), first-class so that round-over-round tracking does not depend on the default batch
+            "batch8_reference": batch8,
             "step_ms_p50": round(statistics.median(step_ms), 2),
             "step_ms": [round(x, 1) for x in step_ms],      # per step, HIP events (ms_per_step is the wall clock over all of them / steps)
             # THE step fraction: FLOPs the kernels executed / step time / dense bf16 MFMA peak

@@ -1,12 +1,13 @@
-"""Beam search (and beam sampling) for `OmicsOne.generate(num_beams > 1)`.
+"""Beam search (and beam sampling): an EXTENSION of this build, reached through `OmicsOne.generate(molly_num_beams=N)`.
 
-The reference forwards `num_beams` to HuggingFace's `generate` (reference src/model/omics_one.py:199-200, 227: `self.model.generate(
-inputs_embeds=..., num_beams=num_beams, ...)`), i.e. to `GenerationMixin._beam_search` (HF:generation/utils.py) with an EMPTY
-`input_ids` (only `inputs_embeds` is passed), so the decoder prompt length is 0 and every length in the scorer counts generated tokens
-only.  This module restates that procedure over two callbacks — "logits of the next position for these B * num_beams rows" and
-"reorder the rows' KV cache" — so that the same code runs on the HIP decode session (molly_amd/generate.py) and, in the CPU test,
-on HuggingFace's own model, where its output is compared token for token with `hf_model.generate(num_beams=...)`
-(tests/test_beam_search.py).
+The reference's `OmicsOne.generate` has a `num_beams` parameter but never forwards it (src/model/omics_one.py:199, 220-232: the call of
+`self.model.generate` passes do_sample / temperature / top_p / top_k / no_repeat_ngram_size / pad / eos / **generate_kwargs), so beam
+search is not reachable through the reference's own API; molly_amd's `num_beams` is ignored in the same way.  What this module
+restates is HuggingFace's `GenerationMixin._beam_search` (HF:generation/utils.py) as it runs when `generate` is given
+`inputs_embeds` only — an EMPTY `input_ids`, so the decoder prompt length is 0 and every length in the scorer counts generated tokens
+only — over two callbacks, "logits of the next position for these B * num_beams rows" and "reorder the rows' KV cache", so that the
+same code runs on the HIP decode session (molly_amd/generate.py) and, in the CPU test, on HuggingFace's own model, where its output is
+compared token for token with `hf_model.generate(num_beams=...)` (tests/test_beam_search.py).
 
 Procedure (one step, per batch row):
   1. log-softmax of the logits (fp32), logits processors applied to the LOG-PROBABILITIES (HF's order in beam mode), plus the
@@ -55,7 +56,7 @@ def beam_search(first_logits: torch.Tensor, step: Callable[[torch.Tensor], torch
     eos = torch.as_tensor(list(eos_token_id), device=dev, dtype=torch.int64) if eos_token_id is not None and len(eos_token_id) else None
     n_eos = 0 if eos is None else int(eos.numel())
     K = max(2, 1 + n_eos) * nb
-    fill = pad_token_id if pad_token_id else (int(eos[0]) if eos is not None else -1)      # HF: `pad_token_id or eos_token_id[0]`
+    fill = pad_token_id if pad_token_id is not None else (int(eos[0]) if eos is not None else -1)      # HF falls back to eos[0] only when pad is None (0 is a valid pad id)
     in_top = torch.zeros(K, dtype=torch.bool, device=dev)
     in_top[:nb] = True
 

@@ -35,6 +35,9 @@ struct AttnArgs {
     int causal;
     int nblk, order_set;                     // block order (block_item): query blocks per head, (batch, kv head) pairs walked together
     int prio;                                // wave_priority(): 0 none, n: the odd wave slot of every SIMD runs at priority n
+    int stagger;                             // attn_fwd_pipe_kernel: waves 4-7 one step behind waves 0-3 (MOLLY_ATTN_PIPE_STAGGER, default 1)
+    int* redo;                               // fixed-reference forward (QB 2): *redo = seq when some row's maximum outgrew its reference;
+    int seq;                                 // attn_fwd_kernel launched behind it returns at once unless *redo == seq (nullptr: always runs)
 };
 
 // One LDS image serves row reads (ds_read_b128: tile row on the lane) AND transposed reads (ds_read_b64_tr_b16: tile
@@ -206,6 +209,11 @@ __device__ unsigned long long g_attn_stamp[32768 * 4 * 8];
 #ifndef MOLLY_ATTN_ROWS_VIA_LDS
 #define MOLLY_ATTN_ROWS_VIA_LDS 1
 #endif
+// timing-only builds of attn_fwd_kernel (wrong results; tools/r05/attn_issue_diag.sh): 1 no row sum, 2 a multiply in place of every exp2,
+// 4 neither fma nor exp2, 8 no LDS-DMA behind the first two tiles, 16 no tile barrier
+#ifndef MOLLY_ATTN_DIAG
+#define MOLLY_ATTN_DIAG 0
+#endif
 template <int HD, int ND>
 __device__ __forceinline__ void store_rows(bf16_t* slab, const f32x16 (&acc)[ND], float mul, bf16_t* dst, size_t ld, int rows_valid,
                                            int lane) {
@@ -312,6 +320,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // launched as the fall-back behind the fixed-reference kernel: nothing to do unless that kernel asked for it
+    if (p.redo && __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != p.seq) return;
     wave_priority(p.prio);
     // 1-D grid, XCD-aware item order (block_item); within a pair the heaviest causal blocks (largest query index) start first
     const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);
@@ -414,15 +424,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         }
         const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sc[e] = fast_exp2(sc[e] * p.scale_log2 - m_ref);       // one fma + one exp2 per score
+        for (int e = 0; e < 16; ++e) {
+            if (MOLLY_ATTN_DIAG == 4) sc[e] = sc[e] * m_ref;
+            else if (MOLLY_ATTN_DIAG & 2) sc[e] = (sc[e] * p.scale_log2 - m_ref) * m_ref;
+            else sc[e] = fast_exp2(sc[e] * p.scale_log2 - m_ref);       // one fma + one exp2 per score
+        }
         // (tried, round 4: the fma and the row sum as packed fp32 — v_pk_fma_f32 / v_pk_add_f32, two scores per instruction, 15 % fewer
         // vector instructions in this loop: 164.0-164.9 us against 162.0-162.3 at B8 T2048 H16 D128, the backward unchanged too —
         // these loops are not bound by vector-instruction throughput: profiles/r04_logs/attn_pk.log)
         // row sum as a tree (a 16-deep dependent add chain would serialise on the add latency)
         float rs[4];
+        if (MOLLY_ATTN_DIAG & 1) { l_run += sc[0]; } else {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) rs[g4] = (sc[4 * g4] + sc[4 * g4 + 1]) + (sc[4 * g4 + 2] + sc[4 * g4 + 3]);
         l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);                                                    // per-half-wave partial; merged at the end
+        }
         const bf16x8 p0 = acc_to_frag(sc, 0), p1 = acc_to_frag(sc, 8);
 #if MOLLY_ATTN_STAMP
         asm volatile("" ::"v"(p0), "v"(p1));
@@ -465,7 +481,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     for (int t = t_first; t <= t_last; ++t) {
         const bf16_t* sK = smem + cur * 2 * TILE;
         const bf16_t* sV = sK + TILE;
-        if (t + 1 <= t_last) stage_tile(t + 1, cur ^ 1);
+        // (MOLLY_ATTN_DIAG & 8, timing only: no LDS-DMA behind the first two tiles — what does the staging's ISSUE cost?
+        //  & 16: no tile barrier either)
+        if (t + 1 <= t_last && !((MOLLY_ATTN_DIAG & 8) && t > t_first)) stage_tile(t + 1, cur ^ 1);
         const int k0 = t * BKV;
         if (t <= tw_last) {
 #pragma unroll
@@ -484,8 +502,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             }
         }
         ALAP(0);
+        if (!(MOLLY_ATTN_DIAG & 16)) {
         dma_wait();
         __syncthreads();
+        }
         ALAP(4);                                          // wait for the next tile + the workgroup barrier
         cur ^= 1;
     }
@@ -541,17 +561,20 @@ __device__ __forceinline__ void pipe_lane_const(int wave, int lane, unsigned& ro
 // hd 128 only: a piece = one 4-row block row of the image; piece i of wave w is instruction w * NP + i.  Rows past the end of the
 // sequence re-read row T - 1 (`last` = T - 1 - key0 >= 0; masked by index later): one v_min per piece, and no second code path.
 template <int HD, int NW>
-__device__ __forceinline__ void pipe_stage(const char* base, unsigned ldb, unsigned row0, unsigned colb, unsigned last, unsigned lds_addr, int wave) {
+__device__ __forceinline__ void pipe_stage_piece(int i, const char* base, unsigned ldb, unsigned row0, unsigned colb, unsigned last, unsigned lds_addr, int wave) {
     static_assert(HD == 128, "pipe_stage: hd 128");
     constexpr int NP = PipeStage<HD, NW>::NP;
+    // b0 = i & 1 always (w * NP is even); b1 = (i >> 1) & 1 when NP = 4 (w * NP a multiple of 4), a wave constant (in colb) when NP = 2
+    const unsigned cx = (unsigned)((((i & 1) << 4) ^ (NP == 4 ? (((i >> 1) & 1) << 3) : 0)) * 2);
+    const unsigned off = __umul24(min(row0 + 4u * i, last), ldb) + (colb ^ cx);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + (unsigned)((wave * NP + i) * 1024));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
+}
+template <int HD, int NW>
+__device__ __forceinline__ void pipe_stage(const char* base, unsigned ldb, unsigned row0, unsigned colb, unsigned last, unsigned lds_addr, int wave) {
+    constexpr int NP = PipeStage<HD, NW>::NP;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        // b0 = i & 1 always (w * NP is even); b1 = (i >> 1) & 1 when NP = 4 (w * NP a multiple of 4), a wave constant (in colb) when NP = 2
-        const unsigned cx = (unsigned)((((i & 1) << 4) ^ (NP == 4 ? (((i >> 1) & 1) << 3) : 0)) * 2);
-        const unsigned off = __umul24(min(row0 + 4u * i, last), ldb) + (colb ^ cx);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + (unsigned)((wave * NP + i) * 1024));
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
-    }
+    for (int i = 0; i < NP; ++i) pipe_stage_piece<HD, NW>(i, base, ldb, row0, colb, last, lds_addr, wave);
 }
 
 // one-instruction helpers (asm without `volatile`: pure, the scheduler may still move them inside their slot): a three-way
@@ -567,6 +590,16 @@ __device__ __forceinline__ float vmax2(float a, float b) {
     return d;
 }
 #define SLOT_END() __builtin_amdgcn_sched_barrier(0)
+// fragment reads run this many MFMA slots ahead of the MFMA that consumes them (K: ds_read_b128, V: two ds_read_b64_tr_b16)
+#ifndef MOLLY_ATTN_PIPE_KD
+#define MOLLY_ATTN_PIPE_KD 1
+#endif
+#ifndef MOLLY_ATTN_PIPE_VD
+#define MOLLY_ATTN_PIPE_VD 2
+#endif
+#ifndef MOLLY_ATTN_PIPE_MFMA_LATE
+#define MOLLY_ATTN_PIPE_MFMA_LATE 1
+#endif
 // MFMAs issued from asm with the register FILE of each operand chosen here.  With two waves per SIMD a wave has 256 registers, and
 // LLVM splits them 128 architected + 128 accumulation as soon as an `a` operand appears; left to itself at 256 architected registers
 // the allocator ping-ponged O between two register sets across the loop body's two steps (128 registers for 64) and spilled Q.
@@ -575,53 +608,75 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 // statistics) in the architected one.  hipcc does not see these as MFMAs, so the hazards its recognizer would pad are ours: a vector
 // instruction that reads an MFMA result needs the MFMA's passes + 3 wait states behind it — the fast path has >= 20 instructions
 // there by construction, the other paths call mfma_settle() — and back-to-back accumulation into the same registers is legal as is.
-#ifndef MOLLY_ATTN_PIPE_ASM_MFMA
-#define MOLLY_ATTN_PIPE_ASM_MFMA 0
+// ASM = true (one wave per SIMD, 512 registers = 256 architected + 256 accumulation): the register FILE of every operand is chosen here.
+#ifndef MOLLY_ATTN_PIPE_ASM_O
+#define MOLLY_ATTN_PIPE_ASM_O 1
 #endif
-#if MOLLY_ATTN_PIPE_ASM_MFMA
-__device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "v"(b));
+template <bool ASM> __device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    // (the V^T fragment is put together from two ds_read_b64_tr_b16: as an `a` operand hipcc reads it into architected registers and
+    // copies it over, four v_accvgpr_write per fragment; as a `v` operand it is used where it lands)
+    if constexpr (ASM && MOLLY_ATTN_PIPE_ASM_O) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
-__device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& bq) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(bq));
+template <bool ASM> __device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& bq) {
+    if constexpr (ASM) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "v"(bq));
+    else {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, z, 0, 0, 0);
+    }
 }
-__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& bq) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(bq));
+template <bool ASM> __device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& bq) {
+    if constexpr (ASM) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(bq));
+    else d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, d, 0, 0, 0);
 }
-#else
-__device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-}
-__device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& bq) {
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, z, 0, 0, 0);
-}
-__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& bq) {
-    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, d, 0, 0, 0);
-}
-#endif
-__device__ __forceinline__ void mfma_settle() {
-#if MOLLY_ATTN_PIPE_ASM_MFMA
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+template <bool ASM> __device__ __forceinline__ void mfma_settle() {
+    if constexpr (ASM) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
-template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
+// QB = query blocks (32 rows) per wave.  QB 1 x NW 8: two waves per SIMD, 256 registers each.  QB 2 x NW 4: ONE wave per SIMD with the
+// whole 512-register file, every K / V fragment feeding two MFMAs (half the LDS reads and LDS-DMA issue per MFMA), fragments read
+// KD / VD = 3 slots ahead — the guide's 4-wave structure (cdna_hip_programming.md 'Fused attention prefill'); nothing covers a stall
+// there, so the stream has to be dense by itself: its vector work (4 cycles of issue per instruction for a lone wave, 8 per exp) is
+// 0.6-0.7 of the MFMA time per step.
+template <int HD, int NW, int QB>
+__global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void attn_fwd_pipe_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);        // [3 K tiles][3 V tiles]
     constexpr int TILE = BKV * HD;
-    constexpr int NS = HD / 16, ND = HD / 32, BQW = NW * 32;
+    constexpr int NS = HD / 16, ND = HD / 32, BQW = NW * 32 * QB;
     static_assert(NS == 8 && ND == 4, "attn_fwd_pipe_kernel: the slot schedule is written for hd 128");
+    constexpr int KD = QB == 2 ? 3 : MOLLY_ATTN_PIPE_KD, VD = QB == 2 ? 3 : MOLLY_ATTN_PIPE_VD;
+    constexpr bool ASM = QB == 2;                               // asm MFMAs with chosen register files (see mfma_o)
+    // FIXED (with ASM): no vector instruction ever writes O.  The running maximum of a row is set ONCE, by the first step that has a
+    // live key for it, and kept: P = 2^(scale S - m_ref) may then exceed 1, which bf16 (fp32's exponent range) and the fp32 sums carry
+    // without loss — every term is scaled by the same 2^-m_ref, the quotient O / l does not see it.  What the online rescale protects
+    // against is overflow, so that is what is tested: a row whose maximum outgrows its reference by more than 2^64 raises *redo and
+    // attn_fwd_kernel, launched behind this kernel, recomputes the launch (it returns at once otherwise).  Why: `o *= alpha` in ANY
+    // path makes hipcc carry a second home for O in architected registers — 128 at QB 2 — and spill Q into the MFMA slots.
+    constexpr bool FIXED = ASM;
+    constexpr float REDO_THR = 64.f;
+    bool overflow = false;
+    static_assert(KD >= 1 && KD <= 3 && VD >= 1 && VD <= 3, "prefetch distance 1..3 slots");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // STAGGER (NW = 8): the two waves of a SIMD are waves w and w + 4.  Run in lockstep they sit in the same phase at the same time:
+    // they halve the matrix pipe between them in the MFMA slots and leave it idle together at the barrier and while both issue
+    // LDS-DMA (stamps, round 5: waves 4-7 took 1,230 cycles for a phase A that waves 0-3 finished in 615, and those then waited
+    // 1,100 cycles per tile at the barrier).  Waves 4-7 therefore take the tile barrier between the phases of the tile's FIRST
+    // step, waves 0-3 of its second: the first barrier holds waves 4-7 back by one step and from then on every phase A (vector-heavy)
+    // runs beside the partner's phase B, and one half's barrier + staging beside the other's MFMA slots.  The rings need no extra
+    // slot: behind Z_t the laggards still read V(t) and K(t+1), never K(t) or V(t-1).
+    const int bsub = (NW == 8 && wave >= 4 && p.stagger) ? 0 : 1;
+    if (NW == 8 && wave >= 4 && p.prio > 0) __builtin_amdgcn_s_setprio(1);   // (knob: static priority for the younger half)
     const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);
     const int qb = p.nblk - 1 - bi.blk;
     const int b = bi.b, kvh = bi.kvh, head = kvh * (p.nh / p.nkv) + bi.g;
-    const int q0 = qb * BQW + wave * 32;
+    const int q0 = qb * BQW + wave * 32 * QB;                  // the wave's first query row; its query block c covers q0 + 32 c ..
     const int T = p.T;
     // (readfirstlane: the loads are wave-uniform, but hipcc cannot prove it and would carry every loop counter that depends on them
     // in vector registers)
@@ -631,32 +686,48 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
     const bf16_t* Kb = p.K + (size_t)b * T * p.ldk + kvh * HD;
     const bf16_t* Vb = p.V + (size_t)b * T * p.ldv + kvh * HD;
 
-    bf16x8 qf[NS];
-    {
-        int qrow = q0 + r;
+    bf16x8 qf[QB][NS];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+        int qrow = q0 + 32 * c + r;
         qrow = qrow < T ? qrow : T - 1;
         const bf16_t* qp = Qb + (size_t)qrow * p.ldq + 8 * h;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) arrived(qf[s]);
+        for (int s = 0; s < NS; ++s) qf[c][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
-    f32x16 o[ND];
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
+    for (int c = 0; c < QB; ++c)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const int qi = q0 + r;
+        for (int s = 0; s < NS; ++s) {
+            arrived(qf[c][s]);
+        }
+    f32x16 o[QB][ND];
+#pragma unroll
+    for (int c = 0; c < QB; ++c)
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[c][d][e] = 0.f;
+    float m_run[QB], l_run[QB], m_new[QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) { m_run[c] = -INFINITY; l_run[c] = 0.f; m_new[c] = 0.f; }
+    const int qi = q0 + r;                                      // query row of block 0 on this lane (block c: qi + 32 c)
+#if MOLLY_ATTN_STAMP
+    unsigned long long tq0_ = 0, tq1_ = 0, ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
-    // tiles of the BLOCK [t_first, t_last]; steps (32 keys) of this WAVE [s_first, s_last]
+    // tiles of the BLOCK [t_first, t_last]; steps (32 keys) of the wave's query block c: [s_first, s_last[c]]
     const int blk_q_last = min(qb * BQW + BQW - 1, T - 1);
     const int kv_end = p.causal ? min(blk_q_last + 1, hi) : hi;       // exclusive
     const int t_first = lo / BKV;
     const int t_last = kv_end > lo ? (kv_end - 1) / BKV : t_first - 1;
-    const int kv_end_w = p.causal ? min(q0 + 32, kv_end) : kv_end;
     const int s_first = 2 * t_first;
-    const int s_last = kv_end_w > lo ? (kv_end_w - 1) / 32 : s_first - 1;
+    int s_last[QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+        const int kv_end_w = p.causal ? min(q0 + 32 * c + 32, kv_end) : kv_end;
+        s_last[c] = kv_end_w > lo ? (kv_end_w - 1) / 32 : s_first - 1;
+    }
 
     unsigned row0, colb;
     pipe_lane_const<HD, NW>(wave, lane, row0, colb);
@@ -676,43 +747,62 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
         vslot = vslot == 2 ? 0 : vslot + 1;
     };
     // barrier Z_t (between the phases of tile t's second step) and the staging behind it: K(t+3) into K(t)'s slot, V(t+2) into V(t-1)'s
-    auto tile_barrier = [&](int t) {
+    auto tile_sync = [&]() {
         // own LDS-DMA pieces landed AND own fragment reads returned (the slots behind the barrier are overwritten by other waves' DMA)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    };
+    auto tile_barrier = [&](int t) {
+        tile_sync();
         if (t + 3 <= t_last) stage_k(t + 3);
         if (t + 2 <= t_last) stage_v(t + 2);
     };
+    // the same staging, one piece at a time (fast path: a piece per MFMA slot of phase B): piece i < NP of K(t+3), then of V(t+2)
+    constexpr int NPW = PipeStage<HD, NW>::NP;
+    auto stage_piece = [&](int t, int i) {
+        if (i < NPW) {
+            if (t + 3 <= t_last) {
+                const int key0 = (t + 3) * BKV;
+                pipe_stage_piece<HD, NW>(i, reinterpret_cast<const char*>(Kb + (size_t)key0 * p.ldk), (unsigned)p.ldk * 2u, row0, colb,
+                                         (unsigned)(T - 1 - key0), smem_lds + (unsigned)(kslot * TILE * 2), wave);
+                if (i == NPW - 1) kslot = kslot == 2 ? 0 : kslot + 1;
+            }
+        } else if (t + 2 <= t_last) {
+            const int key0 = (t + 2) * BKV;
+            pipe_stage_piece<HD, NW>(i - NPW, reinterpret_cast<const char*>(Vb + (size_t)key0 * p.ldv), (unsigned)p.ldv * 2u, row0, colb,
+                                     (unsigned)(T - 1 - key0), smem_lds + (unsigned)((3 + vslot) * TILE * 2), wave);
+            if (i == 2 * NPW - 1) vslot = vslot == 2 ? 0 : vslot + 1;
+        }
+    };
 
     // ---- shared state of the phases
-    bf16x8 kpre0, kpre1;              // fast path: fragments 0, 1 of the K half whose S^T comes next (read at the end of the phase before)
-    bf16x8 p0, p1;                    // P^T of the step whose P.V comes next
-    float m_new = 0.f;                // pending rescale (valid when `resc`)
-    bool resc = false;
+    bf16x8 kpre[KD];                  // fast path: the first KD fragments of the K half whose S^T comes next (read at the end of the phase before)
+    bf16x8 p0[QB], p1[QB];            // P^T of the step whose P.V comes next
+    bool resc = false;                // a rescale is pending (m_new valid)
     int ks = 0, vs = 0;               // ring slots of the CURRENT tile's K and V (advance per tile)
     auto k_tile = [&](int slot) { return smem + slot * TILE; };
     auto v_tile = [&](int slot) { return smem + (3 + slot) * TILE; };
     auto nxt3 = [](int x) { return x == 2 ? 0 : x + 1; };
 
     // ---- unsliced pieces (prologue and the guarded steps): fragments read where they are used, two MFMAs per scheduling region
-    auto qk = [&](f32x16& sc, const bf16_t* sK, int sub) {      // (the caller settles before vector instructions read sc)
+    auto qk = [&](f32x16& sc, int c, const bf16_t* sK, int sub) {      // (the caller settles before vector instructions read sc)
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const bf16x8 f = row_frag<HD>(sK, 32 * sub + r, i, h);
-            if (i == 0) mfma_s0(sc, f, qf[0]); else mfma_s(sc, f, qf[i]);
+            if (i == 0) mfma_s0<ASM>(sc, f, qf[c][0]); else mfma_s<ASM>(sc, f, qf[c][i]);
             if (i & 1) SLOT_END();
         }
     };
-    auto pv = [&](const bf16_t* sV, int sub) {
+    auto pv = [&](int c, const bf16_t* sV, int sub) {
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            mfma_o(o[d], tr_frag<HD>(sV, 32 * sub, 0, d, lane), p0);
-            mfma_o(o[d], tr_frag<HD>(sV, 32 * sub, 1, d, lane), p1);
+            mfma_o<ASM>(o[c][d], tr_frag<HD>(sV, 32 * sub, 0, d, lane), p0[c]);
+            mfma_o<ASM>(o[c][d], tr_frag<HD>(sV, 32 * sub, 1, d, lane), p1[c]);
             SLOT_END();
         }
     };
     // row max of S(s) (masked where the step touches the diagonal or a range edge) and the rescale decision
-    auto start = [&](f32x16& sc, int s, auto MASKED) {
+    auto start = [&](f32x16& sc, int c, int s, auto MASKED) {
         const int kbase = 32 * s;
         float mx;
         if (MASKED) {
@@ -720,7 +810,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
+                const bool ok = key >= lo && key < hi && (!p.causal || key <= qi + 32 * c);
                 sc[e] = ok ? sc[e] : -INFINITY;
                 mx = fmaxf(mx, sc[e]);
             }
@@ -729,38 +819,51 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
                        vmax3(vmax3(sc[9], sc[10], sc[11]), vmax3(sc[12], sc[13], sc[14]), sc[15]));
         }
         mx = xhalf_max(mx) * p.scale_log2;
-        resc = !__all(mx - m_run <= RESCALE_THR);
-        m_new = fmaxf(m_run, mx);
+        if constexpr (FIXED) {
+            m_run[c] = (m_run[c] == -INFINITY) ? mx : m_run[c];
+            if (!__all(!(mx - m_run[c] > REDO_THR))) overflow = true;
+        } else {
+            if (!__all(mx - m_run[c] <= RESCALE_THR)) resc = true;
+            m_new[c] = fmaxf(m_run[c], mx);
+        }
     };
-    auto apply_rescale = [&]() {      // after P.V of the step before has been issued: everything at the old maximum is scaled once
+    // after P.V of the step before has been issued: everything at the old maximum is scaled once.  (With two query blocks a pending
+    // rescale moves BOTH to their exact running maxima — alpha is 1 for rows whose maximum did not grow.)
+    auto apply_rescale = [&]() {
+        if constexpr (FIXED) return;
         if (resc) {
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run - m_use);               // m_run = -inf -> 0
-            l_run *= alpha;
-            m_run = m_new;
-            mfma_settle();                                              // the P.V MFMAs just issued write o (asm: no hazard padding by hipcc)
+            mfma_settle<ASM>();
 #pragma unroll
-            for (int d = 0; d < ND; ++d)
+            for (int c = 0; c < QB; ++c) {
+                const float m_use = (m_new[c] == -INFINITY) ? 0.f : m_new[c];
+                const float alpha = fast_exp2(m_run[c] - m_use);        // m_run = -inf -> 0
+                l_run[c] *= alpha;
+                m_run[c] = m_new[c];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-            mfma_settle();                                              // ... and the next MFMA reads what these moves write
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        o[c][d][e] *= alpha;
+                    }
+            }
+            mfma_settle<ASM>();
             resc = false;
         }
     };
     // P(s) = 2^(scale S - m), row sum, bf16 fragments
-    auto finish = [&](f32x16& sc) {
-        const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
+    auto finish = [&](f32x16& sc, int c) {
+        const float m_ref = (m_run[c] == -INFINITY) ? 0.f : m_run[c];
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[e] = fast_exp2(sc[e] * p.scale_log2 - m_ref);
         float rs[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) rs[g4] = (sc[4 * g4] + sc[4 * g4 + 1]) + (sc[4 * g4 + 2] + sc[4 * g4 + 3]);
-        l_run += (rs[0] + rs[1]) + (rs[2] + rs[3]);
-        p0 = acc_to_frag(sc, 0);
-        p1 = acc_to_frag(sc, 8);
-        asm volatile("" ::"v"(p0), "v"(p1), "v"(l_run));
+        l_run[c] += (rs[0] + rs[1]) + (rs[2] + rs[3]);
+        p0[c] = acc_to_frag(sc, 0);
+        p1[c] = acc_to_frag(sc, 8);
+        asm volatile("" ::"v"(p0[c]), "v"(p1[c]), "v"(l_run[c]));
     };
-    auto need_mask = [&](int s) { return (p.causal && 32 * s + 31 > q0) || 32 * s < lo || 32 * s + 32 > hi; };
+    auto need_mask = [&](int s, int c) { return (p.causal && 32 * s + 31 > q0 + 32 * c) || 32 * s < lo || 32 * s + 32 > hi; };
 
     // ---- prologue: K(t0), V(t0), K(t0+1) -> barrier -> K(t0+2), V(t0+1) behind it
     if (t_last >= t_first) {
@@ -773,94 +876,151 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
     if (t_first + 2 <= t_last) stage_k(t_first + 2);
     if (t_first + 1 <= t_last) stage_v(t_first + 1);
 
-    f32x16 sX, sY;                    // S of the current / the next step; the roles swap every step
-    if (s_last >= s_first) {
-        qk(sX, k_tile(0), 0);
-        mfma_settle();
-        if (need_mask(s_first)) start(sX, s_first, std::true_type{}); else start(sX, s_first, std::false_type{});
-        apply_rescale();
-    }
+    f32x16 sX[QB], sY[QB];            // S of the current / the next step; the roles swap every step
+#pragma unroll
+    for (int c = 0; c < QB; ++c)
+        if (s_last[c] >= s_first) qk(sX[c], c, k_tile(0), 0);
+    mfma_settle<ASM>();
+#pragma unroll
+    for (int c = 0; c < QB; ++c)
+        if (s_last[c] >= s_first) {
+            if (need_mask(s_first, c)) start(sX[c], c, s_first, std::true_type{}); else start(sX[c], c, s_first, std::false_type{});
+        }
+    apply_rescale();
 
     // one step under wave-uniform guards (first / last tiles of the wave, and its idle tiles behind the causal diagonal).
     // Step s = (tile t, half sub); K(s+1) = tile t's half 1 (sub 0) or tile t+1's half 0 (sub 1).
-    auto step_guarded = [&](f32x16& cur, f32x16& nxt, int s) {
+    auto step_guarded = [&](f32x16 (&cur)[QB], f32x16 (&nxt)[QB], int s) {
         const int sub = s & 1;
-        const bool a_cur = s <= s_last, a_nxt = s + 1 <= s_last;
-        if (a_nxt) qk(nxt, sub ? k_tile(nxt3(ks)) : k_tile(ks), sub ^ 1);
-        if (a_cur) finish(cur);
-        if (sub) tile_barrier(s >> 1);
-        if (a_cur) pv(v_tile(vs), sub);
-        if (a_nxt) {
-            mfma_settle();                                              // S(s+1) is read by vector instructions next
-            if (need_mask(s + 1)) start(nxt, s + 1, std::true_type{}); else start(nxt, s + 1, std::false_type{});
-            apply_rescale();
-        }
+#pragma unroll
+        for (int c = 0; c < QB; ++c)
+            if (s + 1 <= s_last[c]) qk(nxt[c], c, sub ? k_tile(nxt3(ks)) : k_tile(ks), sub ^ 1);
+#pragma unroll
+        for (int c = 0; c < QB; ++c)
+            if (s <= s_last[c]) finish(cur[c], c);
+        if (sub == bsub) tile_barrier(s >> 1);
+#pragma unroll
+        for (int c = 0; c < QB; ++c)
+            if (s <= s_last[c]) pv(c, v_tile(vs), sub);
+        mfma_settle<ASM>();                                                  // S(s+1) is read by vector instructions next
+#pragma unroll
+        for (int c = 0; c < QB; ++c)
+            if (s + 1 <= s_last[c]) {
+                if (need_mask(s + 1, c)) start(nxt[c], c, s + 1, std::true_type{}); else start(nxt[c], c, s + 1, std::false_type{});
+            }
+        apply_rescale();
     };
 
-    // the branch-free step, placed by hand: 8 MFMA slots per phase, each closed by a sched_barrier so that hipcc keeps what was put
-    // beside each MFMA there (fragment reads two slots ahead of their MFMA, the softmax in slices)
-    auto step_fast = [&](f32x16& cur, f32x16& nxt, int s, auto SUB) {
+    // the branch-free step, placed by hand: 8 MFMA slots per phase (one MFMA per query block each), each closed by a sched_barrier
+    // so that hipcc keeps what was put beside the MFMAs there (fragment reads KD / VD slots ahead, the softmax in slices)
+    auto step_fast = [&](f32x16 (&cur)[QB], f32x16 (&nxt)[QB], int s, auto SUB) {
         constexpr int sub = decltype(SUB)::value;
+#if MOLLY_ATTN_STAMP
+        if (!sub) { ASTAMP(tq0_); ++ts_[7]; }
+#endif
         // ---- phase A: S(s+1) = K(s+1) Q^T beside P(s) = 2^(scale S(s) - m)
         const bf16_t* sKa = sub ? k_tile(nxt3(ks)) : k_tile(ks);           // K(s+1): tile t half 1 | tile t+1 half 0
         constexpr int suba = sub ^ 1;
         const bf16_t* sV = v_tile(vs);
-        const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;
-        float tot = 0.f;
-        u32x4 w0, w1;
+        float m_ref[QB], tot[QB];
+        u32x4 w0[QB], w1[QB];
+#pragma unroll
+        for (int c = 0; c < QB; ++c) { m_ref[c] = (m_run[c] == -INFINITY) ? 0.f : m_run[c]; tot[c] = 0.f; }
         bf16x8 kfr[NS];
         bf16x8 vfr[2 * ND];                                                // V^T fragments by P.V slot j = 2 d + sp
-        kfr[0] = kpre0;
-        kfr[1] = kpre1;
+#pragma unroll
+        for (int i = 0; i < KD; ++i) kfr[i] = kpre[i];
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            if (i + 2 < NS) kfr[i + 2] = row_frag<HD>(sKa, 32 * suba + r, i + 2, h);
-            else vfr[i + 2 - NS] = tr_frag<HD>(sV, 32 * sub, (i + 2 - NS) & 1, (i + 2 - NS) >> 1, lane);
-            if (i == 0) mfma_s0(nxt, kfr[0], qf[0]); else mfma_s(nxt, kfr[i], qf[i]);
-            cur[2 * i] = fast_exp2(cur[2 * i] * p.scale_log2 - m_ref);
-            cur[2 * i + 1] = fast_exp2(cur[2 * i + 1] * p.scale_log2 - m_ref);
-            if (i > 0) {
-                const int j = i - 1;
-                tot += cur[2 * j] + cur[2 * j + 1];
-                const unsigned pk = pack_bf2(cur[2 * j], cur[2 * j + 1]);
-                if (j < 4) w0[j] = pk; else w1[j - 4] = pk;
+            if (i + KD < NS) kfr[i + KD] = row_frag<HD>(sKa, 32 * suba + r, i + KD, h);
+            if (i + VD >= NS) vfr[i + VD - NS] = tr_frag<HD>(sV, 32 * sub, (i + VD - NS) & 1, (i + VD - NS) >> 1, lane);
+#pragma unroll
+            for (int c = 0; c < QB; ++c) {
+                cur[c][2 * i] = fast_exp2(cur[c][2 * i] * p.scale_log2 - m_ref[c]);
+                cur[c][2 * i + 1] = fast_exp2(cur[c][2 * i + 1] * p.scale_log2 - m_ref[c]);
+                if (i > 0) {
+                    const int j = i - 1;
+                    tot[c] += cur[c][2 * j] + cur[c][2 * j + 1];
+                    const unsigned pk = pack_bf2(cur[c][2 * j], cur[c][2 * j + 1]);
+                    if (j < 4) w0[c][j] = pk; else w1[c][j - 4] = pk;
+                }
+            }
+            // the MFMAs close their slot: the fragment they wait for gets this slot's vector work as extra cover
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < QB; ++c) {
+                if (i == 0) mfma_s0<ASM>(nxt[c], kfr[0], qf[c][0]); else mfma_s<ASM>(nxt[c], kfr[i], qf[c][i]);
             }
             SLOT_END();
         }
-        tot += cur[14] + cur[15];
-        w1[3] = pack_bf2(cur[14], cur[15]);
-        l_run += tot;
-        p0 = __builtin_bit_cast(bf16x8, w0);
-        p1 = __builtin_bit_cast(bf16x8, w1);
-        // "used here": without it LLVM sinks the whole exp / sum / pack chain below the barrier's branches to its first real use,
-        // i.e. out from beside the S^T MFMAs and in front of the P.V MFMAs that wait for it
-        asm volatile("" ::"v"(p0), "v"(p1), "v"(l_run));
+#pragma unroll
+        for (int c = 0; c < QB; ++c) {
+            tot[c] += cur[c][14] + cur[c][15];
+            w1[c][3] = pack_bf2(cur[c][14], cur[c][15]);
+            l_run[c] += tot[c];
+            p0[c] = __builtin_bit_cast(bf16x8, w0[c]);
+            p1[c] = __builtin_bit_cast(bf16x8, w1[c]);
+            // "used here": without it LLVM sinks the whole exp / sum / pack chain below the barrier's branches to its first real use,
+            // i.e. out from beside the S^T MFMAs and in front of the P.V MFMAs that wait for it
+            asm volatile("" ::"v"(p0[c]), "v"(p1[c]), "v"(l_run[c]));
+        }
         SLOT_END();
-        if (sub) tile_barrier(s >> 1);
+        ALAP(sub ? 2 : 0);                                                 // phase A
+        const bool zt = sub == bsub;                                       // this wave's tile barrier sits in this step
+        if (zt) {
+#if MOLLY_ATTN_STAMP
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            ALAP(3);                                                       // own LDS-DMA pieces landed
+            __builtin_amdgcn_s_barrier();
+            ALAP(4);                                                       // the workgroup's barrier
+#else
+            tile_sync();
+#endif
+        }
         SLOT_END();
-        // ---- phase B: O^T += V(s)^T P(s)^T beside the row max of S(s+1); K(s+2) = tile t+1's half `sub`: fragments 0, 1 prefetched
+        // ---- phase B: O^T += V(s)^T P(s)^T beside the row max of S(s+1); K(s+2) = tile t+1's half `sub`: first KD fragments prefetched
         const bf16_t* sKb = k_tile(nxt3(ks));
-        float ma = 0.f, mb = 0.f, mc = 0.f, md = 0.f, me = 0.f, mx = 0.f;
+        float ma[QB], mb[QB], mc[QB], md[QB], me[QB], mx[QB];
+#pragma unroll
+        for (int c = 0; c < QB; ++c) ma[c] = mb[c] = mc[c] = md[c] = me[c] = mx[c] = 0.f;
 #pragma unroll
         for (int j = 0; j < 2 * ND; ++j) {
-            if (j + 2 < 2 * ND) vfr[j + 2] = tr_frag<HD>(sV, 32 * sub, (j + 2) & 1, (j + 2) >> 1, lane);
-            else if (j == 6) kpre0 = row_frag<HD>(sKb, 32 * sub + r, 0, h);
-            else kpre1 = row_frag<HD>(sKb, 32 * sub + r, 1, h);
-            mfma_o(o[j >> 1], vfr[j], (j & 1) ? p1 : p0);
+            if (j + VD < 2 * ND) vfr[j + VD] = tr_frag<HD>(sV, 32 * sub, (j + VD) & 1, (j + VD) >> 1, lane);
+            if (j + KD >= 2 * ND) kpre[j + KD - 2 * ND] = row_frag<HD>(sKb, 32 * sub + r, j + KD - 2 * ND, h);
+            // behind the barrier: the LDS-DMA of K(t+3), V(t+2), a piece per slot (issued in a lump they cost ~ 90 cycles each with
+            // the matrix pipe idle: 360 of a tile's 3,600)
+            if (zt && j < 2 * NPW) stage_piece(s >> 1, j);
             // S(s+1) is complete one MFMA latency behind phase A's last MFMA: nothing reads it in slots 0, 1
-            if (j == 2) { ma = vmax3(nxt[0], nxt[1], nxt[2]); mb = vmax3(nxt[3], nxt[4], nxt[5]); }
-            if (j == 3) { mc = vmax3(nxt[6], nxt[7], nxt[8]); md = vmax3(nxt[9], nxt[10], nxt[11]); }
-            if (j == 4) { me = vmax3(nxt[12], nxt[13], nxt[14]); ma = vmax3(ma, mb, mc); }
-            if (j == 5) { md = vmax3(md, me, nxt[15]); mx = vmax2(ma, md); }
-            if (j == 6) { mx = xhalf_max(mx) * p.scale_log2; }
-            if (j == 7) { resc = !__all(mx - m_run <= RESCALE_THR); m_new = fmaxf(m_run, mx); }
+#pragma unroll
+            for (int c = 0; c < QB; ++c) {
+                f32x16& n = nxt[c];
+                if (j == 2) { ma[c] = vmax3(n[0], n[1], n[2]); mb[c] = vmax3(n[3], n[4], n[5]); }
+                if (j == 3) { mc[c] = vmax3(n[6], n[7], n[8]); md[c] = vmax3(n[9], n[10], n[11]); }
+                if (j == 4) { me[c] = vmax3(n[12], n[13], n[14]); ma[c] = vmax3(ma[c], mb[c], mc[c]); }
+                if (j == 5) { md[c] = vmax3(md[c], me[c], n[15]); mx[c] = vmax2(ma[c], md[c]); }
+                if (j == 6) { mx[c] = xhalf_max(mx[c]) * p.scale_log2; }
+                if (j == 7) {
+                    if constexpr (FIXED) {
+                        m_run[c] = (m_run[c] == -INFINITY) ? mx[c] : m_run[c];
+                        if (!__all(!(mx[c] - m_run[c] > REDO_THR))) overflow = true;
+                    } else {
+                        if (!__all(mx[c] - m_run[c] <= RESCALE_THR)) resc = true;
+                        m_new[c] = fmaxf(m_run[c], mx[c]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < QB; ++c) mfma_o<ASM>(o[c][j >> 1], vfr[j], (j & 1) ? p1[c] : p0[c]);
             SLOT_END();
         }
         apply_rescale();
         SLOT_END();
+        ALAP(sub ? 6 : 1);                                                 // phase B
     };
-    // interior for this wave: steps 2t, 2t+1 with S(2t+1), S(2t+2) unmasked and K(2t+3) still wanted
-    auto is_fast = [&](int t) { return 2 * t + 3 <= s_last && !need_mask(2 * t + 1) && !need_mask(2 * t + 2); };
+    // interior for this wave: steps 2t, 2t+1 with S(2t+1), S(2t+2) unmasked for every query block (block 0's diagonal comes first)
+    // and K(2t+3) still wanted
+    auto is_fast = [&](int t) { return 2 * t + 3 <= s_last[0] && !need_mask(2 * t + 1, 0) && !need_mask(2 * t + 2, 0); };
 
     // ONE loop over the tiles with the two bodies as the arms of a branch: guarded tiles (a range that starts inside a tile, the wave's
     // causal diagonal, its idle tiles up to the block's last) and interior ones.  (Loops per kind — in sequence, or nested in an outer
@@ -868,9 +1028,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
     bool prev_fast = false;
     for (int t = t_first; t <= t_last; ++t) {
         if (is_fast(t)) {
-            if (!prev_fast) {         // entering a fast run at step 2t: fragments 0, 1 of K(2t+1) = tile t's half 1
-                kpre0 = row_frag<HD>(k_tile(ks), 32 + r, 0, h);
-                kpre1 = row_frag<HD>(k_tile(ks), 32 + r, 1, h);
+            if (!prev_fast) {         // entering a fast run at step 2t: the first KD fragments of K(2t+1) = tile t's half 1
+#pragma unroll
+                for (int i = 0; i < KD; ++i) kpre[i] = row_frag<HD>(k_tile(ks), 32 + r, i, h);
             }
             step_fast(sX, sY, 2 * t, std::false_type{});
             step_fast(sY, sX, 2 * t + 1, std::true_type{});
@@ -884,14 +1044,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(AttnArgs p) {
         vs = nxt3(vs);
     }
 
-    // ---- epilogue: O[q][d] = o / l ; LSE2 = m + log2(l).  No wave reads K / V fragments behind the last tile barrier, so the slabs
-    // may overwrite the rings.
-    mfma_settle();
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    store_rows<HD, ND>(smem + wave * 32 * (HD + 8), o, inv, p.O + ((size_t)b * T + q0) * p.ldo + head * HD, p.ldo, T - q0, lane);
-    if (qi < T && p.LSE && h == 0)
-        p.LSE[((size_t)b * p.nh + head) * T + qi] = l_tot > 0.f ? m_run + log2f(l_tot) : -INFINITY;
+    // ---- epilogue: O[q][d] = o / l ; LSE2 = m + log2(l).  Behind the last tile barrier waves still read V (and, staggered, K)
+    // fragments, so one more barrier before the slabs overwrite the rings.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    mfma_settle<ASM>();
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+        const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
+        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        const int qc = q0 + 32 * c;
+        store_rows<HD, ND>(smem + wave * 32 * (HD + 8), o[c], inv, p.O + ((size_t)b * T + qc) * p.ldo + head * HD, p.ldo, T - qc, lane);
+        if (qc + r < T && p.LSE && h == 0)
+            p.LSE[((size_t)b * p.nh + head) * T + qc + r] = l_tot > 0.f ? m_run[c] + log2f(l_tot) : -INFINITY;
+    }
+    if (FIXED && overflow && lane == 0) __hip_atomic_store(p.redo, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if MOLLY_ATTN_STAMP
+    if (lane == 0 && (blockIdx.x * NW + wave) < 32768 * 4) {            // [block][wave][8]: laps 0..6 of the FAST tiles, [7] = their count
+        unsigned long long* q = g_attn_stamp + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] += ts_[i];
+    }
+#endif
 }
 
 // ================================================================================================
@@ -1342,6 +1516,16 @@ static int order_set(int dkv, int npairs) {
     return s;
 }
 
+static bool attr_set_fwd() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 65536);
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+        attr_set = true;
+    }
+    return true;
+}
+
 extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
                               const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim,
                               int ldq, int ldk, int ldv, int ldo, float scale, int causal) {
@@ -1355,7 +1539,8 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     MOLLY_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0, "attn_fwd: alignment");
     MOLLY_CHECK(B > 0 && T > 0, "attn_fwd: empty problem");
     AttnArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, lse2, kv_lo, kv_hi, T, n_heads,
-               n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal, cdiv(T, BQ), order_set(0, B * n_kv_heads), wave_prio()};
+               n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal, cdiv(T, BQ), order_set(0, B * n_kv_heads), wave_prio(),
+               [] { const char* e = getenv("MOLLY_ATTN_PIPE_STAGGER"); return e ? atoi(e) : 1; }(), nullptr, 0};
     if (head_dim < 64) {
         const dim3 g(n_heads * B, cdiv(T, 128));
 #define MOLLY_SMALL(HD_) case HD_: hipLaunchKernelGGL(attn_fwd_small_kernel<HD_>, g, dim3(128), 0, (hipStream_t)stream, p); break
@@ -1364,22 +1549,41 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
         MOLLY_LAUNCH_CHECK();
         return 0;
     }
-    // MOLLY_ATTN_FWD_PIPE = 4 | 8: the software-pipelined forward (attn_fwd_pipe_kernel) with that many waves per workgroup; 0: attn_fwd_kernel
+    // MOLLY_ATTN_FWD_PIPE: the software-pipelined forward (attn_fwd_pipe_kernel), 8 = eight waves x 32 query rows (two waves per SIMD),
+    // 4 = four waves x 64 rows (one wave per SIMD); 0: attn_fwd_kernel
     {
         const char* e = getenv("MOLLY_ATTN_FWD_PIPE");
         const int nw = e ? atoi(e) : 0;
         if (head_dim == 128 && (nw == 4 || nw == 8)) {
             static bool pipe_attr = false;
             if (!pipe_attr) {
-                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
-                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
+                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
+                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
                 pipe_attr = true;
             }
-            p.nblk = cdiv(T, nw * 32);
+            p.nblk = cdiv(T, 256);
             const dim3 gp(n_heads * B * p.nblk);
             const size_t ldsp = 6 * BKV * 128 * sizeof(bf16_t);
-            if (nw == 4) hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 4>), gp, dim3(256), ldsp, (hipStream_t)stream, p);
-            else hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 8>), gp, dim3(512), ldsp, (hipStream_t)stream, p);
+            if (nw == 8) {
+                hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 8, 1>), gp, dim3(512), ldsp, (hipStream_t)stream, p);
+                MOLLY_LAUNCH_CHECK();
+                return 0;
+            }
+            // fixed-reference kernel + its conditional fall-back: a ring of flags (one per launch in flight), each holding the sequence
+            // number of the launch that raised it — nothing to reset, and launches on other streams use other slots
+            static int* flags = nullptr;
+            static int seq = 0;
+            if (!flags) {
+                MOLLY_CHECK(hipMalloc(&flags, 64 * sizeof(int)) == hipSuccess, "attn_fwd: flag ring allocation failed");
+                MOLLY_CHECK(hipMemset(flags, 0, 64 * sizeof(int)) == hipSuccess, "attn_fwd: flag ring reset failed");
+            }
+            seq = seq == 0x7fffffff ? 1 : seq + 1;
+            p.redo = flags + (seq & 63);
+            p.seq = seq;
+            hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 4, 2>), gp, dim3(256), ldsp, (hipStream_t)stream, p);
+            p.nblk = cdiv(T, BQ);
+            if (!attr_set_fwd()) return -1;
+            hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3(n_heads * B * cdiv(T, BQ)), dim3(256), 2 * 2 * BKV * 128 * sizeof(bf16_t), (hipStream_t)stream, p);
             MOLLY_LAUNCH_CHECK();
             return 0;
         }
@@ -1389,12 +1593,7 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     // second wave of every SIMD is worth is then the ratio of the two run times
     static const size_t pad = [] { const char* e = getenv("MOLLY_ATTN_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
     const size_t lds = 2 * 2 * BKV * head_dim * sizeof(bf16_t) + pad;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 65536);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
-        attr_set = true;
-    }
+    (void)attr_set_fwd();
     if (head_dim == 128)
         hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, p);
     else

@@ -144,7 +144,9 @@ class GenerationSession:
         fuse = e.lora is None and os.environ.get("MOLLY_DECODE_FUSE", "1") != "0"
         H = x.shape[1]
         f_qkv = fuse and ops.gemm_rows_tail_supported(B, nq + 2 * nkvd, H, "qkv")
-        f_att = f_qkv and e.hd in (64, 128) and os.environ.get("MOLLY_DECODE_FUSE_ATTN", "1") != "0"
+        # (the fused attention is built for groups of 1 / 2 / 4 / 8 query heads per KV head: other ratios take the plain path)
+        f_att = (f_qkv and e.hd in (64, 128) and e.nh % e.nkv == 0 and e.nh // e.nkv in (1, 2, 4, 8)
+                 and os.environ.get("MOLLY_DECODE_FUSE_ATTN", "1") != "0")
         f_o = fuse and ops.gemm_rows_tail_supported(B, H, nq, "norm")
         f_gu = fuse and ops.gemm_rows_tail_supported(B, 2 * e.ff, H, "swiglu")
         f_dn = fuse and ops.gemm_rows_tail_supported(B, H, e.ff, "norm")
@@ -213,9 +215,14 @@ class GenerationSession:
         `DynamicCache.reorder_cache`, HF:cache_utils.py).  In place, so the captured decode graph's pointers stay valid; only the
         filled part of the caches moves."""
         rows = rows.to(self.rt.dev).long()
+        if bool((rows == torch.arange(rows.numel(), device=rows.device)).all()):
+            return                                      # every beam stays where it is: nothing moves
         n = self.cur_len
-        self.kc[:, :, :n] = self.kc[:, :, :n].index_select(1, rows)
-        self.vc[:, :, :n] = self.vc[:, :, :n].index_select(1, rows)
+        # layer by layer: the temporary is one layer's filled cache (B x n x kv width), not all L of them — at Qwen3-8B with a 3 k-token
+        # prompt and B * num_beams rows the whole-cache gather was a multi-GB allocation beside a cache sized for 3,072 new tokens
+        for i in range(self.kc.shape[0]):
+            self.kc[i, :, :n] = self.kc[i, :, :n].index_select(0, rows)
+            self.vc[i, :, :n] = self.vc[i, :, :n].index_select(0, rows)
         for t in (self.pos, self.hi, self.lo, self.n_valid):
             t.copy_(t.index_select(0, rows))
         # (slot = row * Tmax + cur_len belongs to the ROW, not to the beam that moved into it)
@@ -377,7 +384,8 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
 def _generate_beams(model, input_ids, attention_mask, omic_ids, omic_info_list, max_new_tokens, do_sample, repetition_penalty, pad_token_id,
                     eos_token_id, no_repeat_ngram_size, num_beams, length_penalty, early_stopping, temperature=None, top_k=None, top_p=None,
                     generator=None):
-    """`num_beams > 1` of the reference's generate signature (src/model/omics_one.py:199-200, 227 -> HF `_beam_search`): the prompt rows
+    """Beam search, this build's extension (`OmicsOne.generate(molly_num_beams=N)`; the reference's own `num_beams` parameter is dropped
+    by its generate, src/model/omics_one.py:220-232, and is ignored here too).  Procedure = HF `_beam_search` (molly_amd/beam.py): the prompt rows
     repeated num_beams times through one prefill, then molly_amd.beam.beam_search over the decode session (logits from
     `GenerationSession.step`, the KV cache gathered by `GenerationSession.reorder`).  With do_sample=True this is HF's beam sampling:
     the warpers (temperature, top-k, top-p) act on the log-probabilities and the continuations are drawn by torch.multinomial — the

@@ -652,7 +652,18 @@ class OmicsOne(_MetaSafe):
                  do_sample=True, temperature=0.8, top_p=0.95, top_k=None, num_beams=None, no_repeat_ngram_size=None,
                  **generate_kwargs):
         """reference: src/model/omics_one.py:187-233 — same signature; returns the NEW tokens only.  `max_new_tokens`
-        defaults to the reference's hard-coded 3072 (:223) and may be overridden through generate_kwargs."""
+        defaults to the reference's hard-coded 3072 (:223) and may be overridden through generate_kwargs.
+
+        `num_beams`, `max_length` and `min_length` are named parameters the reference accepts and DROPS: its call of
+        `self.model.generate` (:220-232) forwards do_sample, temperature, top_p, top_k, no_repeat_ngram_size, the pad / eos ids and
+        **generate_kwargs only, so `num_beams=4` there still samples (or decodes greedily).  The same happens here (one warning).
+        Beam search / beam sampling (molly_amd/beam.py, pinned to HuggingFace's `_beam_search`) is an EXTENSION of this build,
+        opt-in through `generate_kwargs["molly_num_beams"]`."""
+        if num_beams not in (None, 1) and not getattr(OmicsOne, "_warned_num_beams", False):
+            import warnings
+            warnings.warn("OmicsOne.generate: `num_beams` is accepted and ignored, as in the reference (src/model/omics_one.py:220-232 "
+                          "does not forward it); pass molly_num_beams=N for this build's beam search", stacklevel=2)
+            OmicsOne._warned_num_beams = True
         if omic_ids is not None:
             for i in range(len(omic_ids)):
                 assert len(omic_ids[i]) == len(omic_info_list[i]), f"Mismatch in omic count vs info count at index {i}"
@@ -662,7 +673,7 @@ class OmicsOne(_MetaSafe):
                     max_new_tokens=generate_kwargs.pop("max_new_tokens", 3072), do_sample=do_sample, temperature=temperature,
                     top_p=top_p, top_k=top_k, repetition_penalty=generate_kwargs.pop("repetition_penalty", None),
                     pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id, generator=generate_kwargs.pop("generator", None),
-                    no_repeat_ngram_size=no_repeat_ngram_size, num_beams=num_beams or 1,
+                    no_repeat_ngram_size=no_repeat_ngram_size, num_beams=int(generate_kwargs.pop("molly_num_beams", 1) or 1),
                     length_penalty=generate_kwargs.pop("length_penalty", 1.0), early_stopping=generate_kwargs.pop("early_stopping", False))
 
 

@@ -100,6 +100,55 @@ class _DistComm:
         dist.all_reduce(region, group=self.group)
 
 
+class _NullComm:
+    """MEASUREMENT ONLY (bench.py at N > 1, after the timed region): the same step with no bytes exchanged — every collective a
+    no-op, so each rank keeps its own gradients and the replicas diverge from here on.  `step time with the exchange overlapped` minus
+    `step time without any exchange` is the communication the overlap failed to hide (`comm.exposed_comm_ms`)."""
+    rs_algo = "none"
+    staged = False
+
+    def reduce_scatter(self, out_chunk, region):
+        pass
+
+    def all_gather(self, region, chunk):
+        pass
+
+    def all_reduce(self, t):
+        pass
+
+    def all_reduce_region(self, region):
+        pass
+
+
+def sweep_exchange(candidates, measure, steps_each: int):
+    """Which (bucket size, reduce-scatter algorithm) runs this job's step fastest on this job's own ranks?  The reference fixes
+    `reduce_bucket_size` / `allgather_bucket_size` at 5e8 elements in a config file (src/configs/ds_z2_config.json:18-27); here the
+    first multi-GPU run measures its own: `measure(bucket_mib, rs_algo)` builds the optimizer with that layout, runs one settling
+    step + `steps_each` timed ones and returns the step time in ms ALREADY maximised over the ranks (so every rank sees the same
+    table and picks the same winner), or raises — a candidate that fails (out of memory at 1 GiB buckets, an algorithm the backend
+    refuses) is recorded with its error and skipped.  Returns {"ms_per_step": {"<MiB>/<algo>": ms | None}, "errors": {...},
+    "chosen": {"bucket_mib": ..., "rs_algo": ...}, "steps_each": n}; ties go to the earlier candidate (smaller bucket first)."""
+    table, errors = {}, {}
+    best_key, best_ms, best = None, None, None
+    for mib, algo in candidates:
+        key = f"{mib:g}/{algo}"
+        try:
+            ms = float(measure(mib, algo))
+        except Exception as e:                                    # noqa: BLE001 — recorded, the sweep goes on
+            table[key] = None
+            errors[key] = f"{type(e).__name__}: {str(e)[:200]}"
+            continue
+        table[key] = round(ms, 2)
+        if best_ms is None or ms < best_ms:
+            best_key, best_ms, best = key, ms, (mib, algo)
+    if best is None:
+        raise RuntimeError(f"bucket sweep: every candidate failed: {errors}")
+    out = {"ms_per_step": table, "chosen": {"bucket_mib": best[0], "rs_algo": best[1], "key": best_key}, "steps_each": steps_each}
+    if errors:
+        out["errors"] = errors
+    return out
+
+
 _STAGED_DEFAULT = False        # set by preflight_collectives when the in-place forms misbehave on this backend
 
 

@@ -1,9 +1,10 @@
-"""CPU: molly_amd.beam.beam_search against HuggingFace's own beam search.  The reference forwards `num_beams` to HF `generate`
-(reference src/model/omics_one.py:199-200, 227) with `inputs_embeds` and no `input_ids`; here a small random HF Qwen3 model provides
-the logits for BOTH sides — HF's `generate(inputs_embeds=..., num_beams=k)` and molly's restatement driven through two callbacks (next
-logits for these rows / gather the rows) — so every token must agree: the scorer, the early-stop heuristic, the EOS bookkeeping and
-the padding of shorter hypotheses are pinned to HF's behaviour independently of any kernel.  (The installed transformers is 5.x; the
-reference pins 4.53, whose BeamSearchScorer the 4.50 refactor reproduced.)"""
+"""CPU: molly_amd.beam.beam_search against HuggingFace's own beam search.  Beam search is an extension of this build
+(`OmicsOne.generate(molly_num_beams=N)`): the reference's generate has a `num_beams` parameter but does not forward it
+(src/model/omics_one.py:199, 220-232).  What is pinned here is the procedure HF runs for `generate(inputs_embeds=..., num_beams=k)` with
+no `input_ids`: a small random HF Qwen3 model provides the logits for BOTH sides — HF's own `generate` and molly's restatement driven
+through two callbacks (next logits for these rows / gather the rows) — so every token must agree: the scorer, the early-stop
+heuristic, the EOS bookkeeping and the padding of shorter hypotheses are pinned to HF's behaviour independently of any kernel.  (The
+installed transformers is 5.x; the reference pins 4.53, whose BeamSearchScorer the 4.50 refactor reproduced.)"""
 import pytest
 import torch
 

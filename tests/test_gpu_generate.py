@@ -338,18 +338,25 @@ def test_session_reorder_gathers_the_cache_rows(tiny_meta):
 
 
 def test_generate_beam_search_through_the_reference_signature(tiny_meta):
-    """`num_beams` of the reference's generate (src/model/omics_one.py:199-200, 227).  The procedure itself is pinned to HuggingFace's
-    beam search token for token on CPU (tests/test_beam_search.py); here it runs on the HIP decode session: deterministic, the best
-    hypothesis scores at least as high under the model as the greedy continuation, one beam equals greedy, beam sampling runs and is
-    reproducible under a seeded generator."""
+    """The reference's generate accepts `num_beams` and drops it (src/model/omics_one.py:199, 220-232): so does this one — `num_beams=3`
+    returns the greedy continuation, with a warning.  Beam search is this build's extension behind `molly_num_beams`; the procedure is
+    pinned to HuggingFace's beam search token for token on CPU (tests/test_beam_search.py), and here it runs on the HIP decode session:
+    deterministic, the best hypothesis scores at least as high under the model as the greedy continuation, one beam equals greedy,
+    beam sampling runs and is reproducible under a seeded generator."""
+    import warnings
     m = build_tiny(tiny_meta)
     ids, mask, omic, info = _left_padded_batch(tiny_meta)
     greedy = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6)
-    one = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, num_beams=1)
+    type(m)._warned_num_beams = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ignored = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, num_beams=3)
+    assert torch.equal(greedy, ignored) and any("num_beams" in str(x.message) for x in w)
+    one = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, molly_num_beams=1)
     assert torch.equal(greedy, one)
-    beams = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, num_beams=3)
+    beams = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, molly_num_beams=3)
     assert beams.shape == (2, 6) and beams.dtype == torch.int64
-    assert torch.equal(beams, m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, num_beams=3))
+    assert torch.equal(beams, m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, molly_num_beams=3))
 
     def seq_logprob(tokens):                                       # sum of log-probabilities of `tokens` under teacher forcing
         from molly_amd.generate import GenerationSession
@@ -364,7 +371,7 @@ def test_generate_beam_search_through_the_reference_signature(tiny_meta):
     assert bool((seq_logprob(beams) >= seq_logprob(greedy) - 5e-2).all())
     # beam sampling: the same procedure with drawn continuations; reproducible under the caller's generator
     g = torch.Generator(device="cuda").manual_seed(5)
-    s1 = m.generate(ids, mask, omic, info, num_beams=3, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, max_new_tokens=6, generator=g)
+    s1 = m.generate(ids, mask, omic, info, molly_num_beams=3, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, max_new_tokens=6, generator=g)
     g = torch.Generator(device="cuda").manual_seed(5)
-    s2 = m.generate(ids, mask, omic, info, num_beams=3, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, max_new_tokens=6, generator=g)
+    s2 = m.generate(ids, mask, omic, info, molly_num_beams=3, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, max_new_tokens=6, generator=g)
     assert s1.shape[0] == 2 and s1.shape[1] <= 6 and torch.equal(s1, s2)
