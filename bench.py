@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
+DEFAULT_BATCH = 16          # samples per GPU of the headline workload (tests/test_gpu_fullsize.py checks the kernels at THIS batch's shapes)
+
+
 def algorithmic_flops_per_token(cfg, T):
     """F_llm = 2*P_mm + 4*L*nh*hd*(T/2) per token forward; training = 3x."""
     h, hd, nh, nkv, ff, L, V = (cfg.hidden_size, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads,
@@ -376,7 +379,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH,
                     help="samples per GPU per step.  BASELINE configs[1] fixes the model, the sequence and the span, not the per-GPU batch; "
                          "16 x 2048 tokens use 100 of the 288 GB and amortise the once-per-step costs (optimizer pass, launch ramps) over "
                          "twice the tokens of rounds 1-3's 8 (same-box sweep, profiles/r04_logs/batch_sweep.log: 8 / 12 / 16 / 24 -> 97.3 k / "

@@ -1,20 +1,37 @@
-"""GPU: the kernels at BASELINE configs[1] sizes (Molly-1.7B, 8 x 2048 tokens) through size-independent properties —
-sampled rows of every GEMM shape of the step against fp32 matmul, run-to-run bitwise determinism of the whole step (no
-atomics anywhere), gradient accumulation = sum, and the algorithmic invariants of attention and the norms."""
+"""GPU: the kernels at BASELINE configs[1] sizes (Molly-1.7B, T = 2048) through size-independent properties — sampled rows of every
+GEMM shape of the step against fp32 matmul, run-to-run bitwise determinism of the whole step (no atomics anywhere), gradient
+accumulation = sum, and the algorithmic invariants of attention and the norms — at the batch the headline TIMES (bench.py's default,
+imported, not restated: VERDICT r04 'the benchmarked shape is not the tested shape') and at rounds 1-3's 8 samples."""
+import os
+import sys
+
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import DEFAULT_BATCH  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 M = 16384
+BATCHES = sorted({8, DEFAULT_BATCH})
+SCORED = lambda b: b * 2048 // 4                                 # rows the lm_head sees: 25 % of the tokens carry a label
 
 
-@pytest.mark.parametrize("name,form,m,n,k", [
-    ("qkv fwd", "nt", M, 4096, 2048), ("gate|up fwd", "nt", M, 12288, 2048), ("down fwd", "nt", M, 2048, 6144),
-    ("lm_head fwd (scored rows)", "nt", 4096, 151936, 2048), ("qkv dgrad", "nn", M, 2048, 4096),
-    ("down dgrad", "nn", M, 6144, 2048), ("lm_head dgrad", "nn", 4096, 2048, 151936),
-    ("gate|up wgrad", "tn", 12288, 2048, M), ("lm_head wgrad", "tn", 151936, 2048, 4096),
-    ("qkv wgrad (transposed narrow operand, transposed output)", "to", 4096, 2048, M)])
+def _gemm_cases():
+    out = []
+    for b in BATCHES:
+        m, ms = b * 2048, SCORED(b)
+        out += [(f"B{b} qkv fwd", "nt", m, 4096, 2048), (f"B{b} o fwd", "nt", m, 2048, 2048), (f"B{b} gate|up fwd", "nt", m, 12288, 2048),
+                (f"B{b} down fwd", "nt", m, 2048, 6144), (f"B{b} lm_head fwd (scored rows)", "nt", ms, 151936, 2048),
+                (f"B{b} qkv dgrad", "nn", m, 2048, 4096), (f"B{b} o dgrad", "nn", m, 2048, 2048), (f"B{b} gate|up dgrad", "nn", m, 2048, 12288),
+                (f"B{b} down dgrad", "nn", m, 6144, 2048), (f"B{b} lm_head dgrad", "nn", ms, 2048, 151936),
+                (f"B{b} gate|up wgrad", "tn", 12288, 2048, m), (f"B{b} lm_head wgrad", "tn", 151936, 2048, ms),
+                (f"B{b} qkv wgrad (transposed narrow operand, transposed output)", "to", 4096, 2048, m)]
+    return out
+
+
+@pytest.mark.parametrize("name,form,m,n,k", _gemm_cases())
 def test_step_gemm_shapes_sampled_rows_vs_fp32(name, form, m, n, k):
     from molly_amd import ops
     ops.ensure_gemm_workspace(1 << 30)
@@ -42,6 +59,41 @@ def test_step_gemm_shapes_sampled_rows_vs_fp32(name, form, m, n, k):
     assert err <= 1.5e-2 * ref.abs().max().item(), (name, err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("batch", BATCHES)
+def test_grouped_weight_gradient_launch_sampled_rows_vs_fp32(batch):
+    """The four weight gradients of a decoder layer as the step launches them: ONE grouped launch over (transposed narrow operand,
+    wide operand, output, orientation) with the remainder tiles carved out by qwen3._carve_remainder when the tile count is a few
+    past whole rounds of the 256 CUs — at the headline's token count.  Sampled output rows of every problem against fp32."""
+    from molly_amd import ops
+    from molly_amd.qwen3 import _carve_remainder
+    ops.ensure_gemm_workspace(1 << 30)
+    Mt = batch * 2048
+    g = torch.Generator(device="cuda").manual_seed(batch)
+    rnd = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).bfloat16()
+    # (dy width N, x width K) of qkv, o, gate|up, down at Qwen3-1.7B: the narrower operand is the one transposed
+    probs, refs = [], []
+    for n, k in ((4096, 2048), (2048, 2048), (12288, 2048), (2048, 6144)):
+        dy, x = rnd(Mt, n), rnd(Mt, k)
+        dw = torch.full((n, k), 7.0, dtype=BF, device="cuda")
+        if k <= n:
+            probs.append((x.t().contiguous(), dy, dw, True))         # dw^T[K, N] = x^T dy, stored transposed into dw
+        else:
+            probs.append((dy.t().contiguous(), x, dw, False))        # dw[N, K] = dy^T x
+        refs.append((dy, x, dw))
+    new, carved = _carve_remainder(list(probs))
+    ops.gemm_grouped(new, accumulate=False)
+    if carved is not None:
+        a, b, out, to = carved
+        ops.gemm(a, b, out=out, accumulate=False, b_kmajor=True, trans_out=to)
+    torch.cuda.synchronize()
+    for dy, x, dw in refs:
+        rows = torch.randint(0, dw.shape[0], (32,), generator=torch.Generator().manual_seed(dw.shape[0])).cuda()
+        rows[-1] = dw.shape[0] - 1                                   # the last tile row (where a carve would sit)
+        ref = dy[:, rows].float().t() @ x.float()
+        err = (dw[rows].float() - ref).abs().max().item()
+        assert err <= 1.5e-2 * ref.abs().max().item(), (tuple(dw.shape), err, ref.abs().max().item())
+
+
 def _molly_17b():
     import molly_amd
     from molly_amd import config as C
@@ -54,10 +106,11 @@ def _molly_17b():
     return m
 
 
-def test_full_size_step_is_bitwise_deterministic_and_accumulation_adds():
+@pytest.mark.parametrize("batch", BATCHES)
+def test_full_size_step_is_bitwise_deterministic_and_accumulation_adds(batch):
     from molly_amd.synth import synth_batch
     m = _molly_17b()
-    b = synth_batch(8, 2048, [("protein", 512)], seed=42)
+    b = synth_batch(batch, 2048, [("protein", 512)], seed=42)
     args = [b[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")]
     l1 = m.forward_backward(*args).clone()
     g1 = m._rt.G.flat.clone()

@@ -155,6 +155,17 @@ def test_bench_launches_its_own_ranks_end_to_end():
     t = c["timings_us"]
     assert t["reduce_scatter"]["n"] == 2 * c["buckets"] and t["all_gather"]["n"] == 2 * c["buckets"]          # 2 timed steps
     assert len(t["reduce_scatter"]["us_per_bucket"]) == c["buckets"] and t["all_gather"]["us_p50"] > 0
+    # round 5: the bucket size x reduce-scatter algorithm sweep before the warm-up (every candidate rebuilt the optimizer and ran on
+    # both ranks), the layout the timed region ran with, and what the overlap left exposed (same steps with no exchange at all)
+    ab = c["bucket_ab"]
+    assert set(ab["ms_per_step"]) == {f"{m}/{a}" for m in ("64", "128", "256", "512", "1024") for a in ("rccl", "a2a")}
+    ok = {k: v for k, v in ab["ms_per_step"].items() if v is not None}
+    assert len(ok) >= 5 and all(v > 0 for v in ok.values()), ab
+    ch = ab["chosen"]
+    assert ch["key"] in ok and ok[ch["key"]] == min(ok.values()) and c["rs_algo"] == ch["rs_algo"]
+    assert abs(c["bucket_mib"] - ch["bucket_mib"]) < 1.0, (c["bucket_mib"], ch)
+    assert c["step_ms_p50_no_exchange"] > 0 and "exposed_comm_ms" in c
+    assert d["batch8_reference"] is None                          # (N > 1: no batch-8 continuity figure)
 
 
 def test_four_ranks_contend_for_one_chip():
@@ -170,7 +181,8 @@ def test_four_ranks_contend_for_one_chip():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MOLLY_GEMM_PERSISTENT_MULTI")}
     env.update(MOLLY_BENCH_DEVICE="0", MOLLY_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--batch", "2",
-                        "--seq", "1024", "--k-protein", "256", "--exposed-comm-steps", "0", "--gemm-mode-ab-steps", "1", "--bucket-mib", "64"],
+                        "--seq", "1024", "--k-protein", "256", "--exposed-comm-steps", "0", "--gemm-mode-ab-steps", "1",
+                        "--bucket-ab-mib", "64,1024", "--bucket-ab-steps", "1"],
                        capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -178,9 +190,31 @@ def test_four_ranks_contend_for_one_chip():
     d = json.loads(lines[0])
     c = d["comm"]
     assert d["n_gpus"] == 4 and c["world_size"] == 4 and c["world_size_by_all_reduce"] == 4 and d["config"]["global_batch"] == 8
-    assert c["buckets"] >= 7 and c["overlap"] is True                       # 3.4 GB of bf16 in 64 MiB buckets
+    # round 5: the sweep rehearsed at world 4 (two sizes x two algorithms, one timed step each), the winner's layout in the timed region
+    ab = c["bucket_ab"]
+    assert set(ab["ms_per_step"]) == {"64/rccl", "1024/rccl", "64/a2a", "1024/a2a"} and ab["chosen"]["key"] in ab["ms_per_step"]
+    assert c["buckets"] >= (7 if ab["chosen"]["bucket_mib"] == 64 else 3) and c["overlap"] is True   # 3.4 GB of bf16 in 64 MiB | 1 GiB buckets
     assert set(c["gemm_mode_ab"]["ms_per_step"]) == {"-3", "dyn", "0"}
     assert 0.5 < d["loss"] < 20.0                                           # the step still trains (random-init CE ~ ln V = 11.9)
+
+
+def test_failed_bring_up_prints_one_json_line_and_exits_non_zero():
+    """a communication bring-up that fails ends the run from a fresh state — ONE JSON line carrying the error on
+    stdout, exit code != 0, nothing retried (never a re-exec of a GPU-initialised process).  Provoked here with a backend name
+    torch.distributed does not know."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MOLLY_BENCH_DEVICE="0", MOLLY_DIST_BACKEND="no_such_backend")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "init_process_group" in d["error"], d
 
 
 def _rccl_world1_worker(rank, port, ret):
