@@ -170,6 +170,23 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based — the output is a pure
 // function of (counter, key), so nothing has to be stored to regenerate it.
+// ROUNDS: 10 is the generator's standard form; the dropout kernels take it as a build knob (MOLLY_DROPOUT_PHILOX_ROUNDS: 7 — the fewest
+// rounds the paper lists as passing BigCrush — measured no faster there in round 5, the fused LoRA kernels are HBM-bound).
+template <int ROUNDS = 10>
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t (&out)[4]) {
 #pragma unroll

@@ -608,6 +608,34 @@ def dropout(x, p: float, seed: int, out=None, accumulate=False):
     return out
 
 
+def lora_down_drop(x, A, p: float, seed: int, scale: float = 1.0, xd=None, out=None):
+    """t[M, R] = scale * (dropout(x) A^T) in one launch (molly_lora_down_drop_bf16); xd (optional, [M, K]) receives dropout(x).
+    The mask is molly_dropout_bf16's function of (seed, flat element index)."""
+    _chk(x, BF16, "x"); _chk(A, BF16, "A")
+    assert x.is_contiguous() and A.is_contiguous() and x.shape[1] == A.shape[1]
+    M, K = x.shape
+    R = A.shape[0]
+    if out is None:
+        out = torch.empty(M, R, dtype=BF16, device=x.device)
+    assert out.shape == (M, R) and out.stride(1) == 1
+    if xd is not None:
+        assert xd.is_contiguous() and xd.shape == x.shape and xd.dtype == BF16
+    lib().call("molly_lora_down_drop_bf16", _stream(), x, A, xd, out, M, K, R, out.stride(0), float(p), int(seed) & ((1 << 64) - 1),
+               float(scale))
+    return out
+
+
+def lora_up_drop_acc(dt, A, dx, p: float, seed: int):
+    """dx[M, K] += mask * bf16(dt[M, R] A[R, K]) in one launch (molly_lora_up_drop_acc_bf16): the LoRA branch's input gradient."""
+    _chk(dt, BF16, "dt"); _chk(A, BF16, "A"); _chk(dx, BF16, "dx")
+    assert A.is_contiguous() and dx.is_contiguous() and dt.stride(1) == 1
+    M, R = dt.shape
+    K = A.shape[1]
+    assert A.shape[0] == R and dx.shape == (M, K)
+    lib().call("molly_lora_up_drop_acc_bf16", _stream(), dt, A, dx, M, K, R, dt.stride(0), float(p), int(seed) & ((1 << 64) - 1))
+    return dx
+
+
 def scale_(x, s: float):
     _chk(x, BF16, "x")
     assert x.is_contiguous()

@@ -27,6 +27,9 @@ from .lora import TARGETS as LORA_TARGETS
 from .params import FlatBuffer
 
 BF16 = torch.bfloat16
+# LoRA training: dropout fused into the two rank-r contractions next to it (csrc/lora.hip, round 5); MOLLY_LORA_FUSED=0 restores the
+# stand-alone dropout launches + GEMMs (same masks: A/B runs and the comparison in tests/test_gpu_lora.py)
+_LORA_FUSED = os.environ.get("MOLLY_LORA_FUSED", "1") != "0"
 
 
 def _ceil(a, b):
@@ -275,9 +278,13 @@ class Qwen3Engine:
         """y += s * (dropout(x) A^T) B^T; keeps t = s * dropout(x) A^T for the backward."""
         lo = self.lora
         t = a["lt"][mod]
-        ops.gemm_nt(self._lora_xd(i, a, mod, x, training), lo.A[i][mod], out=t)
-        if lo.scale != 1.0:
-            ops.scale_(t, lo.scale)
+        if training and lo.p > 0.0 and _LORA_FUSED and lo.rp == 64 and x.shape[1] % 64 == 0:
+            # dropout, the rank-r down-projection and the alpha / r scaling in one launch; dropout(x) is written on the way (dA reads it)
+            ops.lora_down_drop(x, lo.A[i][mod], lo.p, lo.mask_seed(i, mod), lo.scale, xd=a["lxd"][mod], out=t)
+        else:
+            ops.gemm_nt(self._lora_xd(i, a, mod, x, training), lo.A[i][mod], out=t)
+            if lo.scale != 1.0:
+                ops.scale_(t, lo.scale)
         ops.gemm_nt(t, lo.B[i][mod], out=y, accumulate=True)
 
     def _lora_bwd(self, i: int, a: dict, mod: str, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool):
@@ -302,7 +309,9 @@ class Qwen3Engine:
             self._pend.append((dtt, xd, lo.dA[i][mod], False))         # dA[rp, in] = dt^T dropout(x)
         else:
             self._wgrad(dt, xd, lo.dA[i][mod], accumulate)
-        if lo.p > 0.0:
+        if lo.p > 0.0 and _LORA_FUSED and lo.rp == 64 and x.shape[1] % 128 == 0 and dx.is_contiguous():
+            ops.lora_up_drop_acc(dt, lo.A[i][mod], dx, lo.p, lo.mask_seed(i, mod))       # dx += mask * (dt A): one launch
+        elif lo.p > 0.0:
             tmp = self.lora_tmp[:M * x.shape[1]].view(M, x.shape[1]) if grouped else xd   # (ungrouped: dropout(x) is dead by now)
             ops.gemm(dt, lo.A[i][mod], out=tmp, b_kmajor=True)
             ops.dropout(tmp, lo.p, lo.mask_seed(i, mod), out=dx, accumulate=True)

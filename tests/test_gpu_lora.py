@@ -118,6 +118,58 @@ def test_dropout_kernel():
     assert torch.equal(y, (x.float() * 0.25).bfloat16())
 
 
+@pytest.mark.parametrize("M,K,scale", [(300, 256, 2.0), (4096, 2048, 1.0), (1000, 6144, 0.5)])
+def test_fused_lora_down_projection_equals_dropout_then_gemm(M, K, scale):
+    """molly_lora_down_drop_bf16 (round 5): t = scale * dropout(x) A^T and xd = dropout(x) in one launch against the three launches it
+    replaces — the mask is the same function of (seed, element index), so xd is bit-identical; t differs by the fp32 summation
+    order and by ONE rounding instead of two (GEMM output, then scale)."""
+    from molly_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    A = (torch.randn(64, K, device="cuda", generator=g) / 8).bfloat16()
+    p, seed = 0.05, (7 << 32) | 12345
+    xd_ref = ops.dropout(x, p, seed)
+    t_ref = ops.gemm_nt(xd_ref, A)
+    if scale != 1.0:
+        ops.scale_(t_ref, scale)
+    xd = torch.full_like(x, 3.0)
+    t = ops.lora_down_drop(x, A, p, seed, scale, xd=xd)
+    torch.cuda.synchronize()
+    assert torch.equal(xd, xd_ref)
+    exact = (xd_ref.float() @ A.float().t()) * scale
+    tol = 2 ** -7 * exact.abs() + 2 ** -7 * exact.abs().max() * 0.05
+    assert bool(((t.float() - exact).abs() <= tol).all()), (t.float() - exact).abs().max().item()
+    assert bool(((t.float() - t_ref.float()).abs() <= 2 * tol).all())
+    t2 = ops.lora_down_drop(x, A, p, seed, scale)                # without the side output: same t
+    assert torch.equal(t, t2)
+
+
+@pytest.mark.parametrize("M,K", [(300, 256), (2048 + 17, 2048), (512, 6144)])
+def test_fused_lora_input_gradient_equals_gemm_then_masked_accumulate(M, K):
+    """molly_lora_up_drop_acc_bf16 (round 5): dx += mask * bf16(dt A) in one launch against GEMM + dropout-accumulate: the same mask,
+    the product rounded to bf16 before the mask in both, so the results agree except where the fp32 summation order moved a
+    rounding (a bf16 ulp of the product on a few elements)."""
+    from molly_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M * 3 + K)
+    dt = (torch.randn(M, 64, device="cuda", generator=g) / 4).bfloat16()
+    A = (torch.randn(64, K, device="cuda", generator=g) / 4).bfloat16()
+    base = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    p, seed = 0.05, (3 << 32) | 777
+    tmp = ops.gemm(dt, A, b_kmajor=True)
+    ref = base.clone()
+    ops.dropout(tmp, p, seed, out=ref, accumulate=True)
+    got = base.clone()
+    ops.lora_up_drop_acc(dt, A, got, p, seed)
+    torch.cuda.synchronize()
+    keep = ops.dropout(torch.ones_like(tmp), p, seed) != 0
+    assert torch.equal(got[~keep], base[~keep])                  # dropped elements: dx untouched
+    d = (got.float() - ref.float()).abs()
+    assert (d > 0).float().mean().item() < 2e-2, (d > 0).float().mean().item()
+    assert bool((d <= 2 ** -6 * (tmp.float().abs() + base.float().abs()) + 1e-6).all()), d.max().item()
+    exact = base.float() + keep.float() * (dt.float() @ A.float()) / (1 - p)
+    assert bool(((got.float() - exact).abs() <= 2 ** -6 * exact.abs() + 2 ** -6 * (dt.float() @ A.float()).abs() + 1e-3).all())
+
+
 def test_lora_forward_backward_vs_oracle(tiny_meta):
     """r = 8 (padded to 64), alpha = 16 (scaling 2), no dropout: loss and every adapter / projector gradient against
     the oracle's autograd; GA semantics (accumulate=True adds)."""

@@ -65,7 +65,7 @@ def check(src):
 
 def main():
     total, bad = 0, []
-    for src in ("gemm.hip", "attention.hip"):
+    for src in ("gemm.hip", "attention.hip", "lora.hip"):
         n, b = check(src)
         total += n
         bad += b
