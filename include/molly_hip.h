@@ -180,6 +180,9 @@ int molly_transpose_bf16(void* stream, const void* in, void* out, int R, int C, 
  * bwd: dx = norm-backward(g) (+ dres, the residual-branch gradient, fused); dw (+)= sum_rows g*xhat, reduced
  * deterministically through `workspace` (molly_rmsnorm_bwd_blocks(rows) * H floats). */
 int molly_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* rstd_or_null, int rows, int H, float eps);
+/* the same forward with a TRANSPOSED second store: yT[H][ld_t] (ld_t >= rows) = y^T — the k-contiguous operand the weight-gradient GEMM
+ * of the projection behind the norm wants (it replaces a molly_transpose_bf16 launch per operand).  rows % 64 == 0, H % 512 == 0, H <= 2048. */
+int molly_rmsnorm_fwd_t(void* stream, const void* x, const void* w, void* y, void* yT, int rows, int H, int ld_t, float eps);
 int molly_rmsnorm_bwd_blocks(int rows);
 int molly_rmsnorm_bwd(void* stream, const void* x, const void* w, const void* g, const void* dres_or_null, void* dx,
                       void* dw, int dw_f32, int dw_accumulate, float* workspace, int rows, int H, float eps);
@@ -331,6 +334,11 @@ int molly_cast_bf16_to_f32(void* stream, const void* in, float* out, long n);
 int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2, const int* kv_lo,
                    const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv,
                    int ldo, float scale, int causal);
+/* the same forward with O stored a second time TRANSPOSED, OT[n_heads * head_dim][ldot >= B * T] = O^T (the k-contiguous operand of the
+ * o-projection's weight gradient: replaces a molly_transpose_bf16 launch per layer).  head_dim 64 | 128, T % 128 == 0. */
+int molly_attn_fwd_ot(void* stream, const void* Q, const void* K, const void* V, void* O, void* OT, float* lse2, const int* kv_lo,
+                      const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv, int ldo,
+                      int ldot, float scale, int causal);
 
 /* backward of molly_attn_fwd (what autograd runs through flash-attn's backward in the reference).  Recomputes P from
  * Q, K and lse2; writes dQ [.., n_heads*hd], dK/dV [.., n_kv_heads*hd] (GQA group already summed), bitwise

@@ -36,6 +36,7 @@ struct AttnArgs {
     int nblk, order_set;                     // block order (block_item): query blocks per head, (batch, kv head) pairs walked together
     int prio;                                // wave_priority(): 0 none, n: the odd wave slot of every SIMD runs at priority n
     int stagger;                             // attn_fwd_pipe_kernel: waves 4-7 one step behind waves 0-3 (MOLLY_ATTN_PIPE_STAGGER, default 1)
+    bf16_t* OT; int ldot;                    // attn_fwd_kernel: O a second time, transposed [nh * hd][ldot >= B * T] (nullable) — the o-projection's weight-gradient operand
     int* redo;                               // fixed-reference forward (QB 2): *redo = seq when some row's maximum outgrew its reference;
     int seq;                                 // attn_fwd_kernel launched behind it returns at once unless *redo == seq (nullptr: always runs)
 };
@@ -249,6 +250,28 @@ __device__ __forceinline__ void store_rows(bf16_t* slab, const f32x16 (&acc)[ND]
                     u32x2{pack_bf2(acc[d][4 * g4] * mul, acc[d][4 * g4 + 1] * mul), pack_bf2(acc[d][4 * g4 + 2] * mul, acc[d][4 * g4 + 3] * mul)};
     }
 #endif
+}
+
+// The rows store_rows has just parked in the wave's slab, a second time TRANSPOSED: dstT[col][0 .. 31] for the slab's HD columns (the
+// caller points dstT at column 0 / the wave's first row).  The slab is read back through ds_read_b64_tr_b16 the way transpose64_kernel
+// reads its tile (elementwise.hip): a 16-lane group takes 4 rows x 16 columns, a lane ends up with 8 consecutive rows of one column —
+// 16 bytes of an output row; four groups = 64 contiguous bytes of each of 16 output rows per instruction.  Every one of the 32 rows
+// must be valid (the host checks T % 128 == 0).  Replaces one transpose launch per layer (the o-projection's weight gradient reads
+// attn^T): round 5.
+template <int HD>
+__device__ __forceinline__ void store_rows_t(const bf16_t* slab, bf16_t* dstT, size_t ldT, int lane) {
+    constexpr int PITCH = HD + 8;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int rr = g * 8;
+#pragma unroll
+    for (int oc = 0; oc < HD; oc += 16) {
+        const bf16_t* pa = slab + (rr + q) * PITCH + oc + 4 * pp;
+        const bf16_t* pb = slab + (rr + 4 + q) * PITCH + oc + 4 * pp;
+        const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
+        const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
+        const bf16x8 v = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        *reinterpret_cast<bf16x8*>(dstT + (size_t)(oc + i) * ldT + rr) = v;
+    }
 }
 
 // max over the two half-waves' copies of a row statistic without an LDS round trip: after the swap `a` holds the lower half's
@@ -515,6 +538,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     store_rows<HD, ND>(smem + wave * 32 * (HD + 8), o, inv, p.O + ((size_t)b * T + q0) * p.ldo + head * HD, p.ldo, T - q0, lane);
+    if (MOLLY_ATTN_ROWS_VIA_LDS && p.OT)
+        store_rows_t<HD>(smem + wave * 32 * (HD + 8), p.OT + (size_t)(head * HD) * p.ldot + (size_t)b * T + q0, (size_t)p.ldot, lane);
     if (qi < T && p.LSE && h == 0)
         p.LSE[((size_t)b * p.nh + head) * T + qi] = l_tot > 0.f ? m_run + log2f(l_tot) : -INFINITY;
 #if MOLLY_ATTN_STAMP
@@ -1526,9 +1551,9 @@ static bool attr_set_fwd() {
     return true;
 }
 
-extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
+static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
                               const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim,
-                              int ldq, int ldk, int ldv, int ldo, float scale, int causal) {
+                              int ldq, int ldk, int ldv, int ldo, float scale, int causal, void* OT, int ldot) {
     MOLLY_ENTER();
     MOLLY_CHECK(head_dim == 128 || head_dim == 64 || head_dim == 16 || head_dim == 32 || head_dim == 8 || head_dim == 24 ||
                     head_dim == 40 || head_dim == 48,
@@ -1540,7 +1565,12 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     MOLLY_CHECK(B > 0 && T > 0, "attn_fwd: empty problem");
     AttnArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, lse2, kv_lo, kv_hi, T, n_heads,
                n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal, cdiv(T, BQ), order_set(0, B * n_kv_heads), wave_prio(),
-               [] { const char* e = getenv("MOLLY_ATTN_PIPE_STAGGER"); return e ? atoi(e) : 1; }(), nullptr, 0};
+               [] { const char* e = getenv("MOLLY_ATTN_PIPE_STAGGER"); return e ? atoi(e) : 1; }(), (bf16_t*)OT, ldot, nullptr, 0};
+    if (OT) {
+        MOLLY_CHECK(head_dim == 128 || head_dim == 64, "attn_fwd: the transposed second store is built for head dims 64 and 128");
+        MOLLY_CHECK(T % 128 == 0 && ldot >= B * T && ldot % 8 == 0 && ((uintptr_t)OT % 16) == 0,
+                    "attn_fwd: transposed store needs T %% 128 == 0 (T=%d), ldot=%d >= B*T, 16-byte alignment", T, ldot);
+    }
     if (head_dim < 64) {
         const dim3 g(n_heads * B, cdiv(T, 128));
 #define MOLLY_SMALL(HD_) case HD_: hipLaunchKernelGGL(attn_fwd_small_kernel<HD_>, g, dim3(128), 0, (hipStream_t)stream, p); break
@@ -1554,7 +1584,7 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
     {
         const char* e = getenv("MOLLY_ATTN_FWD_PIPE");
         const int nw = e ? atoi(e) : 0;
-        if (head_dim == 128 && (nw == 4 || nw == 8)) {
+        if (head_dim == 128 && (nw == 4 || nw == 8) && !OT) {
             static bool pipe_attr = false;
             if (!pipe_attr) {
                 (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
@@ -1600,6 +1630,17 @@ extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const 
         hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, p);
     MOLLY_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int molly_attn_fwd(void* stream, const void* Q, const void* K, const void* V, void* O, float* lse2,
+                              const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim,
+                              int ldq, int ldk, int ldv, int ldo, float scale, int causal) {
+    return attn_fwd_impl(stream, Q, K, V, O, lse2, kv_lo, kv_hi, B, T, n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, causal, nullptr, 0);
+}
+extern "C" int molly_attn_fwd_ot(void* stream, const void* Q, const void* K, const void* V, void* O, void* OT, float* lse2,
+                                 const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim,
+                                 int ldq, int ldk, int ldv, int ldo, int ldot, float scale, int causal) {
+    return attn_fwd_impl(stream, Q, K, V, O, lse2, kv_lo, kv_hi, B, T, n_heads, n_kv_heads, head_dim, ldq, ldk, ldv, ldo, scale, causal, OT, ldot);
 }
 
 #if MOLLY_ATTN_STAMP

@@ -107,6 +107,81 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
     }
 }
 
+// ---- a block's 64 rows, written a second time TRANSPOSED (round 5).  The weight-gradient GEMMs want their narrow operand with the
+// token index contiguous (dW^T = x^T dy with x^T k-contiguous), which cost one 5 TB/s transpose launch per operand and
+// layer — 113 per step, 5.6 ms at 16 x 2,048 tokens, each re-reading a tensor its producer had just had in registers.  The producer
+// now stores it both ways: the block keeps its 64 rows' results in registers (8 waves x 8 rows x NC 16-byte chunks), and per panel of
+// 512 columns every wave puts its rows into an LDS tile [64][512 + pad], the tile is read back through ds_read_b64_tr_b16 exactly as
+// transpose64_kernel reads its own, and leaves as whole 128-byte lines of the [H][rows] image.
+constexpr int TP_COLS = 512, TP_PITCH = TP_COLS + 72;       // elements; 1,168-byte rows: 16-byte aligned, the transposed reads of transpose64_kernel's pitch class
+// tile: [64][TP_PITCH]; the calling wave's rows 8 w .. 8 w + 7 hold o[j] = columns 8 lane .. 8 lane + 7 of the panel.  out_t = &yT[panel col 0][row0].
+__device__ __forceinline__ void panel_transpose_store(bf16_t* tile, const u32x4 (&o)[8], bf16_t* __restrict__ out_t, size_t ld_t, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(tile + (8 * wave + j) * TP_PITCH + 8 * lane) = o[j];
+    __syncthreads();
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {                       // this wave's 64 panel columns, 16 at a time
+        const int oc = 64 * wave + 16 * cb;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int rr = pass * 32 + g * 8;              // 8 tile rows -> 8 consecutive output columns
+            const bf16_t* pa = tile + (rr + q) * TP_PITCH + oc + 4 * pp;
+            const bf16_t* pb = tile + (rr + 4 + q) * TP_PITCH + oc + 4 * pp;
+            const bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pa);
+            const bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)pb);
+            const bf16x8 v = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+            *reinterpret_cast<bf16x8*>(out_t + (size_t)(oc + i) * ld_t + rr) = v;
+        }
+    }
+    __syncthreads();                                       // the tile is free for the next panel
+}
+
+// RMSNorm forward with the transposed second store: y [rows][H] and yT [H][ld_t] (ld_t >= rows).  rows % 64 == 0, H % 512 == 0.
+template <int NC>
+__global__ __launch_bounds__(512) void rmsnorm_fwd_t_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                            bf16_t* __restrict__ yT, int ld_t, int H, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char tp_smem[];
+    bf16_t* tile = reinterpret_cast<bf16_t*>(tp_smem);
+    // (wave index made provably uniform: the row pointers are then scalar + one 32-bit lane offset; as a vector value hipcc kept a
+    // 64-bit address pair per row, chunk and tensor — 192 registers in the backward form — and spilled)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = blockIdx.x * 64;
+    const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+    u32x4 o[NC][8];                                            // [chunk = panel][row of the wave]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = row0 + 8 * wave + j;
+        const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)row * H);
+        u32x4 v[NC];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            v[i] = ld_stream<u32x4>(xr + lane + i * 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bflo(v[i][e]), b = bfhi(v[i][e]);
+                ss += a * a + b * b;
+            }
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)H + eps);
+        u32x4* yr = reinterpret_cast<u32x4*>(y + (size_t)row * H);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const u32x4 wv = wr[lane + i * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t t = pack_bf2(bflo(v[i][e]) * rstd, bfhi(v[i][e]) * rstd);     // HF: round, then the gain
+                o[i][j][e] = pack_bf2(bflo(t) * bflo(wv[e]), bfhi(t) * bfhi(wv[e]));
+            }
+            st_stream<u32x4>(yr + lane + i * 64, o[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) panel_transpose_store(tile, o[i], yT + (size_t)(i * TP_COLS) * ld_t + row0, (size_t)ld_t, wave, lane);
+}
+
 // backward: dx = rstd*(g*w - xhat*mean(g*w*xhat)) (+dres) ; dw partial per block (fp32) -> workspace[nblk][H]
 // persistent over rows: block b handles rows b*4+wave, stride gridDim*4
 template <int NC>
@@ -194,6 +269,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
 }
 
+// (The BACKWARD with a transposed second store of dx — the down-projection's weight-gradient operand — was built the same way and
+// removed in round 5: eight rows of dx held in registers beside the row's x, g, residual and the 32 gain-gradient accumulators is
+// 228 live registers by count and 514 spilled ones as hipcc compiles it, 8 ms SLOWER per step than norm + transpose launch; the
+// two-phase form that fits re-reads x and g and would have saved 0.6 ms.)
 // out[j] (+)= sum_b part[b][j]  — deterministic column reduce of block partials.
 // block = 32 columns x 8 row groups (fixed summation tree), grid = H/32 blocks
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int nb, int H, int row_stride,
@@ -1182,6 +1261,26 @@ extern "C" int molly_rmsnorm_fwd(void* stream, const void* x, const void* w, voi
                        (bf16_t*)y, rstd, rows, H, eps)
     NC_DISPATCH(H, RMS_FWD);
 #undef RMS_FWD
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int molly_rmsnorm_fwd_t(void* stream, const void* x, const void* w, void* y, void* yT, int rows, int H, int ld_t, float eps) {
+    MOLLY_ENTER();
+    MOLLY_CHECK(rows > 0 && rows % 64 == 0 && H % 512 == 0 && H <= 2048, "rmsnorm_fwd_t: rows=%d (a multiple of 64) H=%d (a multiple of 512, <= 2048)", rows, H);
+    MOLLY_CHECK(ld_t >= rows && ld_t % 8 == 0 && ((uintptr_t)yT % 16) == 0, "rmsnorm_fwd_t: ld_t=%d / alignment", ld_t);
+    const size_t lds = 64 * TP_PITCH * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)rmsnorm_fwd_t_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)rmsnorm_fwd_t_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)rmsnorm_fwd_t_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)rmsnorm_fwd_t_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+#define RMS_FWD_T(NC) hipLaunchKernelGGL(rmsnorm_fwd_t_kernel<NC>, dim3(rows / 64), dim3(512), lds, ST, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (bf16_t*)yT, ld_t, H, eps)
+    switch (H / 512) { case 1: RMS_FWD_T(1); break; case 2: RMS_FWD_T(2); break; case 3: RMS_FWD_T(3); break; default: RMS_FWD_T(4); break; }
+#undef RMS_FWD_T
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -297,12 +297,22 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
     return out
 
 
-def rmsnorm_fwd(x, w, eps, out=None):
+def rmsnorm_fwd_t_supported(rows: int, H: int) -> bool:
+    return rows % 64 == 0 and H % 512 == 0 and H <= 2048
+
+
+def rmsnorm_fwd(x, w, eps, out=None, out_t=None):
+    """out_t (optional, [H, rows] contiguous): the result a second time, transposed (molly_rmsnorm_fwd_t) — what the weight gradient of
+    the projection behind the norm reads as its k-contiguous operand."""
     _chk(x, BF16, "x")
     rows, H = x.shape
     assert x.is_contiguous()
     if out is None:
         out = torch.empty_like(x)
+    if out_t is not None:
+        assert out_t.dtype == BF16 and out_t.shape == (H, rows) and out_t.stride(1) == 1 and rmsnorm_fwd_t_supported(rows, H)
+        lib().call("molly_rmsnorm_fwd_t", _stream(), x, w, out, out_t, rows, H, out_t.stride(0), float(eps))
+        return out
     lib().call("molly_rmsnorm_fwd", _stream(), x, w, out, None, rows, H, float(eps))
     return out
 
@@ -424,14 +434,20 @@ def gelu_bwd(z, dout, dz=None):
     return dz
 
 
-def attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, kv_lo=None, kv_hi=None, out=None, lse=None):
-    """q/k/v: 2-D views [B*T, *] whose row holds the heads of one token (head h at column h*hd)."""
+def attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, kv_lo=None, kv_hi=None, out=None, lse=None, out_t=None):
+    """q/k/v: 2-D views [B*T, *] whose row holds the heads of one token (head h at column h*hd).
+    out_t (optional, [nh * hd, B * T] contiguous, T % 128 == 0): the output a second time, transposed (molly_attn_fwd_ot)."""
     if out is None:
         out = torch.empty((B * T, nh * hd), dtype=BF16, device=q.device)
     if lse is None:
         lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
     elif lse is False:          # caller does not need the log-sum-exp (forward-only encoders)
         lse = None
+    if out_t is not None:
+        assert out_t.dtype == BF16 and out_t.shape == (nh * hd, B * T) and out_t.stride(1) == 1
+        lib().call("molly_attn_fwd_ot", _stream(), q, k, v, out, out_t, lse, kv_lo, kv_hi, B, T, nh, nkv, hd, q.stride(0), k.stride(0),
+                   v.stride(0), out.stride(0), out_t.stride(0), float(scale), int(causal))
+        return out, lse
     lib().call("molly_attn_fwd", _stream(), q, k, v, out, lse, kv_lo, kv_hi, B, T, nh, nkv, hd, q.stride(0), k.stride(0),
                v.stride(0), out.stride(0), float(scale), int(causal))
     return out, lse

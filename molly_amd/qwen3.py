@@ -166,6 +166,17 @@ class Qwen3Engine:
                     # four, stays ungrouped: 396.6 against 398.7 grouped.  MOLLY_GROUPED_WGRAD=2 forces it for an A/B)
                     if ((split >= 3 or (split >= 2 and M <= 4096)) and eff(sum(per)) >= 0.85) or os.environ.get("MOLLY_GROUPED_WGRAD") == "2":
                         self.tTg = [e(min(n, k) * M) for n, k in dims]
+                        # round 5: the two RMSNorm outputs of a layer are stored a second time, TRANSPOSED, by the norm kernel itself
+                        # (molly_rmsnorm_fwd_t): the q|k|v and gate|up weight gradients read that instead of a transpose launch's
+                        # output (2 x 2 bytes x M x h per layer of extra saved activations: 7.5 GB at 16 x 2,048 tokens of Molly-1.7B)
+                        if (h <= self.nqkv and h <= 2 * ff and ops.rmsnorm_fwd_t_supported(M, h)
+                                and os.environ.get("MOLLY_NORM_TRANSPOSED_STORE", "1") != "0"):
+                            for a in self.A:
+                                a["xnT"], a["xn2T"] = e(h, M), e(h, M)
+                            # ... and the attention forward its output (the o-projection's weight gradient reads attn^T)
+                            if self.nh * self.hd <= h and T % 128 == 0 and self.hd in (64, 128):
+                                for a in self.A:
+                                    a["attnT"] = e(self.nh * self.hd, M)
             if not self.train_base:
                 self.junk = torch.zeros(max(h, 2 * self.hd), dtype=BF16, device=dev)   # gain gradients nobody reads
             # split-K scratch for the wgrad GEMMs: 8 slabs of the largest per-layer weight
@@ -215,7 +226,7 @@ class Qwen3Engine:
                 xin = a["x"]
             else:
                 xin = x
-            ops.rmsnorm_fwd(xin, w["ln1"], cfg.rms_norm_eps, out=a["xn"])
+            ops.rmsnorm_fwd(xin, w["ln1"], cfg.rms_norm_eps, out=a["xn"], out_t=a.get("xnT") if training else None)
             ops.gemm_nt(a["xn"], w["qkv"], out=a["qkv"])
             if self.lora is not None:
                 nq_, nk_ = self.nh * self.hd, self.nkv * self.hd
@@ -225,11 +236,12 @@ class Qwen3Engine:
             ops.norm_rope_fwd(a["qkv"], a["qk"], self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos, self.sin,
                               eps=cfg.rms_norm_eps)
             ops.attn_fwd(a["qk"][:, :self.nh * self.hd], a["qk"][:, self.nh * self.hd:], a["qkv"][:, self.nqk:], B, T,
-                         self.nh, self.nkv, self.hd, self.hd ** -0.5, True, kv_lo, kv_hi, out=a["attn"], lse=a["lse"])
+                         self.nh, self.nkv, self.hd, self.hd ** -0.5, True, kv_lo, kv_hi, out=a["attn"], lse=a["lse"],
+                         out_t=a.get("attnT") if training else None)
             ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=xin)
             if self.lora is not None:
                 self._lora_fwd(i, a, "o_proj", a["attn"], a["x2"], training)
-            ops.rmsnorm_fwd(a["x2"], w["ln2"], cfg.rms_norm_eps, out=a["xn2"])
+            ops.rmsnorm_fwd(a["x2"], w["ln2"], cfg.rms_norm_eps, out=a["xn2"], out_t=a.get("xn2T") if training else None)
             if self.fused_swiglu:
                 # gate|up projection with the activation in its epilogue: one launch, no second pass over gu
                 ops.gemm_gate_up_swiglu(a["xn2"], w["gu"], a["gu"], a["act"])
@@ -319,17 +331,19 @@ class Qwen3Engine:
             ops.gemm(dt, lo.A[i][mod], out=dx, accumulate=True, b_kmajor=True)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
-    def _wgrad_layer(self, slot: int, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
+    def _wgrad_layer(self, slot: int, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, xt=None):
         """One of the four per-layer weight gradients (slot: 0 qkv, 1 o, 2 gate|up, 3 down).  With the grouped path the
         narrow operand is transposed NOW (while it is hot) into the slot's own buffer and the GEMM is deferred to
-        `_wgrad_flush`; dy / x must stay unchanged until then (they do: see the call sites)."""
+        `_wgrad_flush`; dy / x must stay unchanged until then (they do: see the call sites).  `xt`: x^T as its producer already
+        stored it (the norm kernels' transposed second store) — no transpose launch then."""
         if self.tTg is None:
             return self._wgrad(dy, x, dw, accumulate)
         M, N = dy.shape
         K = x.shape[1]
         if K <= N:                                             # dw^T[K,N] = (x^T)[K,M] dy[M,N], stored transposed into dw
-            xt = self.tTg[slot][:K * M].view(K, M)
-            ops.transpose(x, xt)
+            if xt is None:
+                xt = self.tTg[slot][:K * M].view(K, M)
+                ops.transpose(x, xt)
             self._pend.append((xt, dy, dw, True))
         else:                                                  # dw[N,K] = (dy^T)[N,M] x[M,K]
             dyt = self.tTg[slot][:N * M].view(N, M)
@@ -449,7 +463,7 @@ class Qwen3Engine:
                 self._lora_bwd(i, a, "gate_proj", a["xn2"], self.d_gu[:, :self.ff], dxn2, accumulate)
                 self._lora_bwd(i, a, "up_proj", a["xn2"], self.d_gu[:, self.ff:], dxn2, accumulate)
             if tb:
-                self._wgrad_layer(2, self.d_gu, a["xn2"], g["gu"], accumulate)
+                self._wgrad_layer(2, self.d_gu, a["xn2"], g["gu"], accumulate, xt=a.get("xn2T"))
             dx2 = spare[1]
             ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, None if defer else gw(g, "ln2"), cfg.rms_norm_eps, dres=dx, dx=dx2,
                             dw_accumulate=acc_n, workspace=self.ws_rms[2 * i] if defer else self.ws)
@@ -458,7 +472,7 @@ class Qwen3Engine:
             if lora is not None:
                 self._lora_bwd(i, a, "o_proj", a["attn"], dx2, self.d_attn, accumulate)
             if tb:
-                self._wgrad_layer(1, dx2, a["attn"], g["o"], accumulate)
+                self._wgrad_layer(1, dx2, a["attn"], g["o"], accumulate, xt=a.get("attnT"))
             ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
                          self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta, ws=self.attn_ws)
@@ -473,7 +487,7 @@ class Qwen3Engine:
                 self._lora_bwd(i, a, "v_proj", a["xn"], self.d_qkv[:, nq + nk_:], dxn, accumulate)
                 self._wgrad_flush(accumulate)                  # the layer's fourteen adapter gradients, one launch
             if tb:
-                self._wgrad_layer(0, self.d_qkv, a["xn"], g["qkv"], accumulate)
+                self._wgrad_layer(0, self.d_qkv, a["xn"], g["qkv"], accumulate, xt=a.get("xnT"))
                 # dx, d_gu, dx2 and d_qkv are all still intact here (the norm backward below overwrites dx)
                 self._wgrad_flush(accumulate)
             ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, None if defer else gw(g, "ln1"), cfg.rms_norm_eps, dres=dx2, dx=dx,

@@ -130,6 +130,19 @@ def test_rmsnorm_fwd_bwd(rows, H):
     _close(dw, wr.grad, 2e-3 * math.sqrt(rows), 1e-3, "rmsnorm dw")
 
 
+@pytest.mark.parametrize("rows,H", [(64, 512), (320, 1024), (2048, 2048), (192, 1536)])
+def test_rmsnorm_with_the_transposed_second_store(rows, H):
+    """molly_rmsnorm_fwd_t (round 5): the norm kernel stores its result a second time transposed — the k-contiguous operand of the
+    weight gradient of the projection behind it — instead of a transpose launch reading it back.  y is bit-identical to the plain
+    kernel's, the transposed copy is its exact transpose."""
+    x = _rand(rows, H, seed=20).to(BF)
+    w = (1 + 0.1 * _rand(H, seed=21)).to(BF)
+    y0 = ops.rmsnorm_fwd(x, w, 1e-6)
+    yt = torch.full((H, rows), 9.0, dtype=BF, device=DEV)
+    y1 = ops.rmsnorm_fwd(x, w, 1e-6, out_t=yt)
+    assert torch.equal(y0, y1) and torch.equal(yt, y0.t().contiguous())
+
+
 def test_swiglu_fwd_bwd():
     rows, ff = 130, 512
     gu = _rand(rows, 2 * ff, seed=14).to(BF)
@@ -259,6 +272,24 @@ def test_attn_fwd(hd, nh, nkv, T, causal, ragged):
     of = o.float().view(B, T, nh, hd).transpose(1, 2)
     _close(of[live], rof[live], 2e-2, 1e-2, "attn O")     # bf16 P and bf16 output
     _close(lse[live], rl[live], 2e-3, 1e-4, "attn lse2")
+
+
+@pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [(128, 4, 2, 256, True, False), (128, 16, 8, 2048, True, True), (64, 4, 4, 384, False, True)])
+def test_attn_fwd_transposed_second_store(hd, nh, nkv, T, causal, ragged):
+    """molly_attn_fwd_ot (round 5): the forward stores O a second time transposed (the o-projection's weight-gradient operand) instead of a
+    transpose launch reading it back: O and LSE are bit-identical to the plain call's, OT is O's exact transpose."""
+    B = 2
+    M = B * T
+    qkv = _rand(M, (nh + 2 * nkv) * hd, seed=44).to(BF)
+    q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
+    lo = hi = None
+    if ragged:
+        lo = torch.tensor([0, 3], device=DEV, dtype=torch.int32)
+        hi = torch.tensor([T, T - 37], device=DEV, dtype=torch.int32)
+    o0, l0 = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, hd ** -0.5, causal, lo, hi)
+    ot = torch.full((nh * hd, M), 9.0, dtype=BF, device=DEV)
+    o1, l1 = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, hd ** -0.5, causal, lo, hi, out_t=ot)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1) and torch.equal(ot, o0.t().contiguous())
 
 
 @pytest.mark.parametrize("pipe", ["8", "4"])
