@@ -418,13 +418,16 @@ def main(argv=None):
     ap.add_argument("--bucket-mib", type=float, default=0.0,
                     help="ZeRO bucket size in MiB of bf16 (one reduce-scatter / all-gather each; every xGMI link carries bucket/world "
                          "of it); 0 = the default of 32 MiB per link (256 MiB at 8 GPUs).  SURVEY §5 sweep: 64 ... 1024")
-    ap.add_argument("--rs-algo", choices=("rccl", "a2a"), default=None,
+    ap.add_argument("--rs-algo", choices=("rccl", "a2a", "p2p"), default=None,
                     help="gradient reduce-scatter: the library's collective (default) or all_to_all_single + a local fp32 reduction "
                          "in rank order (SURVEY 5 option 2: every xGMI link carries one chunk at once, whatever RCCL would pick)")
     ap.add_argument("--bucket-ab-steps", type=int, default=2,
                     help="N > 1, neither --bucket-mib nor --rs-algo pinned: timed steps per (bucket size, reduce-scatter algorithm) candidate "
                          "of the sweep before the warm-up (untimed region; the fastest is kept, the table lands in comm.bucket_ab); 0 = off")
     ap.add_argument("--bucket-ab-mib", default="64,128,256,512,1024", help="bucket sizes (MiB of bf16) the sweep tries")
+    ap.add_argument("--bucket-ab-algos", default="rccl,a2a",
+                    help="reduce-scatter transports the sweep tries: rccl (the library's reduce-scatter), a2a (all_to_all + local fp32 sum), "
+                         "p2p (direct reads / writes of mapped peer buffers, trainer/p2p.py: validated on one GPU only, so opt-in here)")
     ap.add_argument("--exposed-comm-steps", type=int, default=4,
                     help="N>1: extra steps after the timed region with the exchange NOT overlapped, to report the exposed "
                          "communication time (0 = skip)")
@@ -595,7 +598,8 @@ def main(argv=None):
             tm = torch.tensor([dtm], device=dev, dtype=torch.float64)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             return float(tm.item()) / args.bucket_ab_steps * 1e3
-        bucket_ab = sweep_exchange([(mib, algo) for algo in ("rccl", "a2a") for mib in sizes], measure, args.bucket_ab_steps)
+        algos = [a.strip() for a in args.bucket_ab_algos.split(",") if a.strip()]
+        bucket_ab = sweep_exchange([(mib, algo) for algo in algos for mib in sizes], measure, args.bucket_ab_steps)
         ch = bucket_ab["chosen"]
         opt = None
         m._rt.opt = None
@@ -654,8 +658,9 @@ def main(argv=None):
                 "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo,
                 # where the gradient sum is rounded: the library's reduce-scatter adds bf16 partial sums hop by hop (DeepSpeed's
                 # own behaviour with bf16 gradients); the all-to-all variant sums the `world` copies in fp32 on the owner, once
-                "reduce_dtype": ("fp32 on the owning rank, rank order, one rounding (all_to_all + molly_reduce_rows)"
-                                 if opt.rs_algo == "a2a" else "bf16 in the collective (RCCL reduce_scatter: one rounding per hop)"),
+                "reduce_dtype": ("fp32 on the owning rank, rank order, one rounding (all_to_all + molly_reduce_rows)" if opt.rs_algo == "a2a" else
+                                 "fp32 on the owning rank, rank order, one rounding (peer copies read in place: molly_p2p_reduce)" if opt.rs_algo == "p2p"
+                                 else "bf16 in the collective (RCCL reduce_scatter: one rounding per hop)"),
                 "gemm_blocks_mode": getattr(opt, "gemm_blocks_mode", 256), "gemm_mode_ab": gemm_mode_ab, "bucket_ab": bucket_ab,
                 # per bucket, HIP events on the communication stream around each collective of the timed region (overlapped: the
                 # time includes waiting for CUs beside the backward); us_per_bucket = the first timed step's buckets in launch order

@@ -399,6 +399,20 @@ int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* 
 int molly_lora_up_drop_acc_bf16(void* stream, const void* dt, const void* A, void* dx, int M, int K, int R, int lddt, float p, uint64_t seed);
 
 /* ------------------------------------------------------------------------------------------------
+ * Direct peer exchange for the ZeRO-2 step (SURVEY.md §5 option 3; reference role: DeepSpeed ZeRO-2's reduce-scatter / all-gather,
+ * src/configs/ds_z2_config.json:18-27, src/train.py:606-614).  The peers' gradient / parameter / flag buffers are mapped into this
+ * process by IPC (the caller does that); srcs / dsts / flags are HOST arrays of `world` device pointers in rank order.
+ * reduce: out[i] = bf16(sum_r float(srcs[r][i])) in rank order (molly_reduce_rows_bf16's arithmetic on copies that stay where they are).
+ * push:   dsts[r][i] = src[i] for every r != skip.   n % 8 == 0, 16-byte aligned buffers, world <= 16.
+ * flag_set: *flag = value, a system-scope release behind everything the stream has launched so far.
+ * flag_wait: returns (in stream order) when flags[r][idx] >= value for every r; a peer that does not arrive within max_spins polls
+ *            writes 1 + r into *err (device int, the caller checks it) instead of hanging the GPU. */
+int molly_p2p_reduce_bf16(void* stream, const void* const* srcs, int world, long n, void* out);
+int molly_p2p_push_bf16(void* stream, const void* src, void* const* dsts, int world, int skip, long n);
+int molly_p2p_flag_set(void* stream, int* flag, int value);
+int molly_p2p_flag_wait(void* stream, const void* const* flags, int world, int idx, int value, long max_spins, int* err);
+
+/* ------------------------------------------------------------------------------------------------
  * layout / instruction probes (used by tests/test_gpu_kernels.py::test_probe_* to pin the gfx950 operand maps the
  * kernels rely on; not part of the product path) */
 int molly_probe_mfma16(void* stream, const void* A16x32, const void* B16x32, float* D16x16);

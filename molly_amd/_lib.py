@@ -101,6 +101,8 @@ class MollyLib:
                     conv.append(None)
                 elif hasattr(a, "data_ptr"):
                     conv.append(a.data_ptr())
+                elif isinstance(a, ctypes.Array):            # a host array of pointers (molly_p2p_*)
+                    conv.append(ctypes.cast(a, ctypes.c_void_p))
                 else:
                     conv.append(int(a))
             else:

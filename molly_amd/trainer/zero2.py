@@ -275,6 +275,11 @@ class Zero2Optimizer:
         self.t = 0
         # ---- overlap machinery -------------------------------------------------------------------------------
         rs_algo = rs_algo or os.environ.get("MOLLY_RS_ALGO", "rccl")
+        if comm is None and rs_algo == "p2p" and self.world > 1:
+            # direct peer exchange over mapped peer memory (trainer/p2p.py; SURVEY.md 5 option 3): no collective for the buckets at all
+            assert stage == 2 and flat_params.is_cuda, "rs_algo='p2p' is the ZeRO-2 exchange on GPU buffers"
+            from .p2p import P2PComm
+            comm = P2PComm(flat_grads, flat_params, len(self.buckets), group)
         self.comm = comm if comm is not None else _DistComm(group, staged=_STAGED_DEFAULT, rs_algo=rs_algo,
                                                             reduce_rows=getattr(self.k, "reduce_rows", None))
         self.rs_algo = getattr(self.comm, "rs_algo", "rccl")

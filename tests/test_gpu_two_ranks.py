@@ -118,6 +118,51 @@ def test_two_ranks_all_to_all_reduce_scatter(tiny_meta):
     assert torch.equal(res["a2a"][0], res["rccl"][0]) and res["a2a"][1] == res["rccl"][1]
 
 
+def _worker_any_world(rank, world, port, meta, ret, rs_algo):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from molly_amd.synth import synth_batch
+    from molly_amd.trainer import Zero2Optimizer
+    m = _model(meta)
+    opt = Zero2Optimizer(m._rt.P.flat, m._rt.G.flat, m.n_decay, lr=1e-3, weight_decay=1e-2, max_grad_norm=1.0,
+                         chunk_elems=1 << 17, stage=2, rs_algo=rs_algo)
+    assert opt.overlap and opt.world == world and len(opt.buckets) > 2 and opt.rs_algo == rs_algo
+    m.attach_optimizer(opt)
+    sp = {k: tuple(v) for k, v in meta["config"]["special_ids"].items()}
+    b = synth_batch(2, 256, [("protein", 64)], seed=70 + rank, text_vocab=1000, special_ids=sp, pad_id=1000)
+    norms = []
+    for _ in range(3):
+        m.forward_backward(*_args(b))
+        norms.append(float(opt.step(lr=1e-3).item()))
+        opt.wait_all_params()
+        torch.cuda.synchronize()
+    if rs_algo == "p2p":
+        opt.comm.check()                                     # no spin gave up
+    ret[rank] = (m._rt.P.flat.cpu().clone(), norms)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_peer_exchange_equals_all_to_all_bit_for_bit(tiny_meta, world):
+    """rs_algo="p2p" (SURVEY.md 5 option 3, trainer/p2p.py + csrc/p2p.hip): every rank maps the peers' gradient and parameter buffers
+    (CUDA IPC), the owner of a chunk READS the other copies in place and adds them in fp32 in rank order, then WRITES its updated
+    parameter chunk into the peers' buffers; flags that only grow order producers and consumers.  `world` processes on the one GPU
+    of the box, three overlapped steps on different per-rank batches: the replicas are bit-identical, and bit-identical to the
+    all-to-all reduce-scatter (the same arithmetic on copies that were moved instead of read in place).  Never run over links: no
+    speed is claimed."""
+    mgr = mp.Manager()
+    res = {}
+    for algo in ("a2a", "p2p"):
+        ret = mgr.dict()
+        mp.spawn(_worker_any_world, args=(world, _free_port(), tiny_meta, ret, algo), nprocs=world, join=True)
+        for r in range(1, world):
+            assert torch.equal(ret[0][0], ret[r][0]) and ret[0][1] == ret[r][1], (algo, r)
+        res[algo] = ret[0]
+    assert torch.equal(res["p2p"][0], res["a2a"][0]) and res["p2p"][1] == res["a2a"][1]
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
