@@ -392,9 +392,11 @@ int molly_scale_bf16(void* stream, void* x, long n, float s);
 /* The two rank-r contractions next to the dropout mask, fused with it (PEFT lora.Linear.forward, reference src/utils/tools.py:379-389;
  * same mask function of (seed, flat element index of the [M, K] operand) as molly_dropout_bf16, so fused and unfused calls mix):
  * down: t[M, R] = scale * (dropout(x)[M, K] A[R, K]^T), xd (nullable) = dropout(x) written on the way (the dA weight gradient reads it).
- *       x, xd contiguous [M, K]; A [R, K] contiguous; t row stride ldt.  K % 64 == 0, R == 64 (the padded rank).
+ *       x [M, K] with row stride ldx (the mask is indexed by the logical [M, K] position), xd contiguous [M, K]; A [R, K] contiguous; t row
+ *       stride ldt.  K % 64 == 0, R == 64 (the padded rank).  p == 0 and xd == NULL:
+ *       the plain rank-R product (no mask is generated) — the backward's dt = scale * dy B runs through it with A = B^T.
  * up:   dx[M, K] += mask * bf16(dt[M, R] A[R, K])  — the branch's contribution to d(x).  dx contiguous, dt row stride lddt.  K % 128 == 0. */
-int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldt, float p,
+int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt, float p,
                               uint64_t seed, float scale);
 int molly_lora_up_drop_acc_bf16(void* stream, const void* dt, const void* A, void* dx, int M, int K, int R, int lddt, float p, uint64_t seed);
 

@@ -81,9 +81,9 @@ __device__ __forceinline__ u32x4 drop_chunk(const u32x4& v, long t, uint32_t thr
 // fragment reads — 32 rows, one chunk — are conflict-free, guide T2).  D'[r][m] = A[r][k] xd[m][k] (swapped operands: a lane owns one
 // row m of t with four consecutive r per register quad, so t leaves in 8-byte pieces of its rows).
 constexpr int LD_BM = 64, LD_BK = 64;      // (32-row blocks — twice the workgroups, each wave a 16 x 32 piece — measured below)
-template <bool WRITE_XD>
+template <bool WRITE_XD, bool DROP = true>
 __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf16_t* __restrict__ xd,
-                                                             bf16_t* __restrict__ t, int M, int K, int ldt, uint32_t thr, float inv_keep,
+                                                             bf16_t* __restrict__ t, int M, int K, int ldx, int ldt, uint32_t thr, float inv_keep,
                                                              uint32_t seed_lo, uint32_t seed_hi, float scale) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[2][LD_BM * LD_BK], as[2][64 * LD_BK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __res
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = m0 + srow[q];
-            xv[q] = m < M ? *reinterpret_cast<const u32x4*>(x + (size_t)m * K + k0 + 8 * sch[q]) : u32x4{0, 0, 0, 0};
+            xv[q] = m < M ? *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + k0 + 8 * sch[q]) : u32x4{0, 0, 0, 0};
             av[q] = *reinterpret_cast<const u32x4*>(A + (size_t)srow[q] * K + k0 + 8 * sch[q]);
         }
     };
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __res
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = m0 + srow[q];
-            const u32x4 d = drop_chunk(xv[q], ((long)m * K + k0) / 8 + sch[q], thr, inv_keep, seed_lo, seed_hi);
+            const u32x4 d = DROP ? drop_chunk(xv[q], ((long)m * K + k0) / 8 + sch[q], thr, inv_keep, seed_lo, seed_hi) : xv[q];
             if (WRITE_XD && m < M) *reinterpret_cast<u32x4*>(xd + (size_t)m * K + k0 + 8 * sch[q]) = d;
             const int sw = (sch[q] ^ (srow[q] & 7)) * 8;
             *reinterpret_cast<u32x4*>(&xs[buf][srow[q] * LD_BK + sw]) = d;
@@ -274,22 +274,25 @@ extern "C" int molly_dropout_bf16(void* stream, const void* x, void* out, long n
     return 0;
 }
 
-extern "C" int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldt, float p,
-                                         uint64_t seed, float scale) {
+extern "C" int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt,
+                                         float p, uint64_t seed, float scale) {
     MOLLY_ENTER();
     MOLLY_CHECK(M > 0 && K > 0 && K % 64 == 0, "lora_down_drop: M=%d K=%d (K must be a positive multiple of 64)", M, K);
     MOLLY_CHECK(R == 64, "lora_down_drop: padded rank %d (built for 64)", R);
-    MOLLY_CHECK(ldt % 4 == 0 && ldt >= R, "lora_down_drop: ldt=%d", ldt);
+    MOLLY_CHECK(ldt % 4 == 0 && ldt >= R && ldx % 8 == 0 && ldx >= K, "lora_down_drop: ldt=%d ldx=%d", ldt, ldx);
     MOLLY_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)t % 8) == 0 && ((uintptr_t)xd % 16) == 0, "lora_down_drop: alignment");
     MOLLY_CHECK(p >= 0.f && p < 1.f, "lora_down_drop: p=%f not in [0,1)", (double)p);
     const uint32_t thr = (uint32_t)(p * 65536.f + 0.5f);
     const dim3 grid((M + LD_BM - 1) / LD_BM);
-    if (xd)
+    if (p == 0.f && !xd)          // no mask: the plain skinny product t = scale * x A^T (the backward's dt = s * dy B with A = B^T)
+        hipLaunchKernelGGL((lora_down_drop_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)A,
+                           (bf16_t*)nullptr, (bf16_t*)t, M, K, ldx, ldt, 0u, 1.f, 0u, 0u, scale);
+    else if (xd)
         hipLaunchKernelGGL(lora_down_drop_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)xd,
-                           (bf16_t*)t, M, K, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale);
+                           (bf16_t*)t, M, K, ldx, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale);
     else
         hipLaunchKernelGGL(lora_down_drop_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)nullptr,
-                           (bf16_t*)t, M, K, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale);
+                           (bf16_t*)t, M, K, ldx, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

@@ -628,7 +628,7 @@ def lora_down_drop(x, A, p: float, seed: int, scale: float = 1.0, xd=None, out=N
     """t[M, R] = scale * (dropout(x) A^T) in one launch (molly_lora_down_drop_bf16); xd (optional, [M, K]) receives dropout(x).
     The mask is molly_dropout_bf16's function of (seed, flat element index)."""
     _chk(x, BF16, "x"); _chk(A, BF16, "A")
-    assert x.is_contiguous() and A.is_contiguous() and x.shape[1] == A.shape[1]
+    assert x.stride(1) == 1 and A.is_contiguous() and x.shape[1] == A.shape[1]
     M, K = x.shape
     R = A.shape[0]
     if out is None:
@@ -636,8 +636,8 @@ def lora_down_drop(x, A, p: float, seed: int, scale: float = 1.0, xd=None, out=N
     assert out.shape == (M, R) and out.stride(1) == 1
     if xd is not None:
         assert xd.is_contiguous() and xd.shape == x.shape and xd.dtype == BF16
-    lib().call("molly_lora_down_drop_bf16", _stream(), x, A, xd, out, M, K, R, out.stride(0), float(p), int(seed) & ((1 << 64) - 1),
-               float(scale))
+    lib().call("molly_lora_down_drop_bf16", _stream(), x, A, xd, out, M, K, R, x.stride(0), out.stride(0), float(p),
+               int(seed) & ((1 << 64) - 1), float(scale))
     return out
 
 

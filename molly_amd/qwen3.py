@@ -125,6 +125,7 @@ class Qwen3Engine:
                     self.A[-1]["lxd"] = {m: e(M, d) for m, d in dims.items()}
         if self.lora is not None:
             self.lora_dt = e(M, self.lora.rp)
+            self.lora_bT = e(self.lora.rp * max(self.nqkv, 2 * ff, h))
             # adapter gradients (dB, dA of the seven targets) of one layer as ONE grouped launch: each keeps its transposed
             # rank-r operand (t^T, dt^T: rp x M) until the layer's last dgrad; dropout(x) then has to survive the dA GEMM, so
             # the masked dx term goes through a buffer of its own
@@ -311,9 +312,16 @@ class Qwen3Engine:
         else:
             self._wgrad(dy, a["lt"][mod], lo.dB[i][mod], accumulate)
         dt = self.lora_dt
-        self._dgrad(dy, lo.B[i][mod], dt)
-        if lo.scale != 1.0:
-            ops.scale_(dt, lo.scale)
+        if _LORA_FUSED and lo.rp == 64 and dy.shape[1] % 64 == 0 and dy.stride(1) == 1 and dy.stride(0) % 8 == 0:
+            # dt = s * dy B as an operand stream (dy read once at the HBM rate) instead of a 64-column grid on the 128 x 128 GEMM kernel:
+            # B [out, 64] transposed into a scratch (a 5 us launch), then the skinny product with the scale in its epilogue
+            bt = self.lora_bT[:lo.rp * dy.shape[1]].view(lo.rp, dy.shape[1])
+            ops.transpose(lo.B[i][mod], bt)
+            ops.lora_down_drop(dy, bt, 0.0, 0, lo.scale, out=dt)
+        else:
+            self._dgrad(dy, lo.B[i][mod], dt)
+            if lo.scale != 1.0:
+                ops.scale_(dt, lo.scale)
         xd = a["lxd"][mod] if lo.p > 0.0 else x                    # the forward's dropout(x), kept
         if grouped:
             dtt = self.lora_tT[mod][1].view(lo.rp, M)

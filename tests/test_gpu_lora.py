@@ -142,6 +142,12 @@ def test_fused_lora_down_projection_equals_dropout_then_gemm(M, K, scale):
     assert bool(((t.float() - t_ref.float()).abs() <= 2 * tol).all())
     t2 = ops.lora_down_drop(x, A, p, seed, scale)                # without the side output: same t
     assert torch.equal(t, t2)
+    # p = 0: the plain skinny product, also on a column slice of a wider buffer (the backward's dt = s * dy B reads slices of d_qkv / d_gu)
+    wide = torch.randn(M, K + 128, device="cuda", generator=g).bfloat16()
+    xs = wide[:, 64:64 + K]
+    t3 = ops.lora_down_drop(xs, A, 0.0, 0, scale)
+    exact3 = (xs.float() @ A.float().t()) * scale
+    assert bool(((t3.float() - exact3).abs() <= 2 ** -7 * exact3.abs() + 2 ** -7 * exact3.abs().max() * 0.05).all())
 
 
 @pytest.mark.parametrize("M,K", [(300, 256), (2048 + 17, 2048), (512, 6144)])
