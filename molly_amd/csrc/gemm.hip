@@ -60,6 +60,12 @@ struct GemmArgs {
 // Hazards inside the string are ours: m0 is written by an SALU move one wait state before the load (s_nop 0); the SGPR base
 // must not come from a VALU write in the 5 preceding instructions — checked on the generated code by
 // tools/check_asm_dma_hazards.py rather than padded with `s_nop 4` (which measured -2...-6 % on every form).
+#ifndef MOLLY_GEMM_RES_AHEAD
+#define MOLLY_GEMM_RES_AHEAD 4     // row groups of the residual in flight ahead of the residual-add epilogue (of 8)
+#endif
+#ifndef MOLLY_GEMM_SBW_AHEAD
+#define MOLLY_GEMM_SBW_AHEAD 2     // row groups of gate / up in flight ahead of the SwiGLU-backward epilogue's arithmetic (of 8)
+#endif
 #ifndef MOLLY_GEMM_ASM_DMA
 #define MOLLY_GEMM_ASM_DMA 1
 #endif
@@ -1120,12 +1126,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
             }
         } else {
+            // the residual quads of row group i + RES_AHEAD are requested before group i is used (a ring of register sets: the fragment
+            // registers are dead here).  As one load pair per row group the epilogue was eight dependent round trips — each wait also covered the
+            // stores of the group before, older in the in-order vmcnt queue (generated code: load, load, ~100 instructions, store, store,
+            // eight times over)
             const bf16_t* r0 = p.res + (size_t)(em0 + wr * 128 + fr) * p.ldres + en0 + wc * 64 + fq * 8;
+            constexpr int RES_AHEAD = MOLLY_GEMM_RES_AHEAD;
+            u32x4 rva[RES_AHEAD][2];
+            auto res_load = [&](int i, u32x4 (&rv)[2]) {
+                const bf16_t* r = r0 + (size_t)i * 16 * p.ldres;
+                rv[0] = *reinterpret_cast<const u32x4*>(r);
+                rv[1] = *reinterpret_cast<const u32x4*>(r + 32);
+            };
+#pragma unroll
+            for (int i = 0; i < RES_AHEAD; ++i) res_load(i, rva[i]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const bf16_t* r = r0 + (size_t)i * 16 * p.ldres;
                 bf16_t* c = c0 + (size_t)i * 16 * eldc;
-                const u32x4 rv0 = *reinterpret_cast<const u32x4*>(r), rv1 = *reinterpret_cast<const u32x4*>(r + 32);
+                const u32x4 rv0 = rva[i % RES_AHEAD][0], rv1 = rva[i % RES_AHEAD][1];
 #pragma unroll
                 for (int sh = 0; sh < 2; ++sh) {
                     float v[2][4];                               // fp32 sums regrouped (one rounding, as before the regrouping)
@@ -1142,6 +1161,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     *reinterpret_cast<u32x4*>(c + sh * 32) =
                         u32x4{pack_bf2(v[0][0] + bflo(rv[0]), v[0][1] + bfhi(rv[0])), pack_bf2(v[0][2] + bflo(rv[1]), v[0][3] + bfhi(rv[1])),
                               pack_bf2(v[1][0] + bflo(rv[2]), v[1][1] + bfhi(rv[2])), pack_bf2(v[1][2] + bflo(rv[3]), v[1][3] + bfhi(rv[3]))};
+                }
+                if (i + RES_AHEAD < 8) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    res_load(i + RES_AHEAD, rva[i % RES_AHEAD]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -1217,16 +1241,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const size_t col = (size_t)en0 + wc * 64 + fq * 8;
         const bf16_t* g0 = p.res + (size_t)(em0 + wr * 128 + fr) * p.ldres + col;
         bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + col;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        // gate / up of row group i + SBW_AHEAD are requested before group i is worked on (a ring of SBW_AHEAD register sets, 16 each).
+        // One group at a time the epilogue was eight dependent round trips, each wait covering the previous group's stores as well
+        // (in-order vmcnt): ~20 us per tile against ~50 of K loop
+        constexpr int SBW_AHEAD = MOLLY_GEMM_SBW_AHEAD;
+        u32x4 gva[SBW_AHEAD][2], uva[SBW_AHEAD][2];
+        auto sbw_load = [&](int i, u32x4 (&gv)[2], u32x4 (&uv)[2]) {
             const bf16_t* gp = g0 + (size_t)i * 16 * p.ldres;
-            bf16_t* c = c0 + (size_t)i * 16 * eldc;
-            u32x4 gv[2], uv[2];
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 gv[sh] = *reinterpret_cast<const u32x4*>(gp + sh * 32);
                 uv[sh] = *reinterpret_cast<const u32x4*>(gp + ff + sh * 32);
             }
+        };
+#pragma unroll
+        for (int i = 0; i < SBW_AHEAD; ++i) sbw_load(i, gva[i], uva[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bf16_t* c = c0 + (size_t)i * 16 * eldc;
+            u32x4 (&gv)[2] = gva[i % SBW_AHEAD], (&uv)[2] = uva[i % SBW_AHEAD];
             unsigned d[4][2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1247,6 +1281,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
                 *reinterpret_cast<u32x4*>(c + sh * 32) = og;
                 *reinterpret_cast<u32x4*>(c + ff + sh * 32) = ou;
+            }
+            if (i + SBW_AHEAD < 8) {
+                __builtin_amdgcn_sched_barrier(0);
+                sbw_load(i + SBW_AHEAD, gv, uv);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     } else if (!AT && !BT && !TO && !GRP && (p.flags & MOLLY_GEMM_SWIGLU)) {

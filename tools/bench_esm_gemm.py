@@ -26,6 +26,9 @@ def main():
     ctxs["default"].set("rows_max_m", 64)            # (first column: without the 64-row tiles, which are the default up to 1,024 rows)
     ctxs["64-row tiles"].set("rows_max_m", 8192)
     ctxs["128x128"].set("force_tile", 128); ctxs["128x128"].set("small3", int(os.environ.get("MOLLY_3STAGE", "0")))
+    if os.environ.get("MORE"):                       # (MORE=1: + the 256x256 kernel forced, and stream-K forced wherever it applies)
+        ctxs["256x256"] = ops.GemmContext(); ctxs["256x256"].ensure_workspace(256 << 20); ctxs["256x256"].set("force_tile", 512)
+        ctxs["stream-K"] = ops.GemmContext(); ctxs["stream-K"].ensure_workspace(256 << 20); ctxs["stream-K"].set("streamk", 2)
     for M in (int(x) for x in os.environ.get("M", "4096,1024,512").split(",")):
         print(f"M = {M}")
         print(f"{'gemm':18s} {'N':>6s} {'K':>6s} " + " ".join(f"{t + ' us/TF/cfg':>24s}" for t in ctxs))

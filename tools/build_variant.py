@@ -92,7 +92,19 @@ def _patch_stamp_nostore(t):
     return t.replace(a, "                    if (d[2 * sh][0] == 0x12345678u) " + a.strip())
 
 
-PATCHES = {"stamp_nostore": _patch_stamp_nostore, "githead": _patch_githead, "nostore": _patch_nostore, "lateprefetch": _patch_lateprefetch, "tilestamp": _patch_tilestamp}
+def _patch_stamp_reshot(t):
+    """tilestamp + timing-only: the residual-add and SwiGLU-backward epilogues read their second operand from ONE 256 x 256 patch (every
+    tile the same addresses: L2 hits) — is the epilogue's cost the operand's trip from HBM?"""
+    t = _patch_tilestamp(t)
+    a = "const bf16_t* r0 = p.res + (size_t)(em0 + wr * 128 + fr) * p.ldres + en0 + wc * 64 + fq * 8;"
+    assert t.count(a) == 1
+    t = t.replace(a, "const bf16_t* r0 = p.res + (size_t)(wr * 128 + fr) * p.ldres + wc * 64 + fq * 8;")
+    a = "const bf16_t* g0 = p.res + (size_t)(em0 + wr * 128 + fr) * p.ldres + col;"
+    assert t.count(a) == 1
+    return t.replace(a, "const bf16_t* g0 = p.res + (size_t)(wr * 128 + fr) * p.ldres + wc * 64 + fq * 8;")
+
+
+PATCHES = {"stamp_reshot": _patch_stamp_reshot, "stamp_nostore": _patch_stamp_nostore, "githead": _patch_githead, "nostore": _patch_nostore, "lateprefetch": _patch_lateprefetch, "tilestamp": _patch_tilestamp}
 
 
 def main():

@@ -17,10 +17,25 @@ rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
 st = torch.cuda.current_stream().cuda_stream
 names = ["wait K0", "K-tile 0", "K-tile 1", "K-tile 2", "K-tile 3", "middle (each)", "last two (each)", "closing barrier", "prefetch issue",
          "epilogue"]
-for form, M, N, K in (("nt", 16384, 4096, 2048), ("nt", 16384, 4096, 8192), ("nn", 16384, 6144, 2048), ("nt", 16384, 12288, 2048)):
+CASES = (("nt", 16384, 4096, 2048), ("nt", 16384, 4096, 8192), ("nn", 16384, 6144, 2048), ("nt", 16384, 12288, 2048))
+if os.environ.get("TILESTAMP_EPILOGUES"):
+    # the epilogues of the B = 16 step: plain, + residual (o / down forward), SwiGLU forward (gate|up), SwiGLU backward (down dgrad)
+    CASES = (("nt", 32768, 2048, 2048), ("nt+res", 32768, 2048, 2048), ("nt+res", 32768, 2048, 6144),
+             ("nn", 32768, 6144, 2048), ("nn+swiglu_bwd", 32768, 6144, 2048))
+for form, M, N, K in CASES:
+    form, _, epi = form.partition("+")
     a, b = rnd(M, K), (rnd(N, K) if form == "nt" else rnd(K, N))
+    flags, res, ldres, ldc = 0, None, 0, N
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    f = lambda: L.call("molly_gemm_bf16", st, a, b, out, None, None, M, N, K, K, K if form == "nt" else N, N, 0, 0, 0, 0 if form == "nt" else 1)
+    if epi == "res":
+        flags, res, ldres = 4, rnd(M, N), N
+    elif epi == "swiglu":
+        flags, res, ldres = 64, torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev), N // 2
+    elif epi == "swiglu_bwd":
+        flags, res, ldres, ldc = 128, rnd(M, 2 * N), 2 * N, 2 * N
+        out = torch.empty(M, 2 * N, dtype=torch.bfloat16, device=dev)
+    f = lambda: L.call("molly_gemm_bf16", st, a, b, out, None, res, M, N, K, K, K if form == "nt" else N, ldc, ldres, flags, 0, 0 if form == "nt" else 1)
+    form = form + ("+" + epi if epi else "")
     for _ in range(3):
         f()
     torch.cuda.synchronize()
