@@ -80,6 +80,13 @@ __device__ __forceinline__ u32x4 drop_chunk(const u32x4& v, long t, uint32_t thr
 // wave-instruction) one tile ahead, masked in registers, stored to xd and to LDS (16-byte chunks XOR-swizzled by the row: the MFMA
 // fragment reads — 32 rows, one chunk — are conflict-free, guide T2).  D'[r][m] = A[r][k] xd[m][k] (swapped operands: a lane owns one
 // row m of t with four consecutive r per register quad, so t leaves in 8-byte pieces of its rows).
+#ifndef MOLLY_LORA_DOWN_AHEAD
+#define MOLLY_LORA_DOWN_AHEAD 4
+#endif
+#ifndef MOLLY_LORA_UP_AHEAD
+#define MOLLY_LORA_UP_AHEAD 1
+#endif
+constexpr int LD_PD = MOLLY_LORA_DOWN_AHEAD;     // K-steps of x and A in flight per workgroup
 constexpr int LD_BM = 64, LD_BK = 64;      // (32-row blocks — twice the workgroups, each wave a 16 x 32 piece — measured below)
 template <bool WRITE_XD, bool DROP = true>
 __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf16_t* __restrict__ xd,
@@ -93,24 +100,26 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __res
     int srow[2], sch[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) { const int c = tid + 256 * q; srow[q] = c >> 3; sch[q] = c & 7; }
-    u32x4 xv[2], av[2];
-    auto load = [&](int k0) {
+    // x and A tiles travel LD_PD K-steps ahead in registers: with one tile in flight per workgroup (two workgroups per CU at 32k rows) the kernel
+    // ran at the latency of its loads — 2.6 TB/s of a stream that has no other cost
+    u32x4 xv[LD_PD][2], av[LD_PD][2];
+    auto load = [&](int k0, u32x4 (&xq)[2], u32x4 (&aq)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = m0 + srow[q];
-            xv[q] = m < M ? *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + k0 + 8 * sch[q]) : u32x4{0, 0, 0, 0};
-            av[q] = *reinterpret_cast<const u32x4*>(A + (size_t)srow[q] * K + k0 + 8 * sch[q]);
+            xq[q] = m < M ? *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + k0 + 8 * sch[q]) : u32x4{0, 0, 0, 0};
+            aq[q] = *reinterpret_cast<const u32x4*>(A + (size_t)srow[q] * K + k0 + 8 * sch[q]);
         }
     };
-    auto put = [&](int buf, int k0) {
+    auto put = [&](int buf, int k0, const u32x4 (&xq)[2], const u32x4 (&aq)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = m0 + srow[q];
-            const u32x4 d = DROP ? drop_chunk(xv[q], ((long)m * K + k0) / 8 + sch[q], thr, inv_keep, seed_lo, seed_hi) : xv[q];
+            const u32x4 d = DROP ? drop_chunk(xq[q], ((long)m * K + k0) / 8 + sch[q], thr, inv_keep, seed_lo, seed_hi) : xq[q];
             if (WRITE_XD && m < M) *reinterpret_cast<u32x4*>(xd + (size_t)m * K + k0 + 8 * sch[q]) = d;
             const int sw = (sch[q] ^ (srow[q] & 7)) * 8;
             *reinterpret_cast<u32x4*>(&xs[buf][srow[q] * LD_BK + sw]) = d;
-            *reinterpret_cast<u32x4*>(&as[buf][srow[q] * LD_BK + sw]) = av[q];
+            *reinterpret_cast<u32x4*>(&as[buf][srow[q] * LD_BK + sw]) = aq[q];
         }
     };
     f32x16 acc;
@@ -118,20 +127,27 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __res
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int r = lane & 31, h = lane >> 5;
     const int nk = K / LD_BK;
-    load(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        put(buf, kt * LD_BK);
-        __syncthreads();                                       // tile kt visible; everyone is done with buffer buf ^ 1's reads (tile kt - 1)
-        if (kt + 1 < nk) load((kt + 1) * LD_BK);
-        const bf16_t* ar = &as[buf][(32 * rh + r) * LD_BK];
-        const bf16_t* xr = &xs[buf][(32 * mb + r) * LD_BK];
 #pragma unroll
-        for (int s4 = 0; s4 < LD_BK / 16; ++s4) {
-            const int ch = ((2 * s4 + h) ^ (r & 7)) * 8;       // rows 32 j + r: (row & 7) == (r & 7)
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ar + ch);
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + ch);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xf, acc, 0, 0, 0);
+    for (int u = 0; u < LD_PD; ++u)
+        if (u < nk) load(u * LD_BK, xv[u], av[u]);
+    for (int kt0 = 0; kt0 < nk; kt0 += LD_PD) {
+#pragma unroll
+        for (int u = 0; u < LD_PD; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;                                   // (block-uniform)
+            const int buf = kt & 1;
+            put(buf, kt * LD_BK, xv[u], av[u]);
+            __syncthreads();                                       // tile kt visible; everyone is done with buffer buf ^ 1's reads (tile kt - 1)
+            if (kt + LD_PD < nk) load((kt + LD_PD) * LD_BK, xv[u], av[u]);
+            const bf16_t* ar = &as[buf][(32 * rh + r) * LD_BK];
+            const bf16_t* xr = &xs[buf][(32 * mb + r) * LD_BK];
+#pragma unroll
+            for (int s4 = 0; s4 < LD_BK / 16; ++s4) {
+                const int ch = ((2 * s4 + h) ^ (r & 7)) * 8;       // rows 32 j + r: (row & 7) == (r & 7)
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ar + ch);
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + ch);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xf, acc, 0, 0, 0);
+            }
         }
     }
     const int m = m0 + 32 * mb + r;
@@ -210,6 +226,18 @@ __global__ __launch_bounds__(256, 2) void lora_up_drop_acc_kernel(const bf16_t* 
     }
     lu_stage(A + n_begin, K, tiles, wave, lane);
     int cur = 0;
+    // dx's chunks of the NEXT column tile are requested before this tile's masks are computed (MOLLY_LORA_UP_AHEAD): requested where
+    // they are used, every tile paid the latency of its eight loads on top of the Philox arithmetic
+    const int lr = lane >> 4, lc = (lane & 15) * 8;
+    u32x4 oq[8];
+    auto load_dx = [&](int n0, u32x4 (&o)[8]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = m0 + it * 4 + lr;
+            o[it] = m < M ? *reinterpret_cast<const u32x4*>(dx + (size_t)m * K + n0 + lc) : u32x4{0, 0, 0, 0};
+        }
+    };
+    if (MOLLY_LORA_UP_AHEAD) load_dx(n_begin, oq);
     for (int n0 = n_begin; n0 < n_end; n0 += LU_BN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // tile n0 landed for everyone; the other buffer's readers are done
@@ -237,14 +265,22 @@ __global__ __launch_bounds__(256, 2) void lora_up_drop_acc_kernel(const bf16_t* 
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const int lr = lane >> 4, lc = (lane & 15) * 8;
+        u32x4 ocur[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) ocur[it] = oq[it];
+        if (MOLLY_LORA_UP_AHEAD) {
+            if (n0 + LU_BN < n_end) load_dx(n0 + LU_BN, oq);
+        } else {
+            load_dx(n0, ocur);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + lr;
             const int m = m0 + row;
             if (m < M) {
                 bf16_t* dp = dx + (size_t)m * K + n0 + lc;
-                const u32x4 o = *reinterpret_cast<const u32x4*>(dp);
+                const u32x4 o = ocur[it];
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * PITCH + lc);
                 const u32x4 d = drop_chunk(v, ((long)m * K + n0 + lc) / 8, thr, inv_keep, seed_lo, seed_hi);
                 u32x4 w;
