@@ -1075,12 +1075,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // + 2 ds_read_b128 per row-block instead of the swaps: K = 2048 launches 202.5 / 108.4 us against 200.1 / 101.5 with the swaps,
     // bit-identical; not kept.)
     const bool interior = em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && !(GRP ? eto : TO);
-    const bool fast16 = interior && (p.flags == 0 || p.flags == MOLLY_GEMM_RESIDUAL);
+    // (+ MOLLY_GEMM_ACCUMULATE alone, bf16: the residual path with C itself as the second operand — the weight gradients of every micro-batch but
+    // the first under gradient accumulation, which took the generic epilogue's 32 dependent 8-byte read-add-write round trips: +9 % on the grouped
+    // launch of Qwen3-4B's layer at 3,072 rows, +14 % on Qwen3-8B's at 4,096: profiles/r05_logs/grouped_c3.log)
+    const bool fast16 = interior && (p.flags == 0 || p.flags == MOLLY_GEMM_RESIDUAL || p.flags == MOLLY_GEMM_ACCUMULATE);
     const bool swiglu16 = !AT && !BT && !TO && !GRP && p.flags == MOLLY_GEMM_SWIGLU && em0 + 256 <= eM;      // (N % 256 == 0)
     const bool swiglu_bwd16 = !AT && BT && !TO && !GRP && p.flags == MOLLY_GEMM_SWIGLU_BWD && em0 + 256 <= eM && en0 + 256 <= eN;
     // transposed output (weight gradients), interior tile, plain bf16 store: the lane owns 4 consecutive m of one n
     const bool to16 = (GRP ? eto : TO) && em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && p.flags == 0;
-    pend_stores = (fast16 || to16) ? 16 : swiglu16 ? 24 : swiglu_bwd16 ? 32
+    const bool to16acc = (GRP ? eto : TO) && em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && p.flags == MOLLY_GEMM_ACCUMULATE;
+    pend_stores = (fast16 || to16 || to16acc) ? 16 : swiglu16 ? 24 : swiglu_bwd16 ? 32
                 : (em0 + 256 <= eM && en0 + 256 <= eN &&
                    !(p.flags & (MOLLY_GEMM_BIAS | MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_ACCUMULATE | MOLLY_GEMM_SWIGLU | MOLLY_GEMM_SWIGLU_BWD))) ? 32
                 : 0;
@@ -1102,6 +1106,46 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 regroup_rows(d0[0], d1[0]);
                 regroup_rows(d0[1], d1[1]);
                 *reinterpret_cast<u32x4*>(c + sh * 32) = u32x4{d0[0], d0[1], d1[0], d1[1]};
+            }
+        }
+    } else if (to16acc) {
+        // the same store with C^T's old values added in fp32 first (one rounding, as the generic epilogue does): the fp32 quads regrouped, the old
+        // values of column group j + TOA_AHEAD requested before group j is worked on
+        bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(en0 + wc * 64 + fr) * eldc + em0 + wr * 128 + fq * 8;
+        constexpr int TOA_AHEAD = 2;
+        u32x4 ova[TOA_AHEAD][4];
+        auto old_load = [&](int j, u32x4 (&ov)[4]) {
+            const bf16_t* c = c0 + (size_t)j * 16 * eldc;
+#pragma unroll
+            for (int sh = 0; sh < 4; ++sh) ov[sh] = *reinterpret_cast<const u32x4*>(c + sh * 32);
+        };
+#pragma unroll
+        for (int j = 0; j < TOA_AHEAD; ++j) old_load(j, ova[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16_t* c = c0 + (size_t)j * 16 * eldc;
+            u32x4 (&ov)[4] = ova[j % TOA_AHEAD];
+#pragma unroll
+            for (int sh = 0; sh < 4; ++sh) {
+                float v[2][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float f0 = acc[2 * sh][j][e], f1 = acc[2 * sh + 1][j][e];
+                    unsigned x0 = __float_as_uint(f0), x1 = __float_as_uint(f1);
+                    regroup_rows(x0, x1);
+                    v[0][e] = __uint_as_float(x0);
+                    v[1][e] = __uint_as_float(x1);
+                }
+                const u32x4 o = ov[sh];
+                *reinterpret_cast<u32x4*>(c + sh * 32) =
+                    u32x4{pack_bf2(v[0][0] + bflo(o[0]), v[0][1] + bfhi(o[0])), pack_bf2(v[0][2] + bflo(o[1]), v[0][3] + bfhi(o[1])),
+                          pack_bf2(v[1][0] + bflo(o[2]), v[1][1] + bfhi(o[2])), pack_bf2(v[1][2] + bflo(o[3]), v[1][3] + bfhi(o[3]))};
+            }
+            if (j + TOA_AHEAD < 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                old_load(j + TOA_AHEAD, ov);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     } else if (fast16) {
@@ -1130,11 +1174,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             // registers are dead here).  As one load pair per row group the epilogue was eight dependent round trips — each wait also covered the
             // stores of the group before, older in the in-order vmcnt queue (generated code: load, load, ~100 instructions, store, store,
             // eight times over)
-            const bf16_t* r0 = p.res + (size_t)(em0 + wr * 128 + fr) * p.ldres + en0 + wc * 64 + fq * 8;
+            const bool acc_c = p.flags == MOLLY_GEMM_ACCUMULATE;
+            const int ldr = acc_c ? eldc : p.ldres;
+            const bf16_t* r0 = (acc_c ? reinterpret_cast<const bf16_t*>(eC) : p.res) + (size_t)(em0 + wr * 128 + fr) * ldr + en0 + wc * 64 + fq * 8;
             constexpr int RES_AHEAD = MOLLY_GEMM_RES_AHEAD;
             u32x4 rva[RES_AHEAD][2];
             auto res_load = [&](int i, u32x4 (&rv)[2]) {
-                const bf16_t* r = r0 + (size_t)i * 16 * p.ldres;
+                const bf16_t* r = r0 + (size_t)i * 16 * ldr;
                 rv[0] = *reinterpret_cast<const u32x4*>(r);
                 rv[1] = *reinterpret_cast<const u32x4*>(r + 32);
             };

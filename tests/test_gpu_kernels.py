@@ -1076,6 +1076,34 @@ def test_gemm_grouped_equals_separate_launches(accumulate, persist):
         assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
 
 
+@pytest.mark.parametrize("form", ["nt", "nn", "to"])
+def test_gemm_bf16_accumulate_is_one_rounding_of_the_fp32_sum(form):
+    """MOLLY_GEMM_ACCUMULATE into a bf16 output (the weight gradients of the second micro-batch under gradient accumulation): the interior tiles'
+    16-byte read-add-write epilogues and the ragged edge's generic one both give bf16(fp32 accumulators + old value) — compared bit for bit with the
+    same launch's fp32 output added to the old values outside the kernel."""
+    lib().call("molly_gemm_force_tile", 512)
+    try:
+        for M, N, K in ((512, 768, 512), (520, 776, 576)):                  # whole tiles; a ragged last tile row and column
+            a = _rand(M, K, seed=130).to(BF)
+            if form == "nt":
+                b = _rand(N, K, seed=131).to(BF)
+                f32 = ops.gemm_nt(a, b, out_dtype=torch.float32)
+                base = _rand(M, N, seed=132).to(BF)
+                out = base.clone()
+                ops.gemm_nt(a, b, out=out, accumulate=True)
+            else:
+                b = _rand(K, N, seed=131).to(BF)
+                to = form == "to"
+                f32 = ops.gemm(a, b, b_kmajor=True, trans_out=to, out_dtype=torch.float32)
+                base = _rand(*((N, M) if to else (M, N)), seed=132).to(BF)
+                out = base.clone()
+                ops.gemm(a, b, out=out, accumulate=True, b_kmajor=True, trans_out=to)
+            ref = (f32 + base.float()).to(BF)
+            assert torch.equal(out, ref), (form, M, N, (out.float() - ref.float()).abs().max().item())
+    finally:
+        lib().call("molly_gemm_force_tile", 0)
+
+
 def test_argmax_matches_torch_first_maximum():
     g = torch.Generator(device="cpu").manual_seed(5)
     for rows, V in ((32, 151936), (3, 1000), (5, 97)):
