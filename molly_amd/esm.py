@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -22,6 +24,17 @@ from . import ops
 from .config import EncConfig
 from .params import FlatBuffer
 from .qwen3 import rope_tables
+
+# the frozen forward replayed from a hipGraph (EsmEngine._forward_replayed): MOLLY_ENC_GRAPH=1 always, 0 never; default: in single-process
+# jobs only — a capture beside RCCL's watchdog thread and in-flight collectives has never run on hardware here
+_ENC_GRAPH = os.environ.get("MOLLY_ENC_GRAPH", "auto")
+
+
+def _enc_graph_on() -> bool:
+    if _ENC_GRAPH in ("0", "1", True, False):
+        return _ENC_GRAPH in ("1", True)
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 BF16 = torch.bfloat16
 
@@ -47,6 +60,7 @@ class EsmEngine:
         if grads is not None:
             self.d_wemb, self.d_pemb, self.dlayers, self.d_lnf_w, self.d_lnf_b = self._bind(grads)
         self.cap = (0, 0, False)
+        self._g, self._g_key, self._g_seen, self._g_recaptures, self._g_prof = None, None, 0, 0, []
 
     def _bind(self, buf: FlatBuffer):
         cfg, v, e = self.cfg, buf.views, self.pre
@@ -98,6 +112,7 @@ class EsmEngine:
                                       ops.lib().query("molly_colsum_parts", N) * max(self.ffe, 3 * he)),
                                   dtype=torch.float32, device=self.dev)
         self.cap = (n_seq, K, training)
+        self._g, self._g_seen = None, 0                       # a captured forward holds the old buffers' addresses
 
     def forward(self, ids: torch.Tensor, training: bool = False) -> torch.Tensor:
         """ids int64 [n_seq, K] on the GPU, pad id 1 = masked key (reference: src/model/omics_one.py:70).
@@ -109,6 +124,52 @@ class EsmEngine:
         self.reserve(n_seq, K, training)
         if training:
             return self._forward_train(ids, n_seq, K)
+        if ids.is_cuda and self._g_recaptures < 4 and _enc_graph_on() and not torch.cuda.is_current_stream_capturing():
+            return self._forward_replayed(ids, n_seq, K)
+        return self._forward_frozen(ids, n_seq, K)
+
+    def _forward_replayed(self, ids, n_seq, K):
+        """The frozen forward through a hipGraph.  At one sample per GPU (BASELINE configs 3 / 4: 512-1,024 rows) an encoder layer is eight launches of
+        5-20 us each, issued from Python at ~10 us apiece: the stack was bound by the host (3.5 ms of idle GPU per step at config 3:
+        profiles/r05_logs/c3_gaps.log).  Same launches, same buffers, same values: the third consecutive call with one shape (the first sizes scratch and
+        sets kernel attributes, the second confirms the shape is stable) is captured, later calls copy the ids into the captured input and replay.
+        A changed shape (reserve), another GEMM context or a replaced scratch tensor drops the graph; after four captures the engine stays eager
+        (batches whose span length keeps changing would pay a capture — a device synchronize — each time).  MOLLY_ENC_GRAPH=0: always eager.
+        Measured (same box, config 3): 198.0 -> 197.0 ms per step; neutral at 16 samples per GPU, where the launches are long."""
+        key = (n_seq, K, ops._ctx())
+        ws = ops.current_gemm_scratch()
+        if self._g is not None and (self._g_key != key or ws is None or ws.data_ptr() != self._g_ws_ptr):
+            self._g, self._g_seen = None, 0
+        if self._g is None:
+            if self._g_key != key:
+                self._g_key, self._g_seen = key, 0
+            self._g_seen += 1
+            if self._g_seen < 3 or ws is None:
+                return self._forward_frozen(ids, n_seq, K)
+            self._g_ids = torch.empty_like(ids)
+            self._g_ids.copy_(ids)
+            g = torch.cuda.CUDAGraph()
+            # (bench.py's GEMM accounting lists every launch: the list entries made while capturing — no events are recorded inside a capture —
+            # are kept and appended again at every replay, so executed FLOPs stay exact)
+            prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, ([] if ops.GEMM_PROFILE is not None else None)
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._forward_frozen(self._g_ids, n_seq, K)
+                self._g_prof = ops.GEMM_PROFILE or []
+            finally:
+                ops.GEMM_PROFILE = prof
+            assert ops.current_gemm_scratch() is ws, "the GEMM scratch was replaced during graph capture"
+            self._g, self._g_ws, self._g_ws_ptr = g, ws, ws.data_ptr()
+            self._g_recaptures += 1
+        else:
+            self._g_ids.copy_(ids)
+        self._g.replay()                                        # (a capture does not execute)
+        if ops.GEMM_PROFILE is not None:
+            ops.GEMM_PROFILE.extend(self._g_prof)
+        return self.out
+
+    def _forward_frozen(self, ids, n_seq, K):
+        cfg = self.cfg
         ops.esm_embed(ids, self.wemb, self.pemb, self.x, self.pos, self.klen, cfg.pad_token_id, cfg.mask_token_id,
                       cfg.token_dropout)
         x, x2 = self.x, self.x2

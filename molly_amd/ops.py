@@ -27,7 +27,7 @@ def _prof_begin():
     """-> start event when this launch is a sampled one, else None (and counts the launch)."""
     global _prof_n
     _prof_n += 1
-    if _prof_n % GEMM_PROFILE_STRIDE:
+    if _prof_n % GEMM_PROFILE_STRIDE or torch.cuda.is_current_stream_capturing():     # (no timing events inside a hipGraph capture)
         return None
     e0 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -152,6 +152,12 @@ def ensure_gemm_workspace(nbytes: int = 512 << 20, device="cuda"):
         _GEMM_WS = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         lib().call("molly_gemm_set_workspace", _GEMM_WS, _GEMM_WS.numel() * 4)
     return _GEMM_WS
+
+
+def current_gemm_scratch():
+    """The scratch tensor launches of the current context carry pointers into (None: not allocated yet) — what a captured hipGraph must keep alive
+    and compare against before every replay."""
+    return _CTX_STACK[-1].ws if _CTX_STACK else _GEMM_WS
 
 
 def gemm_rows_tail_supported(M: int, N: int, K: int, tail: str) -> bool:

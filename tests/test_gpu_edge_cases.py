@@ -160,3 +160,48 @@ def test_gradient_accumulation_sums_micro_batches_of_different_lengths(tiny_meta
         got = m._rt.G.views[n].float().cpu()
         rel = (got - ref).abs().max().item() / ref.abs().max().item()
         assert rel < 6e-2, (n, rel)
+
+
+def test_frozen_encoder_forward_replayed_from_a_graph_equals_the_eager_launches(tiny_meta, monkeypatch):
+    """The frozen encoders' forward is captured into a hipGraph on the third call with one shape (esm.py::_forward_replayed): the replays
+    must be the eager launches' values bit for bit on FRESH ids (the captured input is a copy target, not the first batch), a shape change must
+    drop the graph, and the engine must come back to replaying on the new shape."""
+    from molly_amd import esm
+    monkeypatch.setattr(esm, "_ENC_GRAPH", True)
+    m = _build(tiny_meta, train_llm=True, train_mlp=True)
+    eng = m._rt.prot
+    g = torch.Generator().manual_seed(3)
+    vocab = eng.cfg.vocab_size
+
+    def ids(n, K, ragged):
+        t = torch.randint(4, vocab, (n, K), generator=g)
+        if ragged:
+            t[0, K - 5:] = eng.cfg.pad_token_id                  # right-padded row: masked keys
+        return t.cuda()
+
+    def eager(x):
+        return eng._forward_frozen(x, *x.shape).clone()
+
+    from molly_amd import ops
+    ctx = m._rt.gemm_ctx
+    ctx.ensure_workspace(0)
+    with ops.use_gemm_context(ctx):
+        _replay_checks(eng, ids, eager)
+
+
+def _replay_checks(eng, ids, eager):
+    eng._g_recaptures = 0
+    for call in range(6):
+        x = ids(3, 64, ragged=call % 2 == 1)
+        got = eng.forward(x).clone()
+        assert (eng._g is not None) == (call >= 2), call         # eager, eager, capture + replay, replay ...
+        assert torch.equal(got, eager(x)), call
+    assert eng._g_recaptures == 1
+    x = ids(2, 32, ragged=False)                                 # another shape: buffers are reallocated, the graph must go
+    got = eng.forward(x).clone()
+    assert eng._g is None and torch.equal(got, eager(x))
+    for call in range(3):
+        x = ids(2, 32, ragged=True)
+        got = eng.forward(x).clone()
+        assert torch.equal(got, eager(x))
+    assert eng._g is not None and eng._g_recaptures == 2
