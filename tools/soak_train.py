@@ -28,7 +28,7 @@ def main():
     m.prepare("cuda", random_init_seed=1234)
     opt = Zero2Optimizer(m._rt.P.flat, m._rt.G.flat, m.n_decay, lr=a.lr)
     m.attach_optimizer(opt)
-    batches = [synth_batch(8, 2048, [("protein", 512)], seed=42 + i) for i in range(2)]
+    batches = [synth_batch(int(os.environ.get("SOAK_BATCH", "16")), 2048, [("protein", 512)], seed=42 + i) for i in range(2)]
     losses, times = [], []
     for s in range(a.steps):
         b = batches[s % 2]
