@@ -396,6 +396,44 @@ def vendor_gemm_yardstick(dev, M):
     return out
 
 
+def clock_under_load(dev, M):
+    """Shader clock and socket power while the step's dominant kernel runs (`rocm-smi`, read-only, polled beside ~2.5 s of queued gate|up forward
+    GEMMs, OUTSIDE the timed region).  The part runs every heavy kernel at its power cap, so the clock — not 2.4 GHz — sets the matrix pipes' peak
+    (DESIGN.md §7 round 5 item 15); `roofline.frac` keeps the guide's 2.5 PFLOP/s, this says what that peak is at the clock the kernel really gets."""
+    import re
+    import subprocess
+    import torch
+    from molly_amd import ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = (torch.rand(M, 2048, device=dev, generator=g) * 2 - 1).bfloat16()
+    b = (torch.rand(12288, 2048, device=dev, generator=g) * 2 - 1).bfloat16()
+    c = torch.empty(M, 12288, dtype=torch.bfloat16, device=dev)
+    for _ in range(5):
+        ops.gemm_nt(a, b, out=c)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = max(50, int(2.5e-3 * 1.3e15 / (2.0 * M * 12288 * 2048) * 1000))          # ~2.5 s of launches at 1.3 PFLOP/s
+    e0.record()
+    for _ in range(n):
+        ops.gemm_nt(a, b, out=c)
+    e1.record()
+    clocks, watts = [], []
+    for _ in range(3):
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20)
+        clocks += [int(x) for x in re.findall(r"sclk clock level: \S+ \((\d+)Mhz\)", r.stdout)]
+        watts += [float(x) for x in re.findall(r"Power \(W\): ([0-9.]+)", r.stdout)]
+        if e1.query():
+            break
+    torch.cuda.synchronize()
+    if not clocks:
+        return None
+    mhz = sorted(clocks)[len(clocks) // 2]
+    return {"kernel": "gemm256_kernel, gate|up forward shape, sustained", "sclk_mhz": mhz, "socket_power_w": max(watts) if watts else None,
+            "sustained_tflops": round(2.0 * M * 12288 * 2048 * n / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1),
+            "mfma_peak_tflops_at_sclk": round(MFMA_BF16_PEAK_TFLOPS * mhz / 2400.0, 1),
+            "note": "rocm-smi beside ~2.5 s of queued launches; the 2.5 PFLOP/s of roofline.peak is the 2.4 GHz figure"}
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -812,6 +850,10 @@ def main(argv=None):
                 out["roofline"]["vendor_gemm_tflops"] = vendor_gemm_yardstick(dev, B * T)
             except Exception as e:          # noqa: BLE001  (a yardstick must never cost the line)
                 out["roofline"]["vendor_gemm_tflops"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+            try:
+                out["roofline"]["clock_under_load"] = clock_under_load(dev, B * T)
+            except Exception as e:  # noqa: BLE001  (a yardstick: rocm-smi absent or unreadable must not cost the headline line)
+                out["roofline"]["clock_under_load"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
         if world == 1 and not args.no_secondary and args.secondary_worker is None:
             # the other BASELINE configs, each in a child of its own: release this process's HBM first
             del m, opt, rt, batches
