@@ -159,3 +159,28 @@ def test_lora_rank64_at_real_widths_vs_oracle():
     worst = _check_grads(m, leaves)
     print("worst relative adapter-grad error at real widths", worst)
     assert len(leaves) == 14 + 4
+
+
+def test_transposed_second_stores_give_the_transpose_launches_gradients(monkeypatch):
+    """Round 5: with the grouped weight-gradient launch on, the two RMSNorm forwards and the attention forward store their results a second time,
+    transposed (qwen3.py::reserve: xnT / xn2T / attnT), instead of a transpose launch per operand in the backward.  Same numbers either way:
+    every gradient tensor of a 1.7B-width layer at 2 x 1,024 tokens must be bit-identical with MOLLY_NORM_TRANSPOSED_STORE=0."""
+    from molly_amd.synth import synth_batch
+    wide_meta, g = wide_fixture("wide")
+    sp = {k: tuple(v) for k, v in wide_meta["config"]["special_ids"].items()}
+    vocab = wide_meta["config"]["text"]["vocab_size"]
+    b = synth_batch(2, 1024, [("protein", wide_meta["config"]["K"])], seed=11, text_vocab=min(vocab, 1000), special_ids=sp, pad_id=min(vocab, 1000))
+    args = [b[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")]
+    monkeypatch.setenv("MOLLY_GROUPED_WGRAD", "2")                  # (the grouped launch is otherwise taken at the step's row counts only)
+    grads = {}
+    for arm in ("1", "0"):
+        monkeypatch.setenv("MOLLY_NORM_TRANSPOSED_STORE", arm)
+        m = _build(wide_meta, train_llm=True, train_mlp=True)
+        loss = m.forward_backward(*args)
+        torch.cuda.synchronize()
+        a0 = m._rt.llm.A[0]
+        assert ("xnT" in a0 and "attnT" in a0) == (arm == "1"), sorted(a0)          # the arm really ran the path it names
+        grads[arm] = ({n: v.clone() for n, v in m._rt.G.views.items()}, float(loss))
+    assert grads["1"][1] == grads["0"][1]
+    for n, v in grads["1"][0].items():
+        assert torch.equal(v, grads["0"][0][n]), n
