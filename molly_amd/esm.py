@@ -28,6 +28,7 @@ from .qwen3 import rope_tables
 # the frozen forward replayed from a hipGraph (EsmEngine._forward_replayed): MOLLY_ENC_GRAPH=1 always, 0 never; default: in single-process
 # jobs only — a capture beside RCCL's watchdog thread and in-flight collectives has never run on hardware here
 _ENC_GRAPH = os.environ.get("MOLLY_ENC_GRAPH", "auto")
+_ENC_GRAPH_MAX_ROWS = int(os.environ.get("MOLLY_ENC_GRAPH_MAX_ROWS", "4096"))
 
 
 def _enc_graph_on() -> bool:
@@ -124,15 +125,18 @@ class EsmEngine:
         self.reserve(n_seq, K, training)
         if training:
             return self._forward_train(ids, n_seq, K)
-        if ids.is_cuda and self._g_recaptures < 4 and _enc_graph_on() and not torch.cuda.is_current_stream_capturing():
+        # (only where the stack is launch-bound: up to 4,096 rows a launch is 5-30 us; at the headline's 8,224 rows nothing is gained and the
+        # capture — a device synchronize — would land in a timed step)
+        if (ids.is_cuda and n_seq * K <= _ENC_GRAPH_MAX_ROWS and self._g_recaptures < 4 and _enc_graph_on()
+                and not torch.cuda.is_current_stream_capturing()):
             return self._forward_replayed(ids, n_seq, K)
         return self._forward_frozen(ids, n_seq, K)
 
     def _forward_replayed(self, ids, n_seq, K):
         """The frozen forward through a hipGraph.  At one sample per GPU (BASELINE configs 3 / 4: 512-1,024 rows) an encoder layer is eight launches of
         5-20 us each, issued from Python at ~10 us apiece: the stack was bound by the host (3.5 ms of idle GPU per step at config 3:
-        profiles/r05_logs/c3_gaps.log).  Same launches, same buffers, same values: the third consecutive call with one shape (the first sizes scratch and
-        sets kernel attributes, the second confirms the shape is stable) is captured, later calls copy the ids into the captured input and replay.
+        profiles/r05_logs/c3_gaps.log).  Same launches, same buffers, same values: the second consecutive call with one shape (the first sizes scratch and
+        sets kernel attributes) is captured, later calls copy the ids into the captured input and replay.
         A changed shape (reserve), another GEMM context or a replaced scratch tensor drops the graph; after four captures the engine stays eager
         (batches whose span length keeps changing would pay a capture — a device synchronize — each time).  MOLLY_ENC_GRAPH=0: always eager.
         Measured (same box, config 3): 198.0 -> 197.0 ms per step; neutral at 16 samples per GPU, where the launches are long."""
@@ -144,7 +148,7 @@ class EsmEngine:
             if self._g_key != key:
                 self._g_key, self._g_seen = key, 0
             self._g_seen += 1
-            if self._g_seen < 3 or ws is None:
+            if self._g_seen < 2 or ws is None:
                 return self._forward_frozen(ids, n_seq, K)
             self._g_ids = torch.empty_like(ids)
             self._g_ids.copy_(ids)

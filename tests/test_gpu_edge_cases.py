@@ -163,7 +163,7 @@ def test_gradient_accumulation_sums_micro_batches_of_different_lengths(tiny_meta
 
 
 def test_frozen_encoder_forward_replayed_from_a_graph_equals_the_eager_launches(tiny_meta, monkeypatch):
-    """The frozen encoders' forward is captured into a hipGraph on the third call with one shape (esm.py::_forward_replayed): the replays
+    """The frozen encoders' forward is captured into a hipGraph on the second call with one shape (esm.py::_forward_replayed): the replays
     must be the eager launches' values bit for bit on FRESH ids (the captured input is a copy target, not the first batch), a shape change must
     drop the graph, and the engine must come back to replaying on the new shape."""
     from molly_amd import esm
@@ -194,13 +194,13 @@ def _replay_checks(eng, ids, eager):
     for call in range(6):
         x = ids(3, 64, ragged=call % 2 == 1)
         got = eng.forward(x).clone()
-        assert (eng._g is not None) == (call >= 2), call         # eager, eager, capture + replay, replay ...
+        assert (eng._g is not None) == (call >= 1), call         # eager, capture + replay, replay ...
         assert torch.equal(got, eager(x)), call
     assert eng._g_recaptures == 1
     x = ids(2, 32, ragged=False)                                 # another shape: buffers are reallocated, the graph must go
     got = eng.forward(x).clone()
     assert eng._g is None and torch.equal(got, eager(x))
-    for call in range(3):
+    for call in range(2):
         x = ids(2, 32, ragged=True)
         got = eng.forward(x).clone()
         assert torch.equal(got, eager(x))
