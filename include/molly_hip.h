@@ -125,6 +125,17 @@ enum {
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
+/* C = A B^T + A2 B2^T (+ the epilogue `flags` of molly_gemm_bf16: bias, GELU, residual, accumulate, or MOLLY_GEMM_SWIGLU) in ONE accumulation:
+ * the NT form with K2 / 64 more K-tiles read from a second operand pair (A2 [M][K2] row stride lda2, B2 [N][K2] row stride ldb2).
+ * Replaces PEFT's `result = base_layer(x) + lora_B(lora_A(dropout(x))) * scaling` second half (`lora.Linear.forward`, injected by
+ * src/utils/tools.py:378-389) as a read-modify-write pass over the projection's output: A2 = t = scaling * lora_A(dropout(x)), B2 = lora_B (for a
+ * fused q|k|v or gate|up weight: the block-diagonal stack of its targets' lora_B).  One rounding of the fp32 sum.
+ * molly_gemm_kx_supported: 1 when (M, N, K, K2, flags) is taken by this launch (whole 256 x 256 tiles' worth of work on the plain persistent walk;
+ * K % 64 == 0, 64 <= K2 <= 512, K2 % 64 == 0, no transposed / fp32 output); otherwise run molly_gemm_bf16_ctx and an accumulating second launch. */
+int molly_gemm_kx_supported(void* ctx, int M, int N, int K, int K2, int flags);
+int molly_gemm_kx_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
+                           int lda, int ldb, int ldc, int ldres, int flags, const void* A2, const void* B2, int K2, int lda2, int ldb2);
+
 /* decode rows (M <= 64, the plain forward form) on the tiled decode-row kernel, with the kernel the decode step would launch next
  * folded into the launch that combines the K slices.  tail 1: C = A B^T (+ bias) (+ res) [M][N] and tail_out = RMSNorm(C) * gain
  * [M][N] (the next block's input norm, HF:models/qwen3/modeling_qwen3.py:50-63, 262-276); tail 2: C = [gate | up] [M][N] and

@@ -43,6 +43,10 @@ struct GemmArgs {
     float* sk_slab;           // [grid][2][8 waves][32 quads][64 lanes] f32x4: the accumulators of the block's (at most two) pieces
     // dynamic tile fetch (gemm256_kernel<..., DYN = true>): one ticket counter per XCD label, 64 bytes apart, zero between launches
     unsigned* dyn_cnt;
+    // K-extension (gemm256_kernel<..., KX = true>, the NT form): k2 more K-tiles behind the K / 64 of (A, B), read from a SECOND operand pair —
+    // C = A B^T + A2 B2^T in one accumulation (a LoRA branch's t B_lora^T riding in the base projection: A2 = t [M][64 k2], B2 = [N][64 k2])
+    const bf16_t* A2; const bf16_t* B2;
+    int lda2, ldb2, k2;
     // grouped launch (gemm256_kernel<..., GRP>): up to 16 problems sharing K, layouts and epilogue flags; one work list
     int ngroup;
     struct Group {
@@ -461,8 +465,9 @@ __device__ __forceinline__ void regroup_rows(unsigned& x0, unsigned& x1) {
 // takes what is left instead of finding its share untouched.  Every block of a label draws exactly one ticket past the end; the
 // block that draws the LAST one (n + blocks - 1) puts the counter back to zero — after it, nobody in this launch reads it again.
 // Results are identical to the static walk's (a tile is computed the same way whoever computes it).
-template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false, bool DYN = false>
+template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false, bool DYN = false, bool KX = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    static_assert(!KX || (!AT && !BT && !TO && !P2 && !GRP && !SKM && !DYN), "the K-extension exists on the plain four-phase NT kernel");
     static_assert(!SKM || (!P2 && !GRP), "stream-K exists on the four-phase, single-problem kernel");
     static_assert(!DYN || (!P2 && !GRP && !SKM), "the dynamic tile fetch exists on the four-phase, single-problem kernel");
     constexpr int BK = 64, HT = 128 * BK;             // half-tile elements (16 KiB)
@@ -487,7 +492,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     auto tto = [&](const Tile& t) { return GRP ? p.grp[t.gi].trans_out != 0 : TO; };
     const int nwork = GRP ? p.grp[p.ngroup - 1].work0 + p.grp[p.ngroup - 1].tiles_m * p.grp[p.ngroup - 1].tiles_n
                           : p.tiles_m * p.tiles_n * p.splits;
-    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_main = (p.K + BK - 1) / BK;                       // K-tiles of (A, B)
+    const int nk_all = nk_main + (KX ? p.k2 : 0);
     // stream-K share of this block, in units of p.sk K-tiles (the last unit of a tile also takes the K-tiles a division leaves over)
     const int sk_upt = SKM ? nk_all / p.sk : 1;                    // units per tile (>= 1)
     // units [u0, u1) of block `b`: label x = b & 7 owns the units [L0, L1) — whole tiles when sk_tile_aligned — and its blocks
@@ -628,7 +634,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     };
     // stage half-tile `which` (0 = A0, 1 = A1, 2 = B0, 3 = B1) of the stream's next K-tile into slots (ab, bb); the K-tile is
     // complete after which == 3
+    // K-extension: the stream's K-tile nk_main is the first of the second operand pair — same tile rows / columns, other matrices and row strides:
+    // the per-lane offsets and the four running pointers are re-derived once (splits == 1: slice-local index = K-tile index)
+    auto ext_stream = [&]() {
+        const int a0 = stage_offsets_kc<128, NWI, BK>(p.lda2, s_m0, s_M, wave, lane, 0, off0);
+        const int a1 = stage_offsets_kc<128, NWI, BK>(p.lda2, s_m0 + 128, s_M, wave, lane, 0, off1);
+        int b0, b1;
+        if (swiglu_b) {
+            b0 = stage_offsets_kc<128, NWI, BK>(p.ldb2, s_n0 >> 1, s_N, wave, lane, s_N >> 1, off2);
+            b1 = stage_offsets_kc<128, NWI, BK>(p.ldb2, (s_n0 >> 1) + 64, s_N, wave, lane, s_N >> 1, off3);
+        } else {
+            b0 = stage_offsets_kc<128, NWI, BK>(p.ldb2, s_n0, s_N, wave, lane, 0, off2);
+            b1 = stage_offsets_kc<128, NWI, BK>(p.ldb2, s_n0 + 128, s_N, wave, lane, 0, off3);
+        }
+        sp0 = reinterpret_cast<const char*>(p.A2 + (long)a0 * p.lda2);
+        sp1 = reinterpret_cast<const char*>(p.A2 + (long)a1 * p.lda2);
+        sp2 = reinterpret_cast<const char*>(p.B2 + (long)b0 * p.ldb2);
+        sp3 = reinterpret_cast<const char*>(p.B2 + (long)b1 * p.ldb2);
+    };
     auto stage_stream = [&](int which, int ab, int bb) {
+        if constexpr (KX) {
+            if (which == 0 && s_ktl == nk_main) ext_stream();
+        }
         if (P2 && ((which < 2) != (wr == 0))) { if (which == 3) ++s_ktl; return; }
         const int wi = P2 ? wc : wave;
         bf16_t* dst = which < 2 ? smem + (ab * 2 + which) * HT : smem + (6 + bb * 2 + (which - 2)) * HT;
@@ -2517,6 +2544,48 @@ int launch_gemm(void* ctx, void* stream, const void* A, const void* B, void* C, 
     return 0;
 }
 
+// ---- C = A B^T + A2 B2^T (+ epilogue): the NT form of the 256x256 kernel with K2 / 64 more K-tiles read from a second operand pair.  Whole tiles of
+// work only (the plain persistent launch: no K slices, no stream-K, no carve): the caller asks kx_supported() first and runs two launches otherwise.
+bool kx_supported(const GemmCtx& c, int M, int N, int K, int K2, int flags) {
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    return c.force_tile == 0 && !two_phase(c) && M >= 256 && N >= 256 && K % 64 == 0 && K >= 128 && K2 % 64 == 0 && K2 >= 64 && K2 <= 512 &&
+           t256 >= 200 && !(flags & (MOLLY_GEMM_TRANS_OUT | MOLLY_GEMM_SWIGLU_BWD | MOLLY_GEMM_OUT_F32)) &&
+           (!(flags & MOLLY_GEMM_SWIGLU) || (flags == MOLLY_GEMM_SWIGLU && N % 256 == 0));
+}
+int launch_gemm_kx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N, int K,
+                   int lda, int ldb, int ldc, int ldres, int flags, const void* A2, const void* B2, int K2, int lda2, int ldb2) {
+    MOLLY_ENTER();
+    GemmCtx& c = ctx_of(ctx);
+    MOLLY_CHECK(kx_supported(c, M, N, K, K2, flags), "gemm_kx: M=%d N=%d K=%d K2=%d flags=0x%x is not taken by the K-extended launch "
+                "(molly_gemm_kx_supported)", M, N, K, K2, flags);
+    MOLLY_CHECK(A && B && C && A2 && B2, "gemm_kx: null operand");
+    MOLLY_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda2 % 8 == 0 && ldb2 % 8 == 0 && ldc % 4 == 0 && lda2 >= K2 && ldb2 >= K2,
+                "gemm_kx: lda/ldb/lda2/ldb2 must be multiples of 8 (lda2, ldb2 >= K2), ldc of 4");
+    MOLLY_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)A2 % 16) == 0 &&
+                ((uintptr_t)B2 % 16) == 0, "gemm_kx: operands must be 16-byte aligned");
+    MOLLY_CHECK(!(flags & MOLLY_GEMM_BIAS) || bias, "gemm_kx: MOLLY_GEMM_BIAS without bias pointer");
+    MOLLY_CHECK(!(flags & (MOLLY_GEMM_RESIDUAL | MOLLY_GEMM_SWIGLU)) || (res && ldres % 4 == 0), "gemm_kx: bad residual / activation output");
+    GemmArgs p{};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+    p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)res;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres; p.flags = flags;
+    p.A2 = (const bf16_t*)A2; p.B2 = (const bf16_t*)B2; p.lda2 = lda2; p.ldb2 = ldb2; p.k2 = K2 / 64;
+    p.splits = 1; p.group_m = c.group_m;
+    p.tiles_m = cdiv(M, 256); p.tiles_n = cdiv(N, 256);
+    if (int rc = resolve_zero_page(&p.zeros)) return rc;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, false, false, false, false, false, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr = true;
+    }
+    const int grid = grid256(c, p.tiles_m * p.tiles_n);
+    c.last_cfg = 512 + 1000 + 7;                                   // (517: the K-extended launch)
+    hipLaunchKernelGGL((gemm256_kernel<false, false, false, false, false, false, false, true>), dim3(grid), dim3(512), 163840, (hipStream_t)stream, p);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_grouped(void* ctx, void* stream, const molly_gemm_problem* problems, int count, int K, int flags) {
     MOLLY_ENTER();
     GemmCtx& c = ctx_of(ctx);
@@ -2674,6 +2743,13 @@ extern "C" int molly_gemm_bf16_ctx(void* ctx, void* stream, const void* A, const
 
 // ---- decode-row GEMM + the kernel the decode step launches behind it (tail 1: RMSNorm of the output rows, the next block's input
 // norm; tail 2: SwiGLU of a gate|up output), in the launch that combines the K slices
+extern "C" int molly_gemm_kx_supported(void* ctx, int M, int N, int K, int K2, int flags) { return kx_supported(ctx_of(ctx), M, N, K, K2, flags) ? 1 : 0; }
+extern "C" int molly_gemm_kx_bf16_ctx(void* ctx, void* stream, const void* A, const void* B, void* C, const void* bias, const void* res, int M, int N,
+                                      int K, int lda, int ldb, int ldc, int ldres, int flags, const void* A2, const void* B2, int K2, int lda2,
+                                      int ldb2) {
+    return launch_gemm_kx(ctx, stream, A, B, C, bias, res, M, N, K, lda, ldb, ldc, ldres, flags, A2, B2, K2, lda2, ldb2);
+}
+
 extern "C" int molly_gemm_rows_tail_supported(void* ctx, int M, int N, int K, int tail) {
     const GemmCtx& c = ctx_of(ctx);
     if (!(tail >= 1 && tail <= 4) || !rows_applicable(c, M, N, K, 0) || !c.ws) return 0;

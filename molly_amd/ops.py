@@ -216,6 +216,38 @@ def gemm_gate_up_swiglu(x, w_gu, gu, act):
     return act
 
 
+def gemm_kx_supported(M: int, N: int, K: int, K2: int, swiglu: bool = False, res: bool = False, bias: bool = False) -> bool:
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_RESIDUAL if res else 0) | (GEMM_BIAS if bias else 0)
+    return bool(lib().query("molly_gemm_kx_supported", _ctx(), M, N, K, K2, flags))
+
+
+def gemm_nt_kx(a, b, a2, b2, out, bias=None, res=None, act=None):
+    """out[M, N] = a[M, K] @ b[N, K]^T + a2[M, K2] @ b2[N, K2]^T (+ bias) (+ res) in one accumulation (molly_gemm_kx_bf16_ctx): a LoRA branch's
+    t B_lora^T riding in the base projection as K2 / 64 more K-tiles.  `act` ([M, N / 2]): the gate|up form — out = [gate | up] and
+    act = silu(gate) * up from the epilogue (MOLLY_GEMM_SWIGLU).  Ask gemm_kx_supported first."""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(a2, BF16, "a2"); _chk(b2, BF16, "b2"); _chk(out, BF16, "out")
+    M, K = a.shape
+    N, K2 = b2.shape
+    assert tuple(b.shape) == (N, K) and tuple(a2.shape) == (M, K2) and tuple(out.shape) == (M, N), (a.shape, b.shape, a2.shape, b2.shape, out.shape)
+    flags, r = 0, res
+    if act is not None:
+        assert bias is None and res is None and tuple(act.shape) == (M, N // 2)
+        _chk(act, BF16, "act")
+        flags, r = GEMM_SWIGLU, act
+    else:
+        if bias is not None:
+            _chk(bias, BF16, "bias"); flags |= GEMM_BIAS
+        if res is not None:
+            _chk(res, BF16, "res"); flags |= GEMM_RESIDUAL
+    prof = GEMM_PROFILE
+    e0 = _prof_begin() if prof is not None else None
+    lib().call("molly_gemm_kx_bf16_ctx", _ctx(), _stream(), a, b, out, bias, r, M, N, K, a.stride(0), b.stride(0), out.stride(0),
+               r.stride(0) if r is not None else 0, flags, a2, b2, K2, a2.stride(0), b2.stride(0))
+    if prof is not None:
+        _prof_end(prof, e0, 2.0 * M * N * (K + K2), (False, False))
+    return out
+
+
 def gemm_down_dgrad_swiglu_bwd(dy, w_down, gu, dgu):
     """d[gate | up][M, 2ff] from ONE launch (MOLLY_GEMM_SWIGLU_BWD): d(act) = dy[M, h] @ w_down[h, ff] stays in the accumulators,
     the SwiGLU backward runs in the epilogue against gu = [gate | up] — bit-identical to gemm(dy, w_down, b_kmajor=True) followed by

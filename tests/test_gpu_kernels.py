@@ -1104,6 +1104,44 @@ def test_gemm_bf16_accumulate_is_one_rounding_of_the_fp32_sum(form):
         lib().call("molly_gemm_force_tile", 0)
 
 
+@pytest.mark.parametrize("epilogue", ["plain", "res", "swiglu"])
+def test_gemm_k_extension_equals_the_sum_of_two_products(epilogue):
+    """molly_gemm_kx_bf16_ctx: C = A B^T + A2 B2^T in ONE accumulation (the LoRA branch riding in the base projection as trailing K-tiles).
+    Against fp32 on the full output; and against the two-launch form it replaces (base GEMM, then an accumulating K2-deep GEMM) within the one
+    extra bf16 rounding that form has.  Shapes: whole tiles and a ragged last tile row / column; K2 = 64 and 192; row-strided A2 / B2 (column
+    slices of wider buffers, as the block-diagonal stack of a fused projection's adapters is)."""
+    for M, N, K, K2 in ((5120 + 256, 2048 + 512, 512, 64), (8192 + 40, 2048 + 256, 256, 192)):       # (>= 200 tiles: the launch's own rule)
+        if epilogue == "swiglu":
+            N = (N // 256) * 256
+        if not ops.gemm_kx_supported(M, N, K, K2, swiglu=epilogue == "swiglu", res=epilogue == "res"):
+            pytest.fail(f"the K-extended launch refuses {M} x {N} x {K} + {K2}")
+        a, b = _rand(M, K, seed=140).to(BF), (_rand(N, K, seed=141) * 0.5).to(BF)
+        a2w, b2w = _rand(M, K2 + 64, seed=142).to(BF), (_rand(N, K2 + 128, seed=143) * 0.5).to(BF)
+        a2, b2 = a2w[:, 64:], b2w[:, 64:64 + K2]
+        exact = a.float() @ b.float().T + a2.float() @ b2.float().T
+        out = torch.empty(M, N, dtype=BF, device=DEV)
+        if epilogue == "swiglu":
+            act = torch.empty(M, N // 2, dtype=BF, device=DEV)
+            ops.gemm_nt_kx(a, b, a2, b2, out, act=act)
+            _close(out, exact, atol=2e-2 * math.sqrt((K + K2) / 64), rtol=8e-3, what="kx gate|up")
+            g, u = out[:, :N // 2].float(), out[:, N // 2:].float()
+            ref_act = (torch.nn.functional.silu(g).to(BF).float() * u)
+            _close(act, ref_act, atol=2e-2, rtol=1e-2, what="kx activation")
+            continue
+        res = _rand(M, N, seed=144).to(BF) if epilogue == "res" else None
+        ops.gemm_nt_kx(a, b, a2, b2, out, res=res)
+        ref = exact + (res.float() if res is not None else 0.0)
+        _close(out, ref, atol=2e-2 * math.sqrt((K + K2) / 64), rtol=8e-3, what="kx vs fp32")
+        two = ops.gemm_nt(a, b, res=res)
+        ops.gemm_nt(a2, b2, out=two, accumulate=True)
+        # (the two-launch form rounds the base product first: its error is an ulp of THAT magnitude, wherever the branch cancels it)
+        mag = torch.maximum(ref.abs(), (a.float() @ b.float().T + (res.float() if res is not None else 0.0)).abs())
+        ulp = 2.0 ** (torch.floor(torch.log2(mag.clamp(min=1e-30))) - 7)
+        assert bool(((out.float() - two.float()).abs() <= 2 * ulp + 1e-30).all())
+        # one accumulation is at least as close to fp32 as two roundings
+        assert (out.float() - ref).abs().mean().item() <= (two.float() - ref).abs().mean().item() * 1.02
+
+
 def test_argmax_matches_torch_first_maximum():
     g = torch.Generator(device="cpu").manual_seed(5)
     for rows, V in ((32, 151936), (3, 1000), (5, 97)):
