@@ -410,6 +410,10 @@ int molly_scale_bf16(void* stream, void* x, long n, float s);
 int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt, float p,
                               uint64_t seed, float scale);
 int molly_lora_up_drop_acc_bf16(void* stream, const void* dt, const void* A, void* dx, int M, int K, int R, int lddt, float p, uint64_t seed);
+/* items_dev: n_items records { const void* src; void* dst; int rows; int ld_dst; } (24 bytes, device memory): src [rows][64] bf16 contiguous is
+ * copied into dst (row stride ld_dst, 16-byte aligned) — the diagonal blocks of the stacked lora_B a fused projection hands to
+ * molly_gemm_kx_bf16_ctx, all layers in one launch.  max_rows: the largest `rows`. */
+int molly_lora_pack_b(void* stream, const void* items_dev, int n_items, int max_rows);
 
 /* ------------------------------------------------------------------------------------------------
  * Direct peer exchange for the ZeRO-2 step (SURVEY.md §5 option 3; reference role: DeepSpeed ZeRO-2's reduce-scatter / all-gather,

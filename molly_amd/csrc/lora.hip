@@ -293,7 +293,26 @@ __global__ __launch_bounds__(256, 2) void lora_up_drop_acc_kernel(const bf16_t* 
     }
 }
 
+// ---- batched block copy: item i copies rows x 64 bf16 (one padded-rank adapter matrix, 128-byte rows) from src (row stride 64) into dst (row
+// stride ld_dst) — the diagonal blocks of the stacked B matrices a fused projection's K-extended GEMM reads (molly_gemm_kx_bf16_ctx), refreshed
+// once per forward for every layer in ONE launch (the adapters change at every optimizer step; the off-diagonal zeros never do).
+struct PackItem { const bf16_t* src; bf16_t* dst; int rows; int ld_dst; };
+__global__ __launch_bounds__(256) void lora_pack_kernel(const PackItem* __restrict__ items) {
+    const PackItem it = items[blockIdx.y];
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+    if (row < it.rows)
+        *reinterpret_cast<u32x4*>(it.dst + (size_t)row * it.ld_dst + 8 * ch) = *reinterpret_cast<const u32x4*>(it.src + (size_t)row * 64 + 8 * ch);
+}
+
 }  // namespace
+
+extern "C" int molly_lora_pack_b(void* stream, const void* items_dev, int n_items, int max_rows) {
+    MOLLY_ENTER();
+    MOLLY_CHECK(items_dev && n_items >= 1 && n_items <= 65535 && max_rows >= 1, "lora_pack_b: %d items, max_rows=%d", n_items, max_rows);
+    hipLaunchKernelGGL(lora_pack_kernel, dim3((max_rows + 31) / 32, n_items), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_dev);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int molly_dropout_bf16(void* stream, const void* x, void* out, long n, float p, uint64_t seed, int accumulate) {
     MOLLY_ENTER();

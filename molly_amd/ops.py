@@ -216,6 +216,21 @@ def gemm_gate_up_swiglu(x, w_gu, gu, act):
     return act
 
 
+def lora_pack_items(pairs):
+    """Device table for lora_pack_b from [(src [rows, 64] contiguous bf16, dst view [rows, 64] with a row stride)]; keep the tensors alive."""
+    import struct
+    raw = b"".join(struct.pack("<QQii", s.data_ptr(), d.data_ptr(), s.shape[0], d.stride(0)) for s, d in pairs)
+    for s, d in pairs:
+        assert s.is_contiguous() and s.shape[1] == 64 and tuple(d.shape) == tuple(s.shape) and d.stride(1) == 1 and d.stride(0) % 8 == 0
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(pairs[0][0].device)
+    return t, len(pairs), max(s.shape[0] for s, _ in pairs)
+
+
+def lora_pack_b(table):
+    t, n, max_rows = table
+    lib().call("molly_lora_pack_b", _stream(), t, n, max_rows)
+
+
 def gemm_kx_supported(M: int, N: int, K: int, K2: int, swiglu: bool = False, res: bool = False, bias: bool = False) -> bool:
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_RESIDUAL if res else 0) | (GEMM_BIAS if bias else 0)
     return bool(lib().query("molly_gemm_kx_supported", _ctx(), M, N, K, K2, flags))

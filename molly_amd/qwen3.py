@@ -30,6 +30,9 @@ BF16 = torch.bfloat16
 # LoRA training: dropout fused into the two rank-r contractions next to it (csrc/lora.hip, round 5); MOLLY_LORA_FUSED=0 restores the
 # stand-alone dropout launches + GEMMs (same masks: A/B runs and the comparison in tests/test_gpu_lora.py)
 _LORA_FUSED = os.environ.get("MOLLY_LORA_FUSED", "1") != "0"
+# ... and the adapters' up-projection y += t B^T as trailing K-tiles of the base projection (molly_gemm_kx_bf16_ctx; MOLLY_LORA_KX=0: the
+# accumulating launch per target again)
+_LORA_KX = os.environ.get("MOLLY_LORA_KX", "1") != "0"
 
 
 def _ceil(a, b):
@@ -133,6 +136,30 @@ class Qwen3Engine:
             if M % 64 == 0 and self.lora.rp % 64 == 0 and os.environ.get("MOLLY_GROUPED_WGRAD", "1") != "0":
                 self.lora_tT = {m: (e(self.lora.rp * M), e(self.lora.rp * M)) for m in LORA_TARGETS}
                 self.lora_tmp = e(M * max(h, ff, self.nh * self.hd))
+        self.lora_kx = False
+        if self.lora is not None and _LORA_KX and _LORA_FUSED and self.lora.rp == 64:
+            # The up-projection of every adapter rides in its base projection as K-tiles 'behind' the weight's own (one accumulation, one rounding, no
+            # read-modify-write pass over the projection's output: 2.7 GB per layer at 32 Ki tokens): the t of a fused projection's targets sit
+            # side by side in ONE [M, 64 n] buffer, their B matrices as the diagonal blocks of ONE [N, 64 n] stack (zeros elsewhere, refreshed by one
+            # launch per forward) — and the gate|up projection keeps its SwiGLU epilogue, which the separate accumulation had cost.
+            rp, nqd, nkd = 64, self.nh * self.hd, self.nkv * self.hd
+            shapes = ((self.nqkv, h, 3 * rp, False, False), (h, nqd, rp, False, True), (2 * ff, h, 2 * rp, True, False), (h, ff, rp, False, True))
+            if all(ops.gemm_kx_supported(M, n, k, k2, swiglu=sw, res=rs) for n, k, k2, sw, rs in shapes):
+                self.lora_kx = True
+                for a in self.A:
+                    a["ltq"], a["ltg"] = e(M, 3 * rp), e(M, 2 * rp)
+                    a["lt"] = {"q_proj": a["ltq"][:, :rp], "k_proj": a["ltq"][:, rp:2 * rp], "v_proj": a["ltq"][:, 2 * rp:],
+                               "gate_proj": a["ltg"][:, :rp], "up_proj": a["ltg"][:, rp:], "o_proj": a["lt"]["o_proj"], "down_proj": a["lt"]["down_proj"]}
+                if getattr(self, "lora_b2", None) is None:
+                    z = lambda *sh: torch.zeros(*sh, dtype=BF16, device=dev)
+                    self.lora_b2, pairs = [], []
+                    for i in range(self.L):
+                        bq, bg = z(self.nqkv, 3 * rp), z(2 * ff, 2 * rp)
+                        self.lora_b2.append({"qkv": bq, "gu": bg})
+                        Bi = self.lora.B[i]
+                        pairs += [(Bi["q_proj"], bq[:nqd, :rp]), (Bi["k_proj"], bq[nqd:nqd + nkd, rp:2 * rp]), (Bi["v_proj"], bq[nqd + nkd:, 2 * rp:]),
+                                  (Bi["gate_proj"], bg[:ff, :rp]), (Bi["up_proj"], bg[ff:, rp:])]
+                    self.lora_pack = ops.lora_pack_items(pairs)
         self.x_out = e(M, h)
         self.hn = e(M, h)
         self.C = min(self.ce_chunk_rows, M)
@@ -216,6 +243,9 @@ class Qwen3Engine:
         self.B_, self.T_, self.kv = B, T, (kv_lo, kv_hi)
         if self.lora is not None and training:
             self.lora.step += 1                           # a fresh dropout stream per training forward
+        kx = self.lora is not None and self.lora_kx
+        if kx:
+            ops.lora_pack_b(self.lora_pack)               # this step's B matrices into the stacked operands (all layers, one launch)
         x = inputs_embeds
         for i in range(self.L):
             a = self.A[i if training else 0]
@@ -228,8 +258,13 @@ class Qwen3Engine:
             else:
                 xin = x
             ops.rmsnorm_fwd(xin, w["ln1"], cfg.rms_norm_eps, out=a["xn"], out_t=a.get("xnT") if training else None)
-            ops.gemm_nt(a["xn"], w["qkv"], out=a["qkv"])
-            if self.lora is not None:
+            if kx:
+                for mod in ("q_proj", "k_proj", "v_proj"):
+                    self._lora_t(i, a, mod, a["xn"], training)
+                ops.gemm_nt_kx(a["xn"], w["qkv"], a["ltq"], self.lora_b2[i]["qkv"], a["qkv"])
+            else:
+                ops.gemm_nt(a["xn"], w["qkv"], out=a["qkv"])
+            if self.lora is not None and not kx:
                 nq_, nk_ = self.nh * self.hd, self.nkv * self.hd
                 self._lora_fwd(i, a, "q_proj", a["xn"], a["qkv"][:, :nq_], training)
                 self._lora_fwd(i, a, "k_proj", a["xn"], a["qkv"][:, nq_:nq_ + nk_], training)
@@ -239,11 +274,19 @@ class Qwen3Engine:
             ops.attn_fwd(a["qk"][:, :self.nh * self.hd], a["qk"][:, self.nh * self.hd:], a["qkv"][:, self.nqk:], B, T,
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, kv_lo, kv_hi, out=a["attn"], lse=a["lse"],
                          out_t=a.get("attnT") if training else None)
-            ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=xin)
-            if self.lora is not None:
-                self._lora_fwd(i, a, "o_proj", a["attn"], a["x2"], training)
+            if kx:
+                self._lora_t(i, a, "o_proj", a["attn"], training)
+                ops.gemm_nt_kx(a["attn"], w["o"], a["lt"]["o_proj"], self.lora.B[i]["o_proj"], a["x2"], res=xin)
+            else:
+                ops.gemm_nt(a["attn"], w["o"], out=a["x2"], res=xin)
+                if self.lora is not None:
+                    self._lora_fwd(i, a, "o_proj", a["attn"], a["x2"], training)
             ops.rmsnorm_fwd(a["x2"], w["ln2"], cfg.rms_norm_eps, out=a["xn2"], out_t=a.get("xn2T") if training else None)
-            if self.fused_swiglu:
+            if kx:
+                self._lora_t(i, a, "gate_proj", a["xn2"], training)
+                self._lora_t(i, a, "up_proj", a["xn2"], training)
+                ops.gemm_nt_kx(a["xn2"], w["gu"], a["ltg"], self.lora_b2[i]["gu"], a["gu"], act=a["act"])
+            elif self.fused_swiglu:
                 # gate|up projection with the activation in its epilogue: one launch, no second pass over gu
                 ops.gemm_gate_up_swiglu(a["xn2"], w["gu"], a["gu"], a["act"])
             else:
@@ -253,9 +296,13 @@ class Qwen3Engine:
                     self._lora_fwd(i, a, "up_proj", a["xn2"], a["gu"][:, self.ff:], training)
                 ops.swiglu_fwd(a["gu"], out=a["act"])
             nxt = self.A[i + 1]["x"] if (training and i + 1 < self.L) else self.x_out
-            ops.gemm_nt(a["act"], w["down"], out=nxt, res=a["x2"])
-            if self.lora is not None:
-                self._lora_fwd(i, a, "down_proj", a["act"], nxt, training)
+            if kx:
+                self._lora_t(i, a, "down_proj", a["act"], training)
+                ops.gemm_nt_kx(a["act"], w["down"], a["lt"]["down_proj"], self.lora.B[i]["down_proj"], nxt, res=a["x2"])
+            else:
+                ops.gemm_nt(a["act"], w["down"], out=nxt, res=a["x2"])
+                if self.lora is not None:
+                    self._lora_fwd(i, a, "down_proj", a["act"], nxt, training)
             x = nxt
         ops.rmsnorm_fwd(self.x_out, self.norm_w, cfg.rms_norm_eps, out=self.hn)
         loss = None
@@ -286,6 +333,14 @@ class Qwen3Engine:
         if not (training and lo.p > 0.0):
             return x
         return ops.dropout(x, lo.p, lo.mask_seed(i, mod), out=a["lxd"][mod])
+
+    def _lora_t(self, i: int, a: dict, mod: str, x: torch.Tensor, training: bool):
+        """t = s * dropout(x) A^T of one target into its slice of the fused projection's t buffer (the K-extended GEMM adds t B^T); dropout(x) is kept
+        for the backward when there is a mask."""
+        lo = self.lora
+        p = lo.p if training else 0.0
+        ops.lora_down_drop(x, lo.A[i][mod], p, lo.mask_seed(i, mod) if p > 0.0 else 0, lo.scale,
+                           xd=a["lxd"][mod] if p > 0.0 else None, out=a["lt"][mod])
 
     def _lora_fwd(self, i: int, a: dict, mod: str, x: torch.Tensor, y: torch.Tensor, training: bool):
         """y += s * (dropout(x) A^T) B^T; keeps t = s * dropout(x) A^T for the backward."""

@@ -184,3 +184,48 @@ def test_transposed_second_stores_give_the_transpose_launches_gradients(monkeypa
     assert grads["1"][1] == grads["0"][1]
     for n, v in grads["1"][0].items():
         assert torch.equal(v, grads["0"][0][n]), n
+
+
+def test_lora_up_projection_as_trailing_k_tiles_equals_the_accumulating_launches(monkeypatch):
+    """Round 5: at the step's row counts the adapters' y += t B^T rides in the base projection (qwen3.py: `lora_kx`, molly_gemm_kx_bf16_ctx) — the
+    fused q|k|v and gate|up projections through block-diagonal stacks of their targets' B, gate|up with its SwiGLU epilogue.  4 x 2,048 tokens of a
+    1.7B-width layer, rank 64, dropout 0.05 (the masks are functions of (seed, layer, target, step): the same in both arms): the loss and all fourteen
+    adapter gradients + the projectors' against the per-target accumulating launches (MOLLY_LORA_KX=0) within bf16 rounding; then, without
+    dropout, against the oracle's autograd."""
+    from molly_amd import qwen3
+    from molly_amd.lora import LoraConfig
+    from molly_amd.synth import synth_batch
+    from oracle import molly_ref as R
+    from test_gpu_lora import _check_grads, _oracle_sd_with_lora, _randomize_B
+    meta, _ = wide_fixture("wide")
+    c = meta["config"]
+    sp = {k: tuple(v) for k, v in c["special_ids"].items()}
+    b = synth_batch(4, 2048, [("protein", 64)], seed=17, text_vocab=1000, special_ids=sp, pad_id=1000)
+    args = [b[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")]
+    runs = {}
+    for arm in (True, False):
+        monkeypatch.setattr(qwen3, "_LORA_KX", arm)
+        m = _build(meta, train_llm=False, lora=LoraConfig(r=64, lora_alpha=64, lora_dropout=0.05))
+        _randomize_B(m, std=0.02)
+        loss = m.forward_backward(*args)
+        torch.cuda.synchronize()
+        assert m._rt.llm.lora_kx == arm                                    # the arm ran the path it names
+        runs[arm] = (float(loss), {n: v.float().clone() for n, v in m._rt.G.views.items()})
+    assert abs(runs[True][0] - runs[False][0]) <= 2e-3, (runs[True][0], runs[False][0])
+    for n, g1 in runs[True][1].items():
+        g0 = runs[False][1][n]
+        assert (g1 - g0).norm().item() <= 0.03 * g0.norm().item() + 1e-6, (n, (g1 - g0).norm().item(), g0.norm().item())
+    # without dropout: the K-extended path against the oracle
+    monkeypatch.setattr(qwen3, "_LORA_KX", True)
+    m = _build(meta, train_llm=False, lora=LoraConfig(r=64, lora_alpha=64, lora_dropout=0.0))
+    _randomize_B(m, std=0.02)
+    b2 = synth_batch(4, 2048, [("protein", 64), ("rna", 64)], seed=18, text_vocab=1000, special_ids=sp, pad_id=1000)   # (both projectors get a gradient)
+    loss = m.forward_backward(*[b2[k] for k in ("input_ids", "attention_mask", "omic_ids", "omic_info_list", "labels")])
+    torch.cuda.synchronize()
+    assert m._rt.llm.lora_kx
+    sd, leaves = _oracle_sd_with_lora(meta, m)
+    llm, dna, prot = R.cfgs_from_meta(c)
+    ref_loss, _ = R.omics_forward(sd, llm, dna, prot, b2, {"dna_rna": 64, "protein": 64})
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) <= 5e-3, (loss.item(), ref_loss.item())
+    _check_grads(m, leaves)
