@@ -210,8 +210,12 @@ def test_lora_up_projection_as_trailing_k_tiles_equals_the_accumulating_launches
         loss = m.forward_backward(*args)
         torch.cuda.synchronize()
         assert m._rt.llm.lora_kx == arm                                    # the arm ran the path it names
-        runs[arm] = (float(loss), {n: v.float().clone() for n, v in m._rt.G.views.items()})
+        with torch.no_grad():                                              # the inference forward (no mask, live adapters) takes the same launches
+            logits = m(input_ids=b["input_ids"], attention_mask=b["attention_mask"], omic_ids=b["omic_ids"],
+                       omic_info_list=b["omic_info_list"]).logits.float().cpu()
+        runs[arm] = (float(loss), {n: v.float().clone() for n, v in m._rt.G.views.items()}, logits)
     assert abs(runs[True][0] - runs[False][0]) <= 2e-3, (runs[True][0], runs[False][0])
+    assert (runs[True][2] - runs[False][2]).abs().max().item() <= 3e-2 * runs[False][2].abs().max().item()
     for n, g1 in runs[True][1].items():
         g0 = runs[False][1][n]
         assert (g1 - g0).norm().item() <= 0.03 * g0.norm().item() + 1e-6, (n, (g1 - g0).norm().item(), g0.norm().item())
