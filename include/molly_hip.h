@@ -414,6 +414,13 @@ int molly_lora_up_drop_acc_bf16(void* stream, const void* dt, const void* A, voi
  * copied into dst (row stride ld_dst, 16-byte aligned) — the diagonal blocks of the stacked lora_B a fused projection hands to
  * molly_gemm_kx_bf16_ctx, all layers in one launch.  max_rows: the largest `rows`. */
 int molly_lora_pack_b(void* stream, const void* items_dev, int n_items, int max_rows);
+/* the same table, transposing: dst [64][ld_dst] = src^T (lora_B^T of every target, the `A` operand of the backward's dt = scaling * dy lora_B through
+ * molly_lora_down_drop_bf16's p = 0 form) */
+int molly_lora_pack_bt(void* stream, const void* items_dev, int n_items, int max_rows);
+/* molly_lora_down_drop_bf16 that also leaves t^T [64][ldtT] (ldtT >= M; NULL: not wanted): the k-contiguous operand of the adapter weight gradients
+ * (dB^T = t^T dy, dA = dt^T dropout(x)) without a transpose launch */
+int molly_lora_down_drop_t_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt, float p,
+                                uint64_t seed, float scale, void* tT, int ldtT);
 
 /* ------------------------------------------------------------------------------------------------
  * Direct peer exchange for the ZeRO-2 step (SURVEY.md §5 option 3; reference role: DeepSpeed ZeRO-2's reduce-scatter / all-gather,

@@ -91,7 +91,7 @@ constexpr int LD_BM = 64, LD_BK = 64;      // (32-row blocks — twice the workg
 template <bool WRITE_XD, bool DROP = true>
 __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ A, bf16_t* __restrict__ xd,
                                                              bf16_t* __restrict__ t, int M, int K, int ldx, int ldt, uint32_t thr, float inv_keep,
-                                                             uint32_t seed_lo, uint32_t seed_hi, float scale) {
+                                                             uint32_t seed_lo, uint32_t seed_hi, float scale, bf16_t* __restrict__ tT, int ldtT) {
     __shared__ __attribute__((aligned(16))) bf16_t xs[2][LD_BM * LD_BK], as[2][64 * LD_BK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * LD_BM;
@@ -156,6 +156,13 @@ __global__ __launch_bounds__(256) void lora_down_drop_kernel(const bf16_t* __res
         for (int g4 = 0; g4 < 4; ++g4)
             *reinterpret_cast<u32x2*>(t + (size_t)m * ldt + 32 * rh + 8 * g4 + 4 * h) =
                 u32x2{pack_bf2(acc[4 * g4] * scale, acc[4 * g4 + 1] * scale), pack_bf2(acc[4 * g4 + 2] * scale, acc[4 * g4 + 3] * scale)};
+        // t^T [64][ldtT] as well (the adapter weight gradients' k-contiguous operand: dB^T = t^T dy, dA = dt^T dropout(x)) — the accumulators already
+        // hold it with the row index across lanes: 32 lanes = 64 contiguous bytes of one rank row per store.  Saves a transpose launch per target.
+        if (tT) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                tT[(size_t)(32 * rh + 8 * (e >> 2) + 4 * h + (e & 3)) * ldtT + m] = f2bf(acc[e] * scale);
+        }
     }
 }
 
@@ -304,7 +311,30 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const PackItem* __restri
         *reinterpret_cast<u32x4*>(it.dst + (size_t)row * it.ld_dst + 8 * ch) = *reinterpret_cast<const u32x4*>(it.src + (size_t)row * 64 + 8 * ch);
 }
 
+// the same table format, transposing: src [rows][64] -> dst [64][ld_dst] (B^T of every target, the `A` operand of the backward's dt = s * dy B skinny
+// product), all layers in one launch per forward instead of a transpose launch per target and layer in the backward
+__global__ __launch_bounds__(256) void lora_pack_t_kernel(const PackItem* __restrict__ items) {
+    const PackItem it = items[blockIdx.y];
+    const int row = blockIdx.x * 32 + (threadIdx.x & 31), ch = threadIdx.x >> 5;      // 32 consecutive rows across a half-wave: 64-byte stores
+    if (row < it.rows) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(it.src + (size_t)row * 64 + 8 * ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            it.dst[(size_t)(8 * ch + 2 * e) * it.ld_dst + row] = (bf16_t)(v[e] & 0xffffu);
+            it.dst[(size_t)(8 * ch + 2 * e + 1) * it.ld_dst + row] = (bf16_t)(v[e] >> 16);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int molly_lora_pack_bt(void* stream, const void* items_dev, int n_items, int max_rows) {
+    MOLLY_ENTER();
+    MOLLY_CHECK(items_dev && n_items >= 1 && n_items <= 65535 && max_rows >= 1, "lora_pack_bt: %d items, max_rows=%d", n_items, max_rows);
+    hipLaunchKernelGGL(lora_pack_t_kernel, dim3((max_rows + 31) / 32, n_items), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_dev);
+    MOLLY_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int molly_lora_pack_b(void* stream, const void* items_dev, int n_items, int max_rows) {
     MOLLY_ENTER();
@@ -329,9 +359,16 @@ extern "C" int molly_dropout_bf16(void* stream, const void* x, void* out, long n
     return 0;
 }
 
+extern "C" int molly_lora_down_drop_t_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt,
+                                           float p, uint64_t seed, float scale, void* tT, int ldtT);
 extern "C" int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt,
                                          float p, uint64_t seed, float scale) {
+    return molly_lora_down_drop_t_bf16(stream, x, A, xd, t, M, K, R, ldx, ldt, p, seed, scale, nullptr, 0);
+}
+extern "C" int molly_lora_down_drop_t_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt,
+                                           float p, uint64_t seed, float scale, void* tT, int ldtT) {
     MOLLY_ENTER();
+    MOLLY_CHECK(!tT || ldtT >= M, "lora_down_drop: ldtT=%d < M=%d", ldtT, M);
     MOLLY_CHECK(M > 0 && K > 0 && K % 64 == 0, "lora_down_drop: M=%d K=%d (K must be a positive multiple of 64)", M, K);
     MOLLY_CHECK(R == 64, "lora_down_drop: padded rank %d (built for 64)", R);
     MOLLY_CHECK(ldt % 4 == 0 && ldt >= R && ldx % 8 == 0 && ldx >= K, "lora_down_drop: ldt=%d ldx=%d", ldt, ldx);
@@ -341,13 +378,13 @@ extern "C" int molly_lora_down_drop_bf16(void* stream, const void* x, const void
     const dim3 grid((M + LD_BM - 1) / LD_BM);
     if (p == 0.f && !xd)          // no mask: the plain skinny product t = scale * x A^T (the backward's dt = s * dy B with A = B^T)
         hipLaunchKernelGGL((lora_down_drop_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)A,
-                           (bf16_t*)nullptr, (bf16_t*)t, M, K, ldx, ldt, 0u, 1.f, 0u, 0u, scale);
+                           (bf16_t*)nullptr, (bf16_t*)t, M, K, ldx, ldt, 0u, 1.f, 0u, 0u, scale, (bf16_t*)tT, ldtT);
     else if (xd)
         hipLaunchKernelGGL(lora_down_drop_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)xd,
-                           (bf16_t*)t, M, K, ldx, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale);
+                           (bf16_t*)t, M, K, ldx, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale, (bf16_t*)tT, ldtT);
     else
         hipLaunchKernelGGL(lora_down_drop_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)nullptr,
-                           (bf16_t*)t, M, K, ldx, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale);
+                           (bf16_t*)t, M, K, ldx, ldt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32), scale, (bf16_t*)tT, ldtT);
     MOLLY_LAUNCH_CHECK();
     return 0;
 }

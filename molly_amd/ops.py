@@ -221,9 +221,15 @@ def lora_pack_items(pairs):
     import struct
     raw = b"".join(struct.pack("<QQii", s.data_ptr(), d.data_ptr(), s.shape[0], d.stride(0)) for s, d in pairs)
     for s, d in pairs:
-        assert s.is_contiguous() and s.shape[1] == 64 and tuple(d.shape) == tuple(s.shape) and d.stride(1) == 1 and d.stride(0) % 8 == 0
+        assert s.is_contiguous() and s.shape[1] == 64 and d.stride(1) == 1 and d.stride(0) % 8 == 0
+        assert tuple(d.shape) in (tuple(s.shape), (64, s.shape[0]))          # (the transposing form: dst [64, rows])
     t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(pairs[0][0].device)
     return t, len(pairs), max(s.shape[0] for s, _ in pairs)
+
+
+def lora_pack_bt(table):
+    t, n, max_rows = table
+    lib().call("molly_lora_pack_bt", _stream(), t, n, max_rows)
 
 
 def lora_pack_b(table):
@@ -677,7 +683,7 @@ def dropout(x, p: float, seed: int, out=None, accumulate=False):
     return out
 
 
-def lora_down_drop(x, A, p: float, seed: int, scale: float = 1.0, xd=None, out=None):
+def lora_down_drop(x, A, p: float, seed: int, scale: float = 1.0, xd=None, out=None, out_t=None):
     """t[M, R] = scale * (dropout(x) A^T) in one launch (molly_lora_down_drop_bf16); xd (optional, [M, K]) receives dropout(x).
     The mask is molly_dropout_bf16's function of (seed, flat element index)."""
     _chk(x, BF16, "x"); _chk(A, BF16, "A")
@@ -689,8 +695,10 @@ def lora_down_drop(x, A, p: float, seed: int, scale: float = 1.0, xd=None, out=N
     assert out.shape == (M, R) and out.stride(1) == 1
     if xd is not None:
         assert xd.is_contiguous() and xd.shape == x.shape and xd.dtype == BF16
-    lib().call("molly_lora_down_drop_bf16", _stream(), x, A, xd, out, M, K, R, x.stride(0), out.stride(0), float(p),
-               int(seed) & ((1 << 64) - 1), float(scale))
+    if out_t is not None:                                   # t^T [R, M] as well (the adapter weight gradients' operand)
+        assert out_t.dtype == BF16 and tuple(out_t.shape) == (R, M) and out_t.stride(1) == 1
+    lib().call("molly_lora_down_drop_t_bf16", _stream(), x, A, xd, out, M, K, R, x.stride(0), out.stride(0), float(p),
+               int(seed) & ((1 << 64) - 1), float(scale), out_t, out_t.stride(0) if out_t is not None else 0)
     return out
 
 

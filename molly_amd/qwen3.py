@@ -136,6 +136,16 @@ class Qwen3Engine:
             if M % 64 == 0 and self.lora.rp % 64 == 0 and os.environ.get("MOLLY_GROUPED_WGRAD", "1") != "0":
                 self.lora_tT = {m: (e(self.lora.rp * M), e(self.lora.rp * M)) for m in LORA_TARGETS}
                 self.lora_tmp = e(M * max(h, ff, self.nh * self.hd))
+                if training and _LORA_FUSED and self.lora.rp == 64:
+                    # t^T of every target and layer, written by the kernel that produces t (no transpose launch in the backward: 4 MB each)
+                    for a in self.A:
+                        a["ltT"] = {m: e(self.lora.rp, M) for m in LORA_TARGETS}
+            if training and _LORA_FUSED and self.lora.rp == 64 and getattr(self, "lora_bTs", None) is None:
+                # B^T of every target (the skinny dt = s * dy B reads it as its `A`), refreshed by ONE launch per backward
+                odim = {"q_proj": self.nh * self.hd, "k_proj": self.nkv * self.hd, "v_proj": self.nkv * self.hd, "o_proj": h, "gate_proj": ff,
+                        "up_proj": ff, "down_proj": h}
+                self.lora_bTs = [{m: e(self.lora.rp, odim[m]) for m in LORA_TARGETS} for _ in range(self.L)]
+                self.lora_pack_t = ops.lora_pack_items([(self.lora.B[i][m], self.lora_bTs[i][m]) for i in range(self.L) for m in LORA_TARGETS])
         self.lora_kx = False
         if self.lora is not None and _LORA_KX and _LORA_FUSED and self.lora.rp == 64:
             # The up-projection of every adapter rides in its base projection as K-tiles 'behind' the weight's own (one accumulation, one rounding, no
@@ -340,7 +350,7 @@ class Qwen3Engine:
         lo = self.lora
         p = lo.p if training else 0.0
         ops.lora_down_drop(x, lo.A[i][mod], p, lo.mask_seed(i, mod) if p > 0.0 else 0, lo.scale,
-                           xd=a["lxd"][mod] if p > 0.0 else None, out=a["lt"][mod])
+                           xd=a["lxd"][mod] if p > 0.0 else None, out=a["lt"][mod], out_t=a["ltT"][mod] if (training and "ltT" in a) else None)
 
     def _lora_fwd(self, i: int, a: dict, mod: str, x: torch.Tensor, y: torch.Tensor, training: bool):
         """y += s * (dropout(x) A^T) B^T; keeps t = s * dropout(x) A^T for the backward."""
@@ -348,11 +358,14 @@ class Qwen3Engine:
         t = a["lt"][mod]
         if training and lo.p > 0.0 and _LORA_FUSED and lo.rp == 64 and x.shape[1] % 64 == 0:
             # dropout, the rank-r down-projection and the alpha / r scaling in one launch; dropout(x) is written on the way (dA reads it)
-            ops.lora_down_drop(x, lo.A[i][mod], lo.p, lo.mask_seed(i, mod), lo.scale, xd=a["lxd"][mod], out=t)
+            ops.lora_down_drop(x, lo.A[i][mod], lo.p, lo.mask_seed(i, mod), lo.scale, xd=a["lxd"][mod], out=t,
+                               out_t=a["ltT"][mod] if "ltT" in a else None)
         else:
             ops.gemm_nt(self._lora_xd(i, a, mod, x, training), lo.A[i][mod], out=t)
             if lo.scale != 1.0:
                 ops.scale_(t, lo.scale)
+            if training and "ltT" in a:
+                ops.transpose(t, a["ltT"][mod])
         ops.gemm_nt(t, lo.B[i][mod], out=y, accumulate=True)
 
     def _lora_bwd(self, i: int, a: dict, mod: str, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool):
@@ -361,8 +374,11 @@ class Qwen3Engine:
         grouped = getattr(self, "lora_tT", None) is not None
         M = dy.shape[0]
         if grouped:
-            tt = self.lora_tT[mod][0].view(lo.rp, M)
-            ops.transpose(a["lt"][mod], tt)
+            if "ltT" in a:
+                tt = a["ltT"][mod]                                     # written by the forward beside t
+            else:
+                tt = self.lora_tT[mod][0].view(lo.rp, M)
+                ops.transpose(a["lt"][mod], tt)
             self._pend.append((tt, dy, lo.dB[i][mod], True))           # dB^T[rp, out] = t^T dy, stored transposed
         else:
             self._wgrad(dy, a["lt"][mod], lo.dB[i][mod], accumulate)
@@ -370,17 +386,24 @@ class Qwen3Engine:
         if _LORA_FUSED and lo.rp == 64 and dy.shape[1] % 64 == 0 and dy.stride(1) == 1 and dy.stride(0) % 8 == 0:
             # dt = s * dy B as an operand stream (dy read once at the HBM rate) instead of a 64-column grid on the 128 x 128 GEMM kernel:
             # B [out, 64] transposed into a scratch (a 5 us launch), then the skinny product with the scale in its epilogue
-            bt = self.lora_bT[:lo.rp * dy.shape[1]].view(lo.rp, dy.shape[1])
-            ops.transpose(lo.B[i][mod], bt)
-            ops.lora_down_drop(dy, bt, 0.0, 0, lo.scale, out=dt)
+            dtt = self.lora_tT[mod][1].view(lo.rp, M) if grouped else None
+            if getattr(self, "lora_bTs", None) is not None:
+                bt = self.lora_bTs[i][mod]                             # (refreshed once per backward: loss_and_backward)
+            else:
+                bt = self.lora_bT[:lo.rp * dy.shape[1]].view(lo.rp, dy.shape[1])
+                ops.transpose(lo.B[i][mod], bt)
+            ops.lora_down_drop(dy, bt, 0.0, 0, lo.scale, out=dt, out_t=dtt)
+            dtt_done = dtt is not None
         else:
+            dtt_done = False
             self._dgrad(dy, lo.B[i][mod], dt)
             if lo.scale != 1.0:
                 ops.scale_(dt, lo.scale)
         xd = a["lxd"][mod] if lo.p > 0.0 else x                    # the forward's dropout(x), kept
         if grouped:
             dtt = self.lora_tT[mod][1].view(lo.rp, M)
-            ops.transpose(dt, dtt)
+            if not dtt_done:
+                ops.transpose(dt, dtt)
             self._pend.append((dtt, xd, lo.dA[i][mod], False))         # dA[rp, in] = dt^T dropout(x)
         else:
             self._wgrad(dt, xd, lo.dA[i][mod], accumulate)
@@ -459,6 +482,8 @@ class Qwen3Engine:
         cfg, B, T = self.cfg, self.B_, self.T_
         M = B * T
         kv_lo, kv_hi = self.kv
+        if self.lora is not None and getattr(self, "lora_bTs", None) is not None:
+            ops.lora_pack_bt(self.lora_pack_t)            # this step's B^T of every target and layer (one launch)
         dh = self.d_a
         rows = self.scored_rows
         if rows is not None:
@@ -492,7 +517,7 @@ class Qwen3Engine:
                     self.d_head.zero_()
         M_loss = n_rows
         ops.sum_f32(self.row_loss[:max(M_loss, 1)], self.scal[2:3], scale=self.scal[0:1])
-        # frozen base: gain gradients go to a scratch nobody reads (the kernels always produce them)
+        # frozen base: the gain gradients' per-block partials stay in the kernels' scratch and are never reduced (no column-sum launches)
         junk = None if tb else self.junk
         gw = (lambda g, k: g[k]) if tb else (lambda g, k: junk[:self.hd] if k == "qn" else
                                              (junk[self.hd:2 * self.hd] if k == "kn" else junk[:self.h]))
@@ -500,7 +525,7 @@ class Qwen3Engine:
         # final norm backward
         dx = self.d_b
         defer = tb and getattr(self, "ws_defer", None) is not None
-        ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, None if defer else (self.d_norm_w if tb else junk[:self.h]),
+        ops.rmsnorm_bwd(self.x_out, self.norm_w, dh, None if (defer or not tb) else self.d_norm_w,
                         cfg.rms_norm_eps, dx=dx, dw_accumulate=accumulate and tb,
                         workspace=self.ws_rms[2 * self.L] if defer else self.ws)
         spare = [self.d_a, self.d_c]
@@ -528,7 +553,7 @@ class Qwen3Engine:
             if tb:
                 self._wgrad_layer(2, self.d_gu, a["xn2"], g["gu"], accumulate, xt=a.get("xn2T"))
             dx2 = spare[1]
-            ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, None if defer else gw(g, "ln2"), cfg.rms_norm_eps, dres=dx, dx=dx2,
+            ops.rmsnorm_bwd(a["x2"], w["ln2"], dxn2, None if (defer or not tb) else gw(g, "ln2"), cfg.rms_norm_eps, dres=dx, dx=dx2,
                             dw_accumulate=acc_n, workspace=self.ws_rms[2 * i] if defer else self.ws)
             # ---- attention: x2 = x + o_proj(attn)
             self._dgrad(dx2, w["o"], self.d_attn)
@@ -540,7 +565,7 @@ class Qwen3Engine:
                          self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
                          self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta, ws=self.attn_ws)
             ops.norm_rope_bwd(a["qkv"], self.d_qk, self.d_qkv, self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos,
-                              self.sin, None if defer else gw(g, "qn"), None if defer else gw(g, "kn"), eps=cfg.rms_norm_eps,
+                              self.sin, None if (defer or not tb) else gw(g, "qn"), None if (defer or not tb) else gw(g, "kn"), eps=cfg.rms_norm_eps,
                               dw_accumulate=acc_n, workspace=self.ws_qk[i] if defer else self.ws)
             dxn = spare[0]
             self._dgrad(self.d_qkv, w["qkv"], dxn)
@@ -553,7 +578,7 @@ class Qwen3Engine:
                 self._wgrad_layer(0, self.d_qkv, a["xn"], g["qkv"], accumulate, xt=a.get("xnT"))
                 # dx, d_gu, dx2 and d_qkv are all still intact here (the norm backward below overwrites dx)
                 self._wgrad_flush(accumulate)
-            ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, None if defer else gw(g, "ln1"), cfg.rms_norm_eps, dres=dx2, dx=dx,
+            ops.rmsnorm_bwd(a["x"], w["ln1"], dxn, None if (defer or not tb) else gw(g, "ln1"), cfg.rms_norm_eps, dres=dx2, dx=dx,
                             dw_accumulate=acc_n, workspace=self.ws_rms[2 * i + 1] if defer else self.ws)
             if tb and final_micro and self.grads_final_hook is not None:
                 self.grads_final_hook(self.layer_lo[i], self.layers_hi)       # matrices of layers i..L-1 are final

@@ -142,6 +142,9 @@ def test_fused_lora_down_projection_equals_dropout_then_gemm(M, K, scale):
     assert bool(((t.float() - t_ref.float()).abs() <= 2 * tol).all())
     t2 = ops.lora_down_drop(x, A, p, seed, scale)                # without the side output: same t
     assert torch.equal(t, t2)
+    tT = torch.empty(64, M, dtype=torch.bfloat16, device="cuda")  # ... and t^T beside it (the adapter weight gradients' operand)
+    t4 = ops.lora_down_drop(x, A, p, seed, scale, out_t=tT)
+    assert torch.equal(t4, t) and torch.equal(tT, t.T.contiguous())
     # p = 0: the plain skinny product, also on a column slice of a wider buffer (the backward's dt = s * dy B reads slices of d_qkv / d_gu)
     wide = torch.randn(M, K + 128, device="cuda", generator=g).bfloat16()
     xs = wide[:, 64:64 + K]
