@@ -410,6 +410,10 @@ int molly_scale_bf16(void* stream, void* x, long n, float s);
 int molly_lora_down_drop_bf16(void* stream, const void* x, const void* A, void* xd, void* t, int M, int K, int R, int ldx, int ldt, float p,
                               uint64_t seed, float scale);
 int molly_lora_up_drop_acc_bf16(void* stream, const void* dt, const void* A, void* dx, int M, int K, int R, int lddt, float p, uint64_t seed);
+/* n (1..3) targets that share their input in ONE pass over dx (q | k | v, gate | up): dx = bf16(... bf16(dx + mask_0 * (dt_0 A_0)) ... + mask_{n-1} * (dt_{n-1} A_{n-1})) —
+ * the roundings of n molly_lora_up_drop_acc_bf16 launches one after the other, bit for bit.  dt, A, lddt, seed: host arrays of n entries. */
+int molly_lora_up_drop_acc_multi_bf16(void* stream, int n, const void* const* dt, const void* const* A, void* dx, int M, int K, int R,
+                                      const int* lddt, float p, const uint64_t* seed);
 /* items_dev: n_items records { const void* src; void* dst; int rows; int ld_dst; } (24 bytes, device memory): src [rows][64] bf16 contiguous is
  * copied into dst (row stride ld_dst, 16-byte aligned) — the diagonal blocks of the stacked lora_B a fused projection hands to
  * molly_gemm_kx_bf16_ctx, all layers in one launch.  max_rows: the largest `rows`. */

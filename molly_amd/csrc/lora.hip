@@ -201,9 +201,15 @@ __device__ __forceinline__ bf16x8 lu_tr_frag(const bf16_t* tile, int row0, int s
     return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 }
 
-__global__ __launch_bounds__(256, 2) void lora_up_drop_acc_kernel(const bf16_t* __restrict__ dt, const bf16_t* __restrict__ A, bf16_t* __restrict__ dx,
-                                                                  int M, int K, int lddt, uint32_t thr, float inv_keep, uint32_t seed_lo,
-                                                                  uint32_t seed_hi) {
+// NTG targets in one pass over dx (NTG = 3: q | k | v of one input, 2: gate | up): dx = bf16(... bf16(bf16(dx + m_0 * z_0) + m_1 * z_1) ...) — the roundings of NTG
+// launches one after the other, bit for bit, with dx read and written ONCE.  The A tiles of (column tile, target) pairs stream through the two LDS buffers.
+struct UpDropArgs {
+    const bf16_t* dt[3]; const bf16_t* A[3];
+    int lddt[3];
+    uint32_t seed_lo[3], seed_hi[3];
+};
+template <int NTG>
+__global__ __launch_bounds__(256, 2) void lora_up_drop_acc_kernel(UpDropArgs q, bf16_t* __restrict__ dx, int M, int K, uint32_t thr, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char lu_smem[];
     bf16_t* tiles = reinterpret_cast<bf16_t*>(lu_smem);                     // [2][64 x 128]
     constexpr int PITCH = LU_BN + 8;
@@ -214,24 +220,29 @@ __global__ __launch_bounds__(256, 2) void lora_up_drop_acc_kernel(const bf16_t* 
     const int m0 = blockIdx.x * 128 + wave * 32;
     const int n_begin = blockIdx.y * LU_NCH, n_end = min(K, n_begin + LU_NCH);
     // dt^T fragments (the register operand), in the k order of the transposed reads: rank indices 16 sp + {4h .. 4h+3, 8 + 4h .. 8 + 4h+3}
-    bf16x8 pf[2][2];
+    bf16x8 pf[NTG][2][2];
     {
         const int m = min(m0 + r, M - 1);
-        const bf16_t* dp = dt + (size_t)m * lddt;
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int u = 0; u < NTG; ++u) {
+            const bf16_t* dp = q.dt[u] + (size_t)m * q.lddt[u];
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(dp + 32 * sub + 16 * sp + 4 * h);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(dp + 32 * sub + 16 * sp + 8 + 4 * h);
-                pf[sub][sp] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
-            }
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+                for (int sp = 0; sp < 2; ++sp) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(dp + 32 * sub + 16 * sp + 4 * h);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(dp + 32 * sub + 16 * sp + 8 + 4 * h);
+                    pf[u][sub][sp] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+                }
+        }
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(pf[sub][sp]));    // arrived: their waits must not land among the DMA waits
+        for (int u = 0; u < NTG; ++u)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) asm volatile("" ::"v"(pf[u][sub][sp]));    // arrived: their waits must not land among the DMA waits
     }
-    lu_stage(A + n_begin, K, tiles, wave, lane);
+    lu_stage(q.A[0] + n_begin, K, tiles, wave, lane);
     int cur = 0;
     // dx's chunks of the NEXT column tile are requested before this tile's masks are computed (MOLLY_LORA_UP_AHEAD): requested where
     // they are used, every tile paid the latency of its eight loads on top of the Philox arithmetic
@@ -246,57 +257,64 @@ __global__ __launch_bounds__(256, 2) void lora_up_drop_acc_kernel(const bf16_t* 
     };
     if (MOLLY_LORA_UP_AHEAD) load_dx(n_begin, oq);
     for (int n0 = n_begin; n0 < n_end; n0 += LU_BN) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                       // tile n0 landed for everyone; the other buffer's readers are done
-        if (n0 + LU_BN < n_end) lu_stage(A + n0 + LU_BN, K, tiles + (cur ^ 1) * 64 * LU_BN, wave, lane);
-        const bf16_t* tile = tiles + cur * 64 * LU_BN;
-        f32x16 acc[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lu_tr_frag(tile, 32 * sub, sp, d, lane), pf[sub][sp], acc[d], 0, 0, 0);
-        // rows of the wave's 32 x 128 result through its slab (bf16), then 16-byte chunks: mask, scale, add into dx
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                *reinterpret_cast<u32x2*>(slab + r * PITCH + 32 * d + 8 * g4 + 4 * h) =
-                    u32x2{pack_bf2(acc[d][4 * g4], acc[d][4 * g4 + 1]), pack_bf2(acc[d][4 * g4 + 2], acc[d][4 * g4 + 3])};
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
         u32x4 ocur[8];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) ocur[it] = oq[it];
-        if (MOLLY_LORA_UP_AHEAD) {
-            if (n0 + LU_BN < n_end) load_dx(n0 + LU_BN, oq);
-        } else {
-            load_dx(n0, ocur);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < NTG; ++u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // tile (n0, u) landed for everyone; the other buffer's readers are done
+            if (u + 1 < NTG) lu_stage(q.A[u + 1] + n0, K, tiles + (cur ^ 1) * 64 * LU_BN, wave, lane);
+            else if (n0 + LU_BN < n_end) lu_stage(q.A[0] + n0 + LU_BN, K, tiles + (cur ^ 1) * 64 * LU_BN, wave, lane);
+            const bf16_t* tile = tiles + cur * 64 * LU_BN;
+            f32x16 acc[4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 4 + lr;
-            const int m = m0 + row;
-            if (m < M) {
-                bf16_t* dp = dx + (size_t)m * K + n0 + lc;
-                const u32x4 o = ocur[it];
-                const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * PITCH + lc);
-                const u32x4 d = drop_chunk(v, ((long)m * K + n0 + lc) / 8, thr, inv_keep, seed_lo, seed_hi);
-                u32x4 w;
+            for (int d = 0; d < 4; ++d)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = pack_bf2(bflo(d[e]) + bflo(o[e]), bfhi(d[e]) + bfhi(o[e]));
-                *reinterpret_cast<u32x4*>(dp) = w;
+                for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lu_tr_frag(tile, 32 * sub, sp, d, lane), pf[u][sub][sp], acc[d], 0, 0, 0);
+            // rows of the wave's 32 x 128 result through its slab (bf16), then 16-byte chunks: mask, scale, add into dx
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<u32x2*>(slab + r * PITCH + 32 * d + 8 * g4 + 4 * h) =
+                        u32x2{pack_bf2(acc[d][4 * g4], acc[d][4 * g4 + 1]), pack_bf2(acc[d][4 * g4 + 2], acc[d][4 * g4 + 3])};
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (u == 0) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) ocur[it] = oq[it];
+                if (MOLLY_LORA_UP_AHEAD) {
+                    if (n0 + LU_BN < n_end) load_dx(n0 + LU_BN, oq);
+                } else {
+                    load_dx(n0, ocur);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + lr;
+                const int m = m0 + row;
+                if (m < M) {
+                    const u32x4 o = ocur[it];
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * PITCH + lc);
+                    const u32x4 d = drop_chunk(v, ((long)m * K + n0 + lc) / 8, thr, inv_keep, q.seed_lo[u], q.seed_hi[u]);
+                    u32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = pack_bf2(bflo(d[e]) + bflo(o[e]), bfhi(d[e]) + bfhi(o[e]));
+                    ocur[it] = w;
+                    if (u + 1 == NTG) *reinterpret_cast<u32x4*>(dx + (size_t)m * K + n0 + lc) = w;
+                }
+            }
+            // (the slab is the wave's own: its reads above are ordered before the next target's writes by the LDS queue)
+            cur ^= 1;
         }
-        cur ^= 1;
     }
 }
 
@@ -389,26 +407,42 @@ extern "C" int molly_lora_down_drop_t_bf16(void* stream, const void* x, const vo
     return 0;
 }
 
-extern "C" int molly_lora_up_drop_acc_bf16(void* stream, const void* dt, const void* A, void* dx, int M, int K, int R, int lddt, float p,
-                                           uint64_t seed) {
+extern "C" int molly_lora_up_drop_acc_multi_bf16(void* stream, int n, const void* const* dt, const void* const* A, void* dx, int M, int K, int R,
+                                                 const int* lddt, float p, const uint64_t* seed) {
     MOLLY_ENTER();
+    MOLLY_CHECK(n >= 1 && n <= 3 && dt && A && lddt && seed, "lora_up_drop_acc: %d targets (1..3)", n);
     MOLLY_CHECK(M > 0 && K > 0 && K % 128 == 0, "lora_up_drop_acc: M=%d K=%d (K must be a positive multiple of 128)", M, K);
     MOLLY_CHECK(R == 64, "lora_up_drop_acc: padded rank %d (built for 64)", R);
-    MOLLY_CHECK(lddt % 4 == 0 && lddt >= R, "lora_up_drop_acc: lddt=%d", lddt);
-    MOLLY_CHECK(((uintptr_t)dt % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)dx % 16) == 0, "lora_up_drop_acc: alignment");
     MOLLY_CHECK(p >= 0.f && p < 1.f, "lora_up_drop_acc: p=%f not in [0,1)", (double)p);
+    MOLLY_CHECK(((uintptr_t)dx % 16) == 0, "lora_up_drop_acc: alignment");
+    UpDropArgs q{};
+    for (int u = 0; u < n; ++u) {
+        MOLLY_CHECK(lddt[u] % 4 == 0 && lddt[u] >= R, "lora_up_drop_acc: lddt=%d", lddt[u]);
+        MOLLY_CHECK(dt[u] && A[u] && ((uintptr_t)dt[u] % 8) == 0 && ((uintptr_t)A[u] % 16) == 0, "lora_up_drop_acc: alignment (target %d)", u);
+        q.dt[u] = (const bf16_t*)dt[u]; q.A[u] = (const bf16_t*)A[u]; q.lddt[u] = lddt[u];
+        q.seed_lo[u] = (uint32_t)seed[u]; q.seed_hi[u] = (uint32_t)(seed[u] >> 32);
+    }
     const uint32_t thr = (uint32_t)(p * 65536.f + 0.5f);
     const size_t lds = (2 * 64 * LU_BN + 4 * 32 * (LU_BN + 8)) * sizeof(bf16_t);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)lora_up_drop_acc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)lora_up_drop_acc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)lora_up_drop_acc_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)lora_up_drop_acc_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const dim3 grid((M + 127) / 128, (K + LU_NCH - 1) / LU_NCH);
-    hipLaunchKernelGGL(lora_up_drop_acc_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dt, (const bf16_t*)A, (bf16_t*)dx, M, K,
-                       lddt, thr, 1.f / (1.f - p), (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float inv_keep = 1.f / (1.f - p);
+    if (n == 1) hipLaunchKernelGGL(lora_up_drop_acc_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, q, (bf16_t*)dx, M, K, thr, inv_keep);
+    else if (n == 2) hipLaunchKernelGGL(lora_up_drop_acc_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, q, (bf16_t*)dx, M, K, thr, inv_keep);
+    else hipLaunchKernelGGL(lora_up_drop_acc_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, q, (bf16_t*)dx, M, K, thr, inv_keep);
     MOLLY_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int molly_lora_up_drop_acc_bf16(void* stream, const void* dt, const void* A, void* dx, int M, int K, int R, int lddt, float p,
+                                           uint64_t seed) {
+    return molly_lora_up_drop_acc_multi_bf16(stream, 1, &dt, &A, dx, M, K, R, &lddt, p, &seed);
 }
 
 extern "C" int molly_scale_bf16(void* stream, void* x, long n, float s) {

@@ -702,6 +702,26 @@ def lora_down_drop(x, A, p: float, seed: int, scale: float = 1.0, xd=None, out=N
     return out
 
 
+def lora_up_drop_acc_multi(dts, As, dx, p: float, seeds):
+    """dx[M, K] += sum over n <= 3 targets of mask_u * bf16(dt_u A_u), one read and one write of dx, the roundings of n lora_up_drop_acc launches one
+    after the other (molly_lora_up_drop_acc_multi_bf16): q | k | v (one input), gate | up."""
+    import ctypes
+    n = len(dts)
+    assert 1 <= n <= 3 and len(As) == n and len(seeds) == n
+    _chk(dx, BF16, "dx")
+    assert dx.is_contiguous()
+    M, K = dx.shape
+    for dt, A in zip(dts, As):
+        _chk(dt, BF16, "dt"); _chk(A, BF16, "A")
+        assert A.is_contiguous() and dt.stride(1) == 1 and tuple(dt.shape) == (M, A.shape[0]) and A.shape[1] == K and A.shape[0] == As[0].shape[0]
+    vp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dts])
+    ap = (ctypes.c_void_p * n)(*[t.data_ptr() for t in As])
+    ld = (ctypes.c_int * n)(*[t.stride(0) for t in dts])
+    sd = (ctypes.c_uint64 * n)(*[int(x) & ((1 << 64) - 1) for x in seeds])
+    lib().call("molly_lora_up_drop_acc_multi_bf16", _stream(), n, vp, ap, dx, M, K, As[0].shape[0], ld, float(p), sd)
+    return dx
+
+
 def lora_up_drop_acc(dt, A, dx, p: float, seed: int):
     """dx[M, K] += mask * bf16(dt[M, R] A[R, K]) in one launch (molly_lora_up_drop_acc_bf16): the LoRA branch's input gradient."""
     _chk(dt, BF16, "dt"); _chk(A, BF16, "A"); _chk(dx, BF16, "dx")

@@ -128,6 +128,7 @@ class Qwen3Engine:
                     self.A[-1]["lxd"] = {m: e(M, d) for m, d in dims.items()}
         if self.lora is not None:
             self.lora_dt = e(M, self.lora.rp)
+            self.lora_dt3 = e(M, 3 * self.lora.rp) if (training and _LORA_FUSED and os.environ.get("MOLLY_LORA_UP_MERGE", "1") != "0") else None
             self.lora_bT = e(self.lora.rp * max(self.nqkv, 2 * ff, h))
             # adapter gradients (dB, dA of the seven targets) of one layer as ONE grouped launch: each keeps its transposed
             # rank-r operand (t^T, dt^T: rp x M) until the layer's last dgrad; dropout(x) then has to survive the dA GEMM, so
@@ -368,8 +369,10 @@ class Qwen3Engine:
                 ops.transpose(t, a["ltT"][mod])
         ops.gemm_nt(t, lo.B[i][mod], out=y, accumulate=True)
 
-    def _lora_bwd(self, i: int, a: dict, mod: str, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool):
-        """dB (+)= dy^T t ; dt = s * dy B ; dA (+)= dt^T dropout(x) ; dx += mask * (dt A)."""
+    def _lora_bwd(self, i: int, a: dict, mod: str, x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool, group=None):
+        """dB (+)= dy^T t ; dt = s * dy B ; dA (+)= dt^T dropout(x) ; dx += mask * (dt A).
+        group (a list, or None): targets that share their input (q | k | v; gate | up) leave their (dt, A, seed) in it instead of launching the last
+        term — the caller adds all of them to dx in ONE pass (`_lora_bwd_flush`)."""
         lo = self.lora
         grouped = getattr(self, "lora_tT", None) is not None
         M = dy.shape[0]
@@ -382,7 +385,11 @@ class Qwen3Engine:
             self._pend.append((tt, dy, lo.dB[i][mod], True))           # dB^T[rp, out] = t^T dy, stored transposed
         else:
             self._wgrad(dy, a["lt"][mod], lo.dB[i][mod], accumulate)
-        dt = self.lora_dt
+        up_fused = lo.p > 0.0 and _LORA_FUSED and lo.rp == 64 and x.shape[1] % 128 == 0 and dx.is_contiguous()
+        if not (up_fused and getattr(self, "lora_dt3", None) is not None):
+            group = None
+        # (a group's dt's live side by side until its one pass over dx)
+        dt = self.lora_dt if group is None else self.lora_dt3[:, lo.rp * len(group):lo.rp * (len(group) + 1)]
         if _LORA_FUSED and lo.rp == 64 and dy.shape[1] % 64 == 0 and dy.stride(1) == 1 and dy.stride(0) % 8 == 0:
             # dt = s * dy B as an operand stream (dy read once at the HBM rate) instead of a 64-column grid on the 128 x 128 GEMM kernel:
             # B [out, 64] transposed into a scratch (a 5 us launch), then the skinny product with the scale in its epilogue
@@ -396,6 +403,8 @@ class Qwen3Engine:
             dtt_done = dtt is not None
         else:
             dtt_done = False
+            if group is not None:                                      # (the plain GEMM + scale want a contiguous dt)
+                group, dt = None, self.lora_dt
             self._dgrad(dy, lo.B[i][mod], dt)
             if lo.scale != 1.0:
                 ops.scale_(dt, lo.scale)
@@ -407,7 +416,9 @@ class Qwen3Engine:
             self._pend.append((dtt, xd, lo.dA[i][mod], False))         # dA[rp, in] = dt^T dropout(x)
         else:
             self._wgrad(dt, xd, lo.dA[i][mod], accumulate)
-        if lo.p > 0.0 and _LORA_FUSED and lo.rp == 64 and x.shape[1] % 128 == 0 and dx.is_contiguous():
+        if up_fused and group is not None:
+            group.append((dt, lo.A[i][mod], lo.mask_seed(i, mod)))
+        elif up_fused:
             ops.lora_up_drop_acc(dt, lo.A[i][mod], dx, lo.p, lo.mask_seed(i, mod))       # dx += mask * (dt A): one launch
         elif lo.p > 0.0:
             tmp = self.lora_tmp[:M * x.shape[1]].view(M, x.shape[1]) if grouped else xd   # (ungrouped: dropout(x) is dead by now)
@@ -415,6 +426,11 @@ class Qwen3Engine:
             ops.dropout(tmp, lo.p, lo.mask_seed(i, mod), out=dx, accumulate=True)
         else:
             ops.gemm(dt, lo.A[i][mod], out=dx, accumulate=True, b_kmajor=True)
+
+    def _lora_bwd_flush(self, group, dx: torch.Tensor):
+        """dx += sum of the group's mask * (dt A) terms: one read and one write of dx, the roundings of the per-target launches in their order."""
+        if group:
+            ops.lora_up_drop_acc_multi([g[0] for g in group], [g[1] for g in group], dx, self.lora.p, [g[2] for g in group])
 
     # ---- helpers ---------------------------------------------------------------------------------------------
     def _wgrad_layer(self, slot: int, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, xt=None):
@@ -548,8 +564,10 @@ class Qwen3Engine:
             dxn2 = spare[0]
             self._dgrad(self.d_gu, w["gu"], dxn2)
             if lora is not None:
-                self._lora_bwd(i, a, "gate_proj", a["xn2"], self.d_gu[:, :self.ff], dxn2, accumulate)
-                self._lora_bwd(i, a, "up_proj", a["xn2"], self.d_gu[:, self.ff:], dxn2, accumulate)
+                grp = []
+                self._lora_bwd(i, a, "gate_proj", a["xn2"], self.d_gu[:, :self.ff], dxn2, accumulate, group=grp)
+                self._lora_bwd(i, a, "up_proj", a["xn2"], self.d_gu[:, self.ff:], dxn2, accumulate, group=grp)
+                self._lora_bwd_flush(grp, dxn2)
             if tb:
                 self._wgrad_layer(2, self.d_gu, a["xn2"], g["gu"], accumulate, xt=a.get("xn2T"))
             dx2 = spare[1]
@@ -570,9 +588,11 @@ class Qwen3Engine:
             dxn = spare[0]
             self._dgrad(self.d_qkv, w["qkv"], dxn)
             if lora is not None:
-                self._lora_bwd(i, a, "q_proj", a["xn"], self.d_qkv[:, :nq], dxn, accumulate)
-                self._lora_bwd(i, a, "k_proj", a["xn"], self.d_qkv[:, nq:nq + nk_], dxn, accumulate)
-                self._lora_bwd(i, a, "v_proj", a["xn"], self.d_qkv[:, nq + nk_:], dxn, accumulate)
+                grp = []
+                self._lora_bwd(i, a, "q_proj", a["xn"], self.d_qkv[:, :nq], dxn, accumulate, group=grp)
+                self._lora_bwd(i, a, "k_proj", a["xn"], self.d_qkv[:, nq:nq + nk_], dxn, accumulate, group=grp)
+                self._lora_bwd(i, a, "v_proj", a["xn"], self.d_qkv[:, nq + nk_:], dxn, accumulate, group=grp)
+                self._lora_bwd_flush(grp, dxn)
                 self._wgrad_flush(accumulate)                  # the layer's fourteen adapter gradients, one launch
             if tb:
                 self._wgrad_layer(0, self.d_qkv, a["xn"], g["qkv"], accumulate, xt=a.get("xnT"))

@@ -179,6 +179,28 @@ def test_fused_lora_input_gradient_equals_gemm_then_masked_accumulate(M, K):
     assert bool(((got.float() - exact).abs() <= 2 ** -6 * exact.abs() + 2 ** -6 * (dt.float() @ A.float()).abs() + 1e-3).all())
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_merged_lora_input_gradients_equal_the_launches_one_after_the_other(n):
+    """molly_lora_up_drop_acc_multi_bf16: the adapters that share an input (q | k | v: 3, gate | up: 2) add their mask * (dt A) terms to dx in ONE pass —
+    bit for bit the result of their launches one after the other (same masks, same order of the bf16 roundings); dt's are column slices of one buffer,
+    as the model passes them."""
+    from molly_amd import ops
+    M, K = 1024 + 40, 2048
+    g = torch.Generator(device="cuda").manual_seed(50 + n)
+    dts = (torch.randn(M, 64 * n, device="cuda", generator=g) / 4).bfloat16()
+    As = [(torch.randn(64, K, device="cuda", generator=g) / 4).bfloat16() for _ in range(n)]
+    base = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    p, seeds = 0.05, [(u << 40) | 12345 + u for u in range(n)]
+    ref = base.clone()
+    for u in range(n):
+        ops.lora_up_drop_acc(dts[:, 64 * u:64 * (u + 1)], As[u], ref, p, seeds[u])
+    got = base.clone()
+    ops.lora_up_drop_acc_multi([dts[:, 64 * u:64 * (u + 1)] for u in range(n)], As, got, p, seeds)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    assert not torch.equal(got, base)
+
+
 def test_lora_forward_backward_vs_oracle(tiny_meta):
     """r = 8 (padded to 64), alpha = 16 (scaling 2), no dropout: loss and every adapter / projector gradient against
     the oracle's autograd; GA semantics (accumulate=True adds)."""
