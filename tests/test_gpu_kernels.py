@@ -346,40 +346,111 @@ def test_attn_fwd_pipelined_forms_survive_a_running_maximum_that_explodes(pipe, 
     _close(o2.float().view(B, T, nh, hd).transpose(1, 2), r2.view(B, T, nh, hd).transpose(1, 2), 2e-2, 1e-2, "attn O (launch after a redo)")
 
 
-@pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [
+def _attn_ref_grads(q, k, v, do, B, T, nh, nkv, hd, scale, causal, lo=None, hi=None, chunk=1024):
+    """fp32 dQ / dK / dV of the same attention by the closed form (P = softmax(S), dV = P^T dO, dS = P * (dP - rowsum(dO * O)),
+    dQ = scale dS K, dK = scale dS^T Q), query rows in chunks so that T = 4096 fits.  A query row with no visible key (left padding
+    under the causal mask) has P = 0 by definition: it contributes NOTHING to dK / dV whatever its dO holds, and its dQ is 0 — so
+    dK and dV are comparable on every parametrisation, dead rows or not."""
+    M, g = B * T, nh // nkv
+    qh = q.float().view(B, T, nh, hd).transpose(1, 2)
+    kh = k.float().view(B, T, nkv, hd).transpose(1, 2).repeat_interleave(g, 1)
+    vh = v.float().view(B, T, nkv, hd).transpose(1, 2).repeat_interleave(g, 1)
+    doh = do.float().view(B, T, nh, hd).transpose(1, 2)
+    idx = torch.arange(T, device=q.device)
+    dq = torch.zeros(B, nh, T, hd, device=q.device)
+    dk = torch.zeros(B, nh, T, hd, device=q.device)
+    dv = torch.zeros(B, nh, T, hd, device=q.device)
+    live = torch.zeros(B, nh, T, dtype=torch.bool, device=q.device)
+    for r0 in range(0, T, chunk):
+        r1 = min(T, r0 + chunk)
+        s = qh[:, :, r0:r1] @ kh.transpose(2, 3) * scale
+        ok = torch.ones(B, 1, r1 - r0, T, dtype=torch.bool, device=q.device)
+        if causal:
+            ok = ok & (idx[None, :] <= idx[r0:r1, None])[None, None]
+        if lo is not None:
+            ok = ok & ((idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None]))[:, None, None, :]
+        alive = ok.any(-1, keepdim=True)
+        s = s.masked_fill(~ok, float("-inf")).masked_fill(~alive, 0.0)
+        p = torch.softmax(s, -1) * alive
+        o = p @ vh
+        dp = doh[:, :, r0:r1] @ vh.transpose(2, 3)
+        ds = p * (dp - (doh[:, :, r0:r1] * o).sum(-1, keepdim=True))
+        dq[:, :, r0:r1] = ds @ kh * scale
+        dk += ds.transpose(2, 3) @ qh[:, :, r0:r1] * scale
+        dv += p.transpose(2, 3) @ doh[:, :, r0:r1]
+        live[:, :, r0:r1] = alive[..., 0].expand(B, nh, r1 - r0)
+    fold = lambda t: t.view(B, nkv, g, T, hd).sum(2).transpose(1, 2).reshape(M, nkv * hd)
+    return dq.transpose(1, 2).reshape(M, nh * hd), fold(dk), fold(dv), live.transpose(1, 2).reshape(M, nh)
+
+
+def _ragged_ranges(kind, B, T, left=5, cut=41):
+    """kind: False = full rows | True = sample 1 left- AND right-padded (its first `left` queries see no key under the causal mask) |
+    "right" = sample 1 right-padded only (lo = 0, hi < T: what the training collate emits)."""
+    if not kind:
+        return None, None
+    lo = torch.zeros(B, device=DEV, dtype=torch.int32)
+    hi = torch.full((B,), T, device=DEV, dtype=torch.int32)
+    if kind is True:
+        lo[-1] = left
+    hi[-1] = T - cut
+    return lo, hi
+
+
+ATTN_BWD_CASES = [
     (128, 4, 2, 256, True, False), (128, 4, 2, 200, True, True), (64, 2, 2, 128, False, True),
     (128, 2, 1, 320, True, True),
-    (128, 16, 8, 2048, True, False), (128, 8, 2, 4096, True, True), (64, 20, 20, 1024, False, False)])   # real lengths
-def test_attn_bwd(hd, nh, nkv, T, causal, ragged):
+    (128, 16, 8, 2048, True, False), (128, 8, 2, 4096, True, True), (64, 20, 20, 1024, False, False),   # real lengths
+    (128, 16, 8, 2048, True, "right")]                                                                   # right-padded, causal, the step's length
+
+
+def _attn_bwd_run(hd, nh, nkv, T, causal, ragged, cut=41):
     B = 2
     M = B * T
     qkv = _rand(M, (nh + 2 * nkv) * hd, seed=30, scale=0.7).to(BF)
     q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
-    lo = hi = None
-    if ragged:
-        lo = torch.tensor([0, 5], device=DEV, dtype=torch.int32)
-        hi = torch.tensor([T, T - 41], device=DEV, dtype=torch.int32)
+    lo, hi = _ragged_ranges(ragged, B, T, cut=cut)
     scale = hd ** -0.5
     o, lse = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, lo, hi)
-    do = _rand(M, nh * hd, seed=31).to(BF)
+    do = _rand(M, nh * hd, seed=31).to(BF)                     # NOT zeroed on dead rows: the kernels must ignore them by themselves
     dqkv = torch.zeros_like(qkv)
     dq, dk, dv = dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd], dqkv[:, (nh + nkv) * hd:]
     ops.attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, causal, dq, dk, dv, lo, hi)
-    # reference: autograd through the fp32 statement
-    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
-    ro, rl = _attn_ref(qr, kr, vr, B, T, nh, nkv, hd, scale, causal, lo, hi)
-    live = torch.isfinite(rl).transpose(1, 2).reshape(M, nh)            # rows with >= 1 visible key
-    w = do.float().view(M, nh, hd) * live[..., None]
-    (ro.view(M, nh, hd) * w).sum().backward()
-    do_eff = (do.float().view(M, nh, hd) * live[..., None]).reshape(M, nh * hd)
-    assert torch.equal(do_eff.to(BF), do) or True
-    g = lambda t: torch.nan_to_num(t.grad, nan=0.0)
-    # dead query rows produce zero dQ in both; compare everything
-    dq_ref = g(qr) * live[..., None].expand(M, nh, hd).reshape(M, nh * hd)
-    _close(dq * live[..., None].expand(M, nh, hd).reshape(M, nh * hd), dq_ref, 3e-2, 2e-2, "dQ")
-    if bool(live.all()):
-        _close(dk, g(kr), 4e-2, 2e-2, "dK")
-        _close(dv, g(vr), 4e-2, 2e-2, "dV")
+    rq, rk, rv, live = _attn_ref_grads(q, k, v, do, B, T, nh, nkv, hd, scale, causal, lo, hi)
+    return (dq, dk, dv), (rq, rk, rv), live
+
+
+def _attn_bwd_check(got, ref, live, nh, hd):
+    dq, dk, dv = got
+    rq, rk, rv = ref
+    lm = live[..., None].expand(-1, nh, hd).reshape(live.shape[0], nh * hd)
+    assert float((dq.float() * ~lm).abs().max()) == 0.0, "dQ of a query row that sees no key must be exactly 0"
+    _close(dq, rq, 3e-2, 2e-2, "dQ")
+    _close(dk, rk, 4e-2, 2e-2, "dK")          # always: dead query rows contribute nothing in the reference either
+    _close(dv, rv, 4e-2, 2e-2, "dV")
+
+
+@pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", ATTN_BWD_CASES)
+def test_attn_bwd(hd, nh, nkv, T, causal, ragged):
+    """dQ, dK and dV against the fp32 closed form on EVERY parametrisation (round 6: the dK / dV comparison used to be skipped whenever
+    a sample had dead query rows, i.e. on every causal + left-padded case)."""
+    got, ref, live = _attn_bwd_run(hd, nh, nkv, T, causal, ragged)
+    if ragged is True and causal:
+        assert not bool(live.all())                             # the case has the dead rows it is there for
+    _attn_bwd_check(got, ref, live, nh, hd)
+
+
+@pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [(128, 4, 2, 200, True, True), (128, 16, 8, 2048, True, "right")])
+@pytest.mark.parametrize("what", ["dK", "dV"])
+def test_attn_bwd_check_notices_one_zeroed_key_tile(hd, nh, nkv, T, causal, ragged, what):
+    """The comparison above is only worth something if it FAILS on a broken kernel: one 64-key tile of one kv head of dK (or dV) zeroed by
+    hand must trip it."""
+    got, ref, live = _attn_bwd_run(hd, nh, nkv, T, causal, ragged)
+    broken = [t.clone() for t in got]
+    t = broken[1 if what == "dK" else 2]
+    t[T + 64:T + 128, hd:2 * hd] = 0                           # sample 1, keys 64..127, kv head 1
+    with pytest.raises(AssertionError, match=what):
+        _attn_bwd_check(broken, ref, live, nh, hd)
+    _attn_bwd_check(got, ref, live, nh, hd)
 
 
 @pytest.mark.parametrize("nh,nkv,T,ragged", [(32, 8, 1024, False), (16, 8, 2048, True), (8, 2, 1000, True), (32, 8, 3072, False)])
@@ -414,12 +485,12 @@ def test_attn_bwd_split_by_query_head(nh, nkv, T, ragged):
     d = (outs[0].float() - outs[1].float()).abs().max().item()
     ref = outs[0].float().abs().max().item()
     assert d <= 2e-2 * ref, (d, ref)
-    if not ragged and T <= 1024:
-        qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
-        ro, rl = _attn_ref(qr, kr, vr, B, T, nh, nkv, hd, scale, True, None, None)
-        (ro * do.float()).sum().backward()
-        _close(outs[1][:, nh * hd:(nh + nkv) * hd], kr.grad, 4e-2, 2e-2, "dK (split)")
-        _close(outs[1][:, (nh + nkv) * hd:], vr.grad, 4e-2, 2e-2, "dV (split)")
+    # against fp32 at every length, ragged or not (round 6: was T <= 1024 and unpadded only)
+    rq, rk, rv, live = _attn_ref_grads(q, k, v, do, B, T, nh, nkv, hd, scale, True, lo, hi)
+    for name, o_ in (("unsplit", outs[0]), ("split", outs[1])):
+        _close(o_[:, :nh * hd], rq, 3e-2, 2e-2, f"dQ ({name})")
+        _close(o_[:, nh * hd:(nh + nkv) * hd], rk, 4e-2, 2e-2, f"dK ({name})")
+        _close(o_[:, (nh + nkv) * hd:], rv, 4e-2, 2e-2, f"dV ({name})")
 
 
 def test_ce_fwd_bwd_matches_torch():
