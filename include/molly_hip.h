@@ -122,6 +122,9 @@ enum {
                                              that forms silu(gate) * up from its accumulators (no slabs, no combine launch), tile chosen by the launcher;
                                              32 | 64 | 128 = that many W rows per tile; 0 = K slices + the combine launch */
     MOLLY_GEMM_KEY_ROWS_BN = 16,          /* W rows per tile of the tiled decode-row kernel at M <= 32: 64 (default) | 128 */
+    MOLLY_GEMM_KEY_STREAM_EPI = 17,       /* 1 (default; env MOLLY_GEMM_STREAM_EPI): plain NT launches of whole interior 256x256 tiles (M, N multiples of 256,
+                                             one K slice, no epilogue flag) run the streaming-epilogue instantiation: whole-line stores from inside the K
+                                             loop, which runs on into the next tile (bit-identical results; last_config 514); 0 = epilogue after the K loop */
     MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };

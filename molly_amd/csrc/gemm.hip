@@ -67,6 +67,12 @@ struct GemmArgs {
 #ifndef MOLLY_GEMM_RES_AHEAD
 #define MOLLY_GEMM_RES_AHEAD 4     // row groups of the residual in flight ahead of the residual-add epilogue (of 8)
 #endif
+#ifndef MOLLY_GEMM_DIAG_NOEPI
+#define MOLLY_GEMM_DIAG_NOEPI 0     // timing-only diagnostic builds (tools/build_variant.py): 1 = the plain 16-byte epilogue neither packs nor stores
+#endif                              // (wrong results; the accumulators are kept live) — the upper bound of what hiding the epilogue can buy
+#ifndef MOLLY_GEMM_SE_FORM
+#define MOLLY_GEMM_SE_FORM 1        // streaming epilogue: 1 = the product; 2 = timing-only diagnostic, the row halves are packed but never stored
+#endif
 #ifndef MOLLY_GEMM_SBW_AHEAD
 #define MOLLY_GEMM_SBW_AHEAD 2     // row groups of gate / up in flight ahead of the SwiGLU-backward epilogue's arithmetic (of 8)
 #endif
@@ -191,7 +197,9 @@ __device__ __forceinline__ int stage_offsets_kc(int ld, int row0, int rows_total
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         int rel = (wave * PER + i) * RPI + r_in;
-        if (remap_ff) rel = ((rel >> 5) & 1) * remap_ff + (rel >> 6) * 32 + (rel & 31);   // ff % 128 == 0: no ragged tile
+        if (remap_ff > 0) rel = ((rel >> 5) & 1) * remap_ff + (rel >> 6) * 32 + (rel & 31);   // ff % 128 == 0: no ragged tile
+        // (remap_ff < 0, the streaming epilogue: LDS row 64 w + 16 j + f holds row 64 w + 4 f + j — whole tiles only)
+        else if (remap_ff < 0) rel = (rel & 64) + ((rel & 15) << 2) + ((rel >> 4) & 3);
         else rel = rel < last ? rel : last;
         off[i] = ((unsigned)rel * (unsigned)ld + (unsigned)(c_src * 8)) * 2u;
     }
@@ -465,8 +473,27 @@ __device__ __forceinline__ void regroup_rows(unsigned& x0, unsigned& x1) {
 // takes what is left instead of finding its share untouched.  Every block of a label draws exactly one ticket past the end; the
 // block that draws the LAST one (n + blocks - 1) puts the counter back to zero — after it, nobody in this launch reads it again.
 // Results are identical to the static walk's (a tile is computed the same way whoever computes it).
-template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false, bool DYN = false, bool KX = false>
+//
+// SE: STREAMING EPILOGUE WITH WHOLE-LINE STORES (round 6; the NT form).  Two findings behind it (profiles/r06_logs/):
+//  * what a tile's 128 KB of output cost is a property of ONE CU's store path, not of the chip: tools/r06/store_diag/store_bench.hip — 8,600 cycles
+//    per tile for the regrouped 16-byte stores of the fast16 epilogue below, whether 8 or 256 CUs store at that moment, because the swapped MFMA
+//    operands leave the ROW index in the low four lane bits: sixteen consecutive lanes touch sixteen different 128-byte lines.  The same bytes
+//    as instructions whose sixteen consecutive lanes cover ONE line: 5,500 cycles at 8 bytes per lane, 3,550 at 16;
+//  * with no epilogue at all (timing-only build) the K = 2048 forward shapes run 9-12 % faster, and packing / regrouping inside the K loop's
+//    load segments is free (ab_se_2.log): the time is the stores'.
+// So here the MFMA operands are NOT swapped (lane (fr, fq) owns rows 4 fq + e of column fr of each 16 x 16 block) and the B half-tiles are staged
+// with their rows interleaved (the LDS-DMA source address is per lane: free) — LDS row 16 j + f of a wave's 64 holds weight row 4 f + j — so a
+// lane's four column blocks j are four CONSECUTIVE output columns: 8 bytes per lane and row, sixteen lanes = one whole 128-byte line, four lines
+// per store instruction, and no lane swaps at all.  The four-phase schedule finishes the tile's upper row half (m0) with P1 of the LAST K-tile and
+// the lower (m1) with P3, so the upper half is packed and stored in that K-tile's P2 load segment and the lower half in P1 of the NEXT tile's
+// first K-tile, beside the partner group's MFMA segments; the K loop runs on into the next work item (no closing / opening barriers, the wave
+// groups keep their stagger, the staging ring keeps rolling; a tile's first K-tile takes a zero C operand instead of zeroed accumulators).  The
+// stores sit between LDS-DMA pieces in the in-order vmcnt queue, so the counted waits next to a boundary are vmcnt(24).
+// Launched for grids of whole interior tiles (M, N multiples of 256), one K slice, >= 3 K-tiles, no epilogue flag; bit-identical to the
+// plain instantiation (same products in the same order, same roundings).
+template <bool AT, bool BT, bool TO = false, bool P2 = false, bool GRP = false, bool SKM = false, bool DYN = false, bool KX = false, int SE = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    static_assert(!SE || (!AT && !BT && !TO && !P2 && !GRP && !SKM && !DYN && !KX), "the streaming epilogue exists on the plain four-phase NT kernel");
     static_assert(!KX || (!AT && !BT && !TO && !P2 && !GRP && !SKM && !DYN), "the K-extension exists on the plain four-phase NT kernel");
     static_assert(!SKM || (!P2 && !GRP), "stream-K exists on the four-phase, single-problem kernel");
     static_assert(!DYN || (!P2 && !GRP && !SKM), "the dynamic tile fetch exists on the four-phase, single-problem kernel");
@@ -585,6 +612,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
     }
     Tile cur = decode(vcur);
+#ifdef MOLLY_GEMM_SE_SKEW_TICKS
+    // timing-only diagnostic (tools/build_variant.py): the blocks start in eight groups MOLLY_GEMM_SE_SKEW_TICKS x 10 ns apart, so that their tile
+    // boundaries — and the 128 KB of stores each brings — no longer fall on one moment chip-wide
+    if constexpr (SE != 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long dl = (unsigned long long)((blockIdx.x >> 3) & 7) * MOLLY_GEMM_SE_SKEW_TICKS;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < dl) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
 
     f32x4 acc[8][4];
     // LDS = 10 half-tile slots (all 160 KiB): A triple-buffered [3][A0|A1], then B double-buffered [2][B0|B1]
@@ -624,8 +660,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             b0 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0 >> 1, s_N, wi, lane, s_N >> 1, off2);
             b1 = stage_offsets_kc<128, NWI, BK>(s_ldb, (t.n0 >> 1) + 64, s_N, wi, lane, s_N >> 1, off3);
         } else {
-            b0 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0, s_N, wi, lane, 0, off2);
-            b1 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0 + 128, s_N, wi, lane, 0, off3);
+            b0 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0, s_N, wi, lane, SE ? -1 : 0, off2);
+            b1 = stage_offsets_kc<128, NWI, BK>(s_ldb, t.n0 + 128, s_N, wi, lane, SE ? -1 : 0, off3);
         }
         sp0 = reinterpret_cast<const char*>(s_A + ka + (AT ? (long)a0 : (long)a0 * s_lda));
         sp1 = reinterpret_cast<const char*>(s_A + ka + (AT ? (long)a1 : (long)a1 * s_lda));
@@ -748,6 +784,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     int abuf = 0, bbuf = 0;                   // LDS slots of the current K-tile (A: 0..2, B: 0..1)
 
     unsigned tk = 0, tk_here = 0;             // dynamic fetch: the ticket in flight (lane 0 of wave 0) and its copy once it has arrived
+    bool se_first = true;                     // SE: no tile of this block has been computed yet
+    char* se_pc = nullptr;                    // SE: the previous tile's base (its lower row half is stored in this tile's first K-tile)
+    // SE: the lane's byte offset inside any tile: row wr * 128 + 4 fq, column wc * 64 + 4 fr (rows x ldc stay far below 2^31 bytes: host check)
+    const unsigned se_loff = SE ? (unsigned)(((wr * 128 + (lane >> 4) * 4) * p.ldc + wc * 64 + (lane & 15) * 4) * 2) : 0u;
     for (;;) {
     // (dynamic fetch: unknown until the ticket arrives at K-tile nk - 3 — both are only read from K-tile nk - 2 on)
     int vnext = vcur + 1;
@@ -755,19 +795,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int nk = cur.nk;
     int t_stage_end = (roll && more) ? nk : nk - 2;             // loop iterations T < t_stage_end stage a K-tile (T + 2)
     const bool cto = tto(cur);
+    // (SE: a tile after the first starts with its K-tile 0 landed behind the previous loop's last counted wait and inside the barriers of the loop it continues,
+    // and its accumulators are never zeroed: the MFMAs of a tile's first K-tile take a zero C operand)
+    if constexpr (!SE) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // wait for K-tile 0 only.  Outstanding, oldest first: [K-tile 0: 8][K-tile 1: 8 if nk > 1][previous epilogue stores].
     // vmcnt counts loads and stores together in issue order, so with exactly 32 stores behind the loads the counted wait
     // lets all of them (and K-tile 1) stay in flight; any other epilogue falls back to a conservative count.
     if (!landed0) wait_vm((nk > 1 ? 8 : 0) + pend_stores);
     // the first counted wait of a tile sits behind the previous epilogue's stores: [K-tile 1: 8][stores]
     // [K-tile 2: 8] — K-tile 1 has landed once all but the stores and K-tile 2's pieces are done
-    const int first_wait = 8 + pend_stores;
+    const int first_wait = 8 + pend_stores;      // (SE: the counted waits are written into ktile_se)
+    if (!SE || se_first) {
     SEG_BARRIER();
     if (wr == 1) SEG_BARRIER();               // stagger: group 1 runs one segment behind group 0
+    }
+    // SE: this tile's output as the lane sees it: rows m0 + wr * 128 + 4 fq (+ e, + 16 i), columns n0 + wc * 64 + 4 fr .. + 3
+    // (a wave-uniform tile base + one per-lane byte offset that never changes: the stores take their base from scalar registers)
+    char* se_c = nullptr;
+    if constexpr (SE != 0) se_c = reinterpret_cast<char*>(p.C) + ((size_t)cur.m0 * p.ldc + cur.n0) * 2;
+    // one finished row half (MH) of the wave's 128 x 64: 16 stores of 8 bytes per lane, each four whole 128-byte lines
+    auto se_half = [&](auto mh_tag, char* cb) {
+        constexpr int MH = decltype(mh_tag)::value;
+        {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = MH * 4 + ii;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32x2 d = u32x2{pack_bf2(acc[i][0][e], acc[i][1][e]), pack_bf2(acc[i][2][e], acc[i][3][e])};
+#if MOLLY_GEMM_SE_FORM == 2
+                    asm volatile("" :: "v"(d));
+#else
+                    *reinterpret_cast<u32x2*>(cb + (size_t)(i * 16 + e) * p.ldc * 2 + se_loff) = d;
+#endif
+                }
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
 
     // LDS-DMA schedule (one K-tile = 4 half-tiles = 8 instructions per wave), every piece >= 4 phases ahead of its use:
     //   P0 (most operand reads) issues nothing | P1 -> A0(T+2) | P2 -> A1(T+2) | P3 (no reads) -> B0(T+2), B1(T+2)
@@ -906,12 +977,93 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         bbuf ^= 1;
     }
     };
-    if constexpr (GRP) {               // grouped launch: the output orientation is a per-problem property
+    // ---- SE: the same four phases, written out three times — a tile's FIRST K-tile (MODE 0: its MFMAs take a zero C operand; the previous tile's
+    // lower row half leaves in P1), its MIDDLE K-tiles (MODE 1) and its LAST (MODE 2: the upper row half leaves in P2).  Explicit bodies
+    // instead of run-time tests inside one loop: with the accumulators written under a condition hipcc kept two homes for them and moved quadrants
+    // through scratch memory between MFMAs.
+#define MMA_QUAD0(MH, NH, AF, BF)                                                                           \
+    do {                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            acc[(MH) * 4 + i][(NH) * 2 + j] =                                                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0][i], BF[0][j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            acc[(MH) * 4 + i][(NH) * 2 + j] =                                                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1][i], BF[1][j], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    } while (0)
+    auto ktile_se = [&](auto mode_tag, int T) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool TOQ = true;                 // un-swapped operands: the lane owns four rows of one column per 16 x 16 block
+        if (MODE == 1 && T + 2 == nk && t_stage_end == nk) set_stream(decode(vnext));
+        // ---- P0: quadrant (m0,n0)
+        readB(bbuf, 0, b0);
+        readA(abuf, 0, af);
+        SEG_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 0) MMA_QUAD0(0, 0, af, b0); else MMA_QUAD(0, 0, af, b0);
+        SEG_BARRIER();
+        // ---- P1: quadrant (m0,n1)
+        readB(bbuf, 1, b1);
+        stage2(T, 0);
+        if constexpr (MODE == 0) { if (!se_first) se_half(I1{}, se_pc); }      // the PREVIOUS tile's lower row half
+        SEG_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 0) MMA_QUAD0(0, 1, af, b1); else MMA_QUAD(0, 1, af, b1);
+        SEG_BARRIER();
+        // ---- P2: quadrant (m1,n1)
+        readA(abuf, 1, af);
+        stage2(T, 1);
+        if constexpr (MODE == 2) se_half(I0{}, se_c);                            // rows m0: final since P1
+        SEG_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 0) MMA_QUAD0(1, 1, af, b1); else MMA_QUAD(1, 1, af, b1);
+        SEG_BARRIER();
+        // ---- P3: quadrant (m1,n0); retire K-tile T+1
+        if (T < t_stage_end) {
+            stage2(T, 2); stage2(T, 3);
+            // MODE 0 behind a streamed tile: younger than K-tile 1's last piece are the sixteen stores of the previous tile's lower half (this K-tile's
+            // P1) and K-tile 2's eight pieces; MODE 2: the sixteen stores of the upper half sit between the eight pieces staged in this iteration
+            if ((MODE == 0 && !se_first) || MODE == 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        SEG_BARRIER();
+        if constexpr (MODE == 0) MMA_QUAD0(1, 0, af, b0); else MMA_QUAD(1, 0, af, b0);
+        SEG_BARRIER();
+        abuf = abuf == 2 ? 0 : abuf + 1;
+        bbuf ^= 1;
+    };
+    if constexpr (SE) {
+        ktile_se(std::integral_constant<int, 0>{}, 0);
+        for (int T = 1; T < nk - 1; ++T) ktile_se(std::integral_constant<int, 1>{}, T);
+        ktile_se(std::integral_constant<int, 2>{}, nk - 1);
+    } else if constexpr (GRP) {               // grouped launch: the output orientation is a per-problem property
         if (cto) kloop4(std::true_type{});
         else kloop4(std::false_type{});
     } else {
         kloop4(std::integral_constant<bool, TO>{});
     }
+    }
+    if constexpr (SE) {
+        if (more) {
+            // the loop continues into the next work item: Q(m1,n0) leaves in its first K-tile
+            se_pc = se_c;
+            se_first = false;
+            landed0 = true;
+            vcur = vnext;
+            cur = decode(vnext);
+            continue;
+        }
+        if (wr == 0) SEG_BARRIER();
+        se_half(I1{}, se_c);
+        break;
     }
     if (wr == 0) SEG_BARRIER();               // balance the stagger barrier (every LDS read of this tile has returned)
 
@@ -1175,6 +1327,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    } else if (MOLLY_GEMM_DIAG_NOEPI && fast16 && p.flags == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else if (fast16) {
         bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + en0 + wc * 64 + fq * 8;
         if (p.flags == 0) {
@@ -1446,6 +1603,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     cur = nxt;
     }   // persistent tile loop
 #undef MMA_QUAD
+#undef MMA_QUAD0
 #undef SEG_BARRIER
 }
 
@@ -2061,6 +2219,11 @@ struct GemmCtx {
                                    // through the 256x256 kernel (round 2's path; A/B)
     int skinny = 1;                // 1 = M <= 64 forward GEMMs (decode rows) on the weight-streaming kernel; 0 = split-K through the tile kernel (A/B)
     int dynamic_min_work = 257;    // the dynamic fetch applies to launches of at least this many work items (default: more than one round)
+    int stream_epi = [] { const char* e = getenv("MOLLY_GEMM_STREAM_EPI"); return e ? atoi(e) : 1; }();
+                                   // 1 = plain NT launches of whole interior 256x256 tiles run gemm256_kernel<SE>: un-swapped MFMA operands, B rows interleaved
+                                   // at staging, each row half stored as whole 128-byte lines from the K loop's load segments, the loop running on into the
+                                   // next tile; 0 = the epilogue after the K loop (A/B).  Same-process A/B at M = 32,768 (profiles/r06_logs/ab_se_5.log):
+                                   // qkv forward 401.3 -> 383.6 us (1,370 -> 1,433 TF/s; hipBLASLt 1,386), 12,288 x 2,048: 1,168 -> 1,128 us; bit-identical
     int small_split = 1;           // 1 = small grids with long contractions priced for split-K (see launch_cfg); 0 = round 2's rule (A/B)
     int dynamic = 0;               // 1 = plain 256x256 launches of more than one round draw their tiles (gemm256_kernel<DYN>): for GEMMs that
                                    // run beside a collective's kernels (ranks of a multi-GPU job)
@@ -2127,6 +2290,10 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<AT, BT, TO, false, false, false, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if constexpr (!TO && !AT && !BT) {
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, false, false, false, false, false, false, false, 1>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        }
         attr_set = true;
     }
     // heuristic.  Whole rounds of the 256 CUs: the persistent 256x256 kernel, one tile after another.  Anything else with both
@@ -2252,7 +2419,19 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
             c.last_cfg += 1;                                       // 513: the 256x256 kernel drawing its tiles
             hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false, false, false, true>), dim3(256), dim3(512), 163840, st, p);
         } else if (two_phase(c)) hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, true>), dim3(grid), dim3(512), 163840, st, p);
-        else hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false>), dim3(grid), dim3(512), 163840, st, p);
+        else {
+            // the NT form on whole interior tiles, one K slice, the plain epilogue: the streaming-epilogue instantiation
+            bool se = false;
+            if constexpr (!TO && !AT && !BT) {
+                se = c.stream_epi && p.flags == 0 && p.splits == 1 && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 64 == 0 && nk >= 3 && p.ldc < (1 << 21);
+            }
+            if (se) {
+                if constexpr (!TO && !AT && !BT) {
+                    c.last_cfg += 2;                               // 514: the 256x256 kernel with the streaming epilogue
+                    hipLaunchKernelGGL((gemm256_kernel<false, false, false, false, false, false, false, false, 1>), dim3(grid), dim3(512), 163840, st, p);
+                }
+            } else hipLaunchKernelGGL((gemm256_kernel<AT, BT, TO, false>), dim3(grid), dim3(512), 163840, st, p);
+        }
         if (p.splits > 1) {
             const long MN = (long)p.M * p.N;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)min((MN / 4 + 255) / 256, 4096L)), dim3(256), 0, st, p.ws,
@@ -2667,6 +2846,10 @@ int ctx_set(GemmCtx& c, int key, long v) {
         MOLLY_CHECK(v == 0 || v == 1, "gemm dynamic: %ld not in {0,1}", v);
         c.dynamic = (int)v;
         return 0;
+    case MOLLY_GEMM_KEY_STREAM_EPI:
+        MOLLY_CHECK(v == 0 || v == 1, "gemm stream_epi: %ld not in {0,1}", v);
+        c.stream_epi = (int)v;
+        return 0;
     case MOLLY_GEMM_KEY_SMALL_SPLIT:
         MOLLY_CHECK(v == 0 || v == 1, "gemm small_split: %ld not in {0,1}", v);
         c.small_split = (int)v;
@@ -2851,6 +3034,7 @@ extern "C" int molly_gemm_ctx_get(void* ctx, int key) {
     case MOLLY_GEMM_KEY_SMALL3: return c.small3;
     case MOLLY_GEMM_KEY_DYNAMIC: return c.dynamic;
     case MOLLY_GEMM_KEY_SMALL_SPLIT: return c.small_split;
+    case MOLLY_GEMM_KEY_STREAM_EPI: return c.stream_epi;
     case MOLLY_GEMM_KEY_ROWS_TILED: return c.rows_tiled;
     case MOLLY_GEMM_KEY_DYNAMIC_MIN_WORK: return c.dynamic_min_work;
     case MOLLY_GEMM_KEY_ROWS_MAX_M: return c.rows_max_m;

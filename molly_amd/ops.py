@@ -60,7 +60,7 @@ def _chk(t: torch.Tensor, dtype=None, name="tensor"):
 # thread's default context of the library is used (tools, kernel tests).  A model owns one (OmicsOne.prepare), so an optimizer
 # that wants another launch shape at N > 1 changes ITS model's context and nothing else in the process.
 GEMM_KEYS = {"persistent_blocks": 1, "schedule": 2, "force_tile": 3, "group_m": 4, "small_grid_tile": 5, "min_ktiles": 6,
-             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "small_split": 11, "rows_tiled": 12, "dynamic_min_work": 13, "rows_max_m": 14, "rows_gu": 15, "rows_bn": 16, "last_config": 100}
+             "streamk": 7, "skinny": 8, "small3": 9, "dynamic": 10, "small_split": 11, "rows_tiled": 12, "dynamic_min_work": 13, "rows_max_m": 14, "rows_gu": 15, "rows_bn": 16, "stream_epi": 17, "last_config": 100}
 STREAMK_SCRATCH = (64 + 8192 * 64 + 8 * 64) + 256 * 2 * 262144   # header (a counter line per tile) + two 256 KiB accumulator images per block of a 256-block launch
 
 

@@ -1314,6 +1314,55 @@ def test_gemm_launch_shapes_are_bit_identical(form, M, N, K, res):
     _close(outs[0], ref, 2e-2, 2e-2, "gemm vs fp32")
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 192), (2048, 1024, 256), (8192, 4096, 2048), (16384, 2048, 1024), (4096, 12288, 2048)])
+@pytest.mark.parametrize("blocks", [256, 0, -3])
+def test_gemm_streaming_epilogue_is_bit_identical(M, N, K, blocks):
+    """gemm256_kernel<SE> (round 6; context key stream_epi, on by default): plain NT launches of whole interior tiles run with un-swapped MFMA
+    operands, B rows interleaved at staging, and every row half stored as whole 128-byte lines from inside the K loop, which runs on into the next
+    tile.  Same products in the same order with the same roundings: the output must equal the plain instantiation's bit for bit — at three
+    K-tiles (first / middle / last bodies once each), with several tiles per block (the cross-tile store of the lower row half), and in every
+    launch shape — and a canary around the output must survive (a whole-line store one row off would hit it)."""
+    a = _rand(M, K, seed=91).to(BF)
+    b = _rand(N, K, seed=92, scale=0.05).to(BF)
+    outs, cfgs = [], []
+    for se in (0, 1):
+        ctx = ops.GemmContext()
+        ctx.ensure_workspace(64 << 20)
+        ctx.set("stream_epi", se)
+        ctx.set("persistent_blocks", blocks)
+        ctx.set("force_tile", 512)
+        buf = torch.full((M + 2, N), 7.0, dtype=BF, device=DEV)
+        with ops.use_gemm_context(ctx):
+            ops.gemm_nt(a, b, out=buf[1:M + 1])
+            cfgs.append(ctx.get("last_config"))
+        torch.cuda.synchronize()
+        assert bool((buf[0] == 7.0).all()) and bool((buf[M + 1] == 7.0).all()), "the rows around the output were written"
+        outs.append(buf[1:M + 1].clone())
+    assert cfgs == [1512, 1514], cfgs                             # 512 + 1000 x one K slice; + 2: the streaming epilogue
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[1], a.float() @ b.float().t(), 2e-2, 2e-2, "gemm (streaming epilogue) vs fp32")
+
+
+def test_gemm_streaming_epilogue_applies_only_where_it_is_built():
+    """Ragged tiles, an epilogue flag, a k-major operand or a K slice keep the plain instantiation (last_config says which ran)."""
+    ctx = ops.GemmContext()
+    ctx.ensure_workspace(64 << 20)
+    ctx.set("force_tile", 512)
+    with ops.use_gemm_context(ctx):
+        a, b = _rand(512, 256, seed=1).to(BF), _rand(512, 256, seed=2).to(BF)
+        ops.gemm_nt(a, b)
+        assert ctx.get("last_config") == 1514
+        ops.gemm_nt(a, b, res=_rand(512, 512, seed=3).to(BF))
+        assert ctx.get("last_config") == 1512                      # residual add
+        ops.gemm_nt(a[:500], b)
+        assert ctx.get("last_config") == 1512                      # ragged M
+        ops.gemm(a, _rand(256, 512, seed=4).to(BF), b_kmajor=True)
+        assert ctx.get("last_config") == 1512                      # the dgrad form
+        ops.gemm_nt(a[:, :128], b[:, :128])
+        assert ctx.get("last_config") == 1512                      # two K-tiles
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M", [1, 7, 16, 32, 33, 64])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (1000, 1280), (256, 256), (6144, 2560), (12288, 2048)])
 def test_gemm_decode_row_kernel(M, N, K):
