@@ -132,9 +132,9 @@ def _cpu_step_worker(which: str, threads: int, budget_s: float, warmups: int = 2
                       "tokens_per_step": B * T, "loss": float(loss.detach())}), flush=True)
 
 
-def _run_cpu_config(which: str, threads: int, budget_s: float):
+def _run_cpu_config(which: str, threads: int, budget_s: float, warmups: int = 2, timed: int = 5):
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", which, str(threads), str(budget_s)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", which, str(threads), str(budget_s), str(warmups), str(timed)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 3 + 120,
                            env={**os.environ, "HIP_VISIBLE_DEVICES": "", "WORLD_SIZE": "1"})
@@ -177,6 +177,14 @@ def cpu_baseline(budget_s: float = 150.0):
                                 f"{len(d1['step_seconds'])} timed steps {d1['step_seconds']} s, median {d1['median_seconds']:.2f} s")}
     else:
         out["c1"] = {"value": None, "sample": err1}
+    # SURVEY 8d prescribes the PHYSICAL core count; `value` uses 32 threads because that is this host's best case (above).  The prescribed
+    # figure is measured too, in a smaller box (1 warm-up + up to 2 timed steps), so that both are on record in every line
+    if physical > cores and d2 is not None:
+        dp, errp = _run_cpu_config("c2s", physical, min(budget_s, 100.0), warmups=1, timed=2)
+        out["physical_cores_run"] = ({"threads": physical, "value": round(dp["tokens_per_step"] / dp["median_seconds"], 2), "unit": "tokens/s",
+                                      "median_step_seconds": round(dp["median_seconds"], 3), "timed_steps": len(dp["step_seconds"]),
+                                      "sample": "the same down-scaled C2 step on every physical core (SURVEY 8d's prescription), 1 warm-up step"}
+                                     if dp is not None else {"threads": physical, "value": None, "sample": errp})
     return out
 
 
@@ -242,6 +250,8 @@ def _c5_worker():
     t_mid = T + 8 + (NEW - 8) / 2                                   # average cache length over the timed steps
     w_bytes = 2 * (p_layers + h * V)                                # every layer matrix + the (untied) lm_head, bf16
     kv_bytes = 2 * L * B * t_mid * nkv * hd * 2
+    t_mid_s = T + NEW + 4 + n_s / 2                                 # the sampled steps: average cache length over THEIR timed region
+    kv_bytes_s = 2 * L * B * t_mid_s * nkv * hd * 2
     out = {"workload": f"Molly-8B, LoRA merged at load, batch {B}, prompt {T} (one {K}-residue protein span), greedy, {NEW - 8} timed "
                        "decode steps through the captured hipGraph",
            "prefill": {"ms": round(pre_ms, 1), "tokens_per_s": round(B * T / pre_ms * 1e3, 1),
@@ -255,7 +265,9 @@ def _c5_worker():
            # src/inference_lora.py:293-298) — the fused sampling launch (csrc/sampling.hip) replaces the argmax of every step
            "decode_sampled": {"ms_per_step": round(samp_ms, 3), "tokens_per_s": round(B / samp_ms * 1e3, 1),
                               "settings": "do_sample, T 0.8, top_p 0.95, top_k 20, repetition_penalty 1.1", "steps_timed": int(n_s),
-                              "frac": round((w_bytes + kv_bytes) / samp_ms / 1e9 / HBM_PEAK_TBPS, 4)}}
+                              # (these steps run BEHIND the greedy ones: the cache is NEW tokens longer at their start, + 4 untimed sampled steps)
+                              "kv_cache_bytes": int(kv_bytes_s),
+                              "frac": round((w_bytes + kv_bytes_s) / samp_ms / 1e9 / HBM_PEAK_TBPS, 4)}}
     print(json.dumps(out), flush=True)
     return 0
 
@@ -396,6 +408,23 @@ def vendor_gemm_yardstick(dev, M):
     return out
 
 
+def copy_bandwidth(dev, nbytes: int = 1 << 30):
+    """TB/s (read + written) of a 1 GiB device-to-device copy — what HBM-bound kernels see on THIS box (best of 5, HIP events)."""
+    import torch
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return round(2.0 * nbytes / best / 1e9, 3)
+
+
 def clock_under_load(dev, M):
     """Shader clock and socket power while the step's dominant kernel runs (`rocm-smi`, read-only, polled beside ~2.5 s of queued gate|up forward
     GEMMs, OUTSIDE the timed region).  The part runs every heavy kernel at its power cap, so the clock — not 2.4 GHz — sets the matrix pipes' peak
@@ -463,6 +492,10 @@ def main(argv=None):
                     help="N > 1, neither --bucket-mib nor --rs-algo pinned: timed steps per (bucket size, reduce-scatter algorithm) candidate "
                          "of the sweep before the warm-up (untimed region; the fastest is kept, the table lands in comm.bucket_ab); 0 = off")
     ap.add_argument("--bucket-ab-mib", default="64,128,256,512,1024", help="bucket sizes (MiB of bf16) the sweep tries")
+    ap.add_argument("--tune-budget-s", type=float, default=120.0,
+                    help="N > 1: wall budget in seconds of the pre-warm-up tuning (bucket sweep, then the GEMM launch-shape A/B).  When a rank "
+                         "finds it exceeded before the next candidate, every rank stops together, the best so far is kept and "
+                         "comm.bucket_ab.truncated / not_run say so; 0 = no budget")
     ap.add_argument("--bucket-ab-algos", default="rccl,a2a",
                     help="reduce-scatter transports the sweep tries: rccl (the library's reduce-scatter), a2a (all_to_all + local fp32 sum), "
                          "p2p (direct reads / writes of mapped peer buffers, trainer/p2p.py: validated on one GPU only, so opt-in here)")
@@ -484,12 +517,12 @@ def main(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE configs 3 / 4 / 5 side measurements")
     ap.add_argument("--secondary-budget", type=float, default=420.0, help="wall-time box (s) of the whole secondary block")
     ap.add_argument("--secondary-worker", default=None, help="(internal) c3 | c4 | c5: run that side measurement, print its JSON")
-    ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("CONFIG", "THREADS", "BUDGET_S"))
+    ap.add_argument("--cpu-baseline-worker", nargs="+", metavar="CONFIG THREADS BUDGET_S [WARMUPS TIMED]")
     ap.add_argument("--dry-run-launch", action="store_true", help="print the rank launch command instead of running it")
     args = ap.parse_args(argv)
     if args.cpu_baseline_worker:
         w = args.cpu_baseline_worker
-        _cpu_step_worker(w[0], int(w[1]), float(w[2]))
+        _cpu_step_worker(w[0], int(w[1]), float(w[2]), *(int(x) for x in w[3:5]))
         return 0
     if args.secondary_worker == "c5":
         return _c5_worker()
@@ -625,19 +658,31 @@ def main(argv=None):
         total_mib = rt.P.flat.numel() * 2 / (1 << 20)
         sizes = sorted({min(float(x), total_mib) for x in args.bucket_ab_mib.split(",") if x.strip()})
 
-        def measure(mib, algo):
+        from molly_amd.trainer.zero2 import dist_agree
+
+        def build(mib, algo):
+            # the part that can fail on one rank only (memory for the layout's receive buffers, an IPC mapping): followed by a collective
+            # verdict inside sweep_exchange, so the ranks skip a candidate TOGETHER
             nonlocal opt
             opt = None
             m._rt.opt = None
             torch.cuda.empty_cache()
             opt = make_opt(mib, algo)
+
+        def measure(mib, algo):
             step(0)
             dtm, _, _ = timed_steps(args.bucket_ab_steps, 1)
             tm = torch.tensor([dtm], device=dev, dtype=torch.float64)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             return float(tm.item()) / args.bucket_ab_steps * 1e3
+
+        def bcast(obj):
+            box = [obj]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
         algos = [a.strip() for a in args.bucket_ab_algos.split(",") if a.strip()]
-        bucket_ab = sweep_exchange([(mib, algo) for algo in algos for mib in sizes], measure, args.bucket_ab_steps)
+        bucket_ab = sweep_exchange([(mib, algo) for algo in algos for mib in sizes], measure, args.bucket_ab_steps, build=build,
+                                   agree=dist_agree(dev), budget_s=args.tune_budget_s if args.tune_budget_s > 0 else None, broadcast=bcast)
         ch = bucket_ab["chosen"]
         opt = None
         m._rt.opt = None
@@ -645,9 +690,20 @@ def main(argv=None):
         opt = make_opt(ch["bucket_mib"], ch["rs_algo"])
 
     gemm_mode_ab = None
+    gemm_mode_truncated = False
     if world > 1 and opt.overlap and args.gemm_mode_ab_steps > 0 and "MOLLY_GEMM_PERSISTENT_MULTI" not in os.environ:
         gemm_mode_ab = {}
-        for mode in (-3, "dyn", 0):
+        _t_ab = time.monotonic()
+        _agree = None
+        for mi, mode in enumerate((-3, "dyn", 0)):
+            if mi > 0 and args.tune_budget_s > 0:
+                # the launch-shape A/B shares the pre-warm-up wall budget with the bucket sweep (what is left of it, at least a third): one rank
+                # over its budget stops every rank together, the best shape so far is kept
+                from molly_amd.trainer.zero2 import dist_agree
+                _agree = _agree or dist_agree(dev)
+                if not _agree(time.monotonic() - _t_ab <= max(args.tune_budget_s / 3.0, 1.0), None)[0]:
+                    gemm_mode_truncated = True
+                    break
             opt.set_gemm_blocks_mode(mode, m)
             step(0)
             dtm, _, _ = timed_steps(args.gemm_mode_ab_steps, 1)
@@ -657,6 +713,8 @@ def main(argv=None):
         best = min(gemm_mode_ab, key=gemm_mode_ab.get)              # same dict on every rank (all-reduced times)
         opt.set_gemm_blocks_mode("dyn" if best == "dyn" else int(best), m)
         gemm_mode_ab = {"ms_per_step": gemm_mode_ab, "chosen": best, "steps_each": args.gemm_mode_ab_steps}
+        if gemm_mode_truncated:
+            gemm_mode_ab["truncated"] = True
 
     for i in range(args.warmup):
         step(i)
@@ -693,7 +751,7 @@ def main(argv=None):
         comm = {"backend": backend, "world_size": dist.get_world_size(), "preflight": comm_check,
                 "comm_bytes_per_step_per_gpu": opt.comm_bytes_per_step(), "bucket_mib": round(opt.bucket * 2 / (1 << 20), 1),
                 "per_link_mib_per_bucket": round(opt.chunk * 2 / (1 << 20), 1), "buckets": len(opt.buckets),
-                "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo,
+                "overlap": bool(opt.overlap), "rs_algo": opt.rs_algo, "rs_algo_fallback": getattr(opt, "rs_algo_fallback", None),
                 # where the gradient sum is rounded: the library's reduce-scatter adds bf16 partial sums hop by hop (DeepSpeed's
                 # own behaviour with bf16 gradients); the all-to-all variant sums the `world` copies in fp32 on the owner, once
                 "reduce_dtype": ("fp32 on the owning rank, rank order, one rounding (all_to_all + molly_reduce_rows)" if opt.rs_algo == "a2a" else
@@ -854,6 +912,26 @@ def main(argv=None):
                 out["roofline"]["clock_under_load"] = clock_under_load(dev, B * T)
             except Exception as e:  # noqa: BLE001  (a yardstick: rocm-smi absent or unreadable must not cost the headline line)
                 out["roofline"]["clock_under_load"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+        # ---- what kind of box was this?  The devices of the pool differ by +-2.5 % in every MFMA-bound number (a power-capped part: the clock
+        # gives), more than a round's step changes.  Three box properties measured OUTSIDE the timed region and the headline divided by the
+        # vendor library's throughput on the step's largest forward shape make lines from different boxes comparable.
+        if world == 1 and not args.no_vendor_gemm:
+            cal = {}
+            vg = out["roofline"].get("vendor_gemm_tflops") or {}
+            if "gate|up fwd" in vg:
+                cal["torch_matmul_tflops"] = vg["gate|up fwd"]["torch_matmul"]
+                cal["torch_matmul_shape"] = "gate|up forward: M = %d, N = 12288, K = 2048 (hipBLASLt through torch.matmul, random data)" % (B * T)
+            cu = out["roofline"].get("clock_under_load") or {}
+            cal["sclk_mhz"] = cu.get("sclk_mhz")
+            try:
+                cal["copy_TBps"] = copy_bandwidth(dev)
+            except Exception as e:  # noqa: BLE001
+                cal["copy_TBps"] = None
+                cal["copy_error"] = f"{type(e).__name__}: {str(e)[:120]}"
+            out["box_calibration"] = cal
+            if cal.get("torch_matmul_tflops"):
+                # tokens/s per TFLOP/s the vendor's GEMM reaches on this box: moves with the code, not with the device
+                out["value_per_vendor_tflop"] = round(out["value"] / cal["torch_matmul_tflops"], 3)
         if world == 1 and not args.no_secondary and args.secondary_worker is None:
             # the other BASELINE configs, each in a child of its own: release this process's HBM first
             del m, opt, rt, batches

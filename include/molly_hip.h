@@ -125,7 +125,7 @@ enum {
     MOLLY_GEMM_KEY_STREAM_EPI = 17,       /* 1 (default; env MOLLY_GEMM_STREAM_EPI): plain NT launches of whole interior 256x256 tiles (M, N multiples of 256,
                                              one K slice, no epilogue flag) run the streaming-epilogue instantiation: whole-line stores from inside the K
                                              loop, which runs on into the next tile (bit-identical results; last_config 514); 0 = epilogue after the K loop */
-    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
+    MOLLY_GEMM_KEY_LAST_CONFIG = 100      /* read-only: 16 (decode-row kernel) | 32 (tiled decode-row kernel) | 128 | 512 | 513 (512 drawing its tiles) | 514 (512 with the streaming epilogue) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems
                                              of a grouped launch) of the context's most recent launch */
 };
 /* C = A B^T + A2 B2^T (+ the epilogue `flags` of molly_gemm_bf16: bias, GELU, residual, accumulate, or MOLLY_GEMM_SWIGLU) in ONE accumulation:
@@ -436,12 +436,15 @@ int molly_lora_down_drop_t_bf16(void* stream, const void* x, const void* A, void
  * reduce: out[i] = bf16(sum_r float(srcs[r][i])) in rank order (molly_reduce_rows_bf16's arithmetic on copies that stay where they are).
  * push:   dsts[r][i] = src[i] for every r != skip.   n % 8 == 0, 16-byte aligned buffers, world <= 16.
  * flag_set: *flag = value, a system-scope release behind everything the stream has launched so far.
- * flag_wait: returns (in stream order) when flags[r][idx] >= value for every r; a peer that does not arrive within max_spins polls
- *            writes 1 + r into *err (device int, the caller checks it) instead of hanging the GPU. */
-int molly_p2p_reduce_bf16(void* stream, const void* const* srcs, int world, long n, void* out);
+ * flag_wait: returns (in stream order) when flags[r][idx] >= value for every r; a peer that does not arrive within timeout_us
+ *            microseconds of wall-clock time (s_memrealtime) writes 1 + r into *err instead of hanging the GPU.  *err is an int the
+ *            device can write and the host can read without a synchronisation (pinned host memory in trainer/p2p.py).
+ * A raised *err is fatal for the step: reduce (given err) then writes bf16 NaN instead of sums, so the gradient norm — all-reduced over
+ * the ranks — is not finite anywhere and every rank skips the optimizer step; the host raises at its next call. err = NULL: no check. */
+int molly_p2p_reduce_bf16(void* stream, const void* const* srcs, int world, long n, void* out, const int* err);
 int molly_p2p_push_bf16(void* stream, const void* src, void* const* dsts, int world, int skip, long n);
 int molly_p2p_flag_set(void* stream, int* flag, int value);
-int molly_p2p_flag_wait(void* stream, const void* const* flags, int world, int idx, int value, long max_spins, int* err);
+int molly_p2p_flag_wait(void* stream, const void* const* flags, int world, int idx, int value, long timeout_us, int* err);
 
 /* ------------------------------------------------------------------------------------------------
  * layout / instruction probes (used by tests/test_gpu_kernels.py::test_probe_* to pin the gfx950 operand maps the

@@ -35,10 +35,7 @@ struct AttnArgs {
     int causal;
     int nblk, order_set;                     // block order (block_item): query blocks per head, (batch, kv head) pairs walked together
     int prio;                                // wave_priority(): 0 none, n: the odd wave slot of every SIMD runs at priority n
-    int stagger;                             // attn_fwd_pipe_kernel: waves 4-7 one step behind waves 0-3 (MOLLY_ATTN_PIPE_STAGGER, default 1)
     bf16_t* OT; int ldot;                    // attn_fwd_kernel: O a second time, transposed [nh * hd][ldot >= B * T] (nullable) — the o-projection's weight-gradient operand
-    int* redo;                               // fixed-reference forward (QB 2): *redo = seq when some row's maximum outgrew its reference;
-    int seq;                                 // attn_fwd_kernel launched behind it returns at once unless *redo == seq (nullptr: always runs)
 };
 
 // One LDS image serves row reads (ds_read_b128: tile row on the lane) AND transposed reads (ds_read_b64_tr_b16: tile
@@ -344,7 +341,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // launched as the fall-back behind the fixed-reference kernel: nothing to do unless that kernel asked for it
-    if (p.redo && __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != p.seq) return;
     wave_priority(p.prio);
     // 1-D grid, XCD-aware item order (block_item); within a pair the heaviest causal blocks (largest query index) start first
     const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);
@@ -552,546 +548,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #endif
 }
 
-
-// ================================================================================================
-// The forward as a SOFTWARE PIPELINE inside each wave (round 5; reference role: --attn_impl flash_attention_2, src/train.py:578-582).
-// Round 4's stamps (profiles/r04_logs/attn_stamp.log) showed a wave of attn_fwd_kernel running its half-step as a serial chain —
-// K fragment reads -> 8 S^T MFMAs -> softmax -> 8 P.V MFMAs, 2,078 cycles for 512 of MFMA — and a second wave per SIMD hiding 30 % of
-// it.  Here every consumer sits one phase behind its producer, so a wave's own matrix and vector instructions are independent and can
-// be interleaved in program order (an in-order wave overlaps nothing else):
-//   step s (32 keys), phase A:  S(s+1) = K(s+1) Q^T  [8 MFMAs]   beside   exp / row sum / pack of S(s) -> P(s);  V(s) fragment reads
-//                     phase B:  O^T += V(s)^T P(s)^T [8 MFMAs]   beside   row max of S(s+1), rescale decision;   K(s+2) fragment reads
-// S is double-buffered in registers (two named accumulators that swap roles every step).  The rare rescale (guide T13) is decided in
-// phase B from S(s+1) and applied after P.V(s) has been issued: O, l (which hold everything up to step s) are scaled once, P(s+1) is
-// then exponentiated against the new maximum.
-// K and V live in rings of their own: K(t+1) is first read in phase B of tile t's FIRST step and K(t) last read before tile t begins,
-// V(t) is read during tile t only — so ONE barrier per 64-key tile (between the phases of its second step) serves both with a K ring
-// of 3 tiles and a V ring of 2 (80 KiB): behind barrier Z_t the wave issues the LDS-DMA of K(t+3) and V(t+2), in front of Z_(t+1) it
-// waits for them.  NW = 4 (128 query rows, two workgroups per CU) or 8 (256 rows, one workgroup per CU, half the staging per wave).
-// Tiles whose two steps are interior for the wave (no mask, nothing past its causal diagonal) run the branch-free body; the first /
-// last tiles run the same phases under wave-uniform guards.
-template <int HD, int NW> struct PipeStage {
-    static constexpr int NP = BKV * HD * 2 / 1024 / NW;                 // 1-KiB LDS-DMA pieces per wave and tile: 4 (NW 4) / 2 (NW 8) at hd 128
-};
-template <int HD, int NW>
-__device__ __forceinline__ void pipe_lane_const(int wave, int lane, unsigned& row0, unsigned& colb) {
-    constexpr int NCB = HD / 16, NP = PipeStage<HD, NW>::NP;
-    const int P = wave * NP * 64 + lane;                  // piece 0 of this wave
-    const int blk = P >> 3, cin = P & 7;
-    const int rowblk = blk / NCB, cbs = blk % NCB;
-    const int b0 = rowblk & 1, b1 = (rowblk >> 1) & 1;
-    row0 = (unsigned)(rowblk * 4 + (cin >> 1));
-    colb = (unsigned)((((cbs ^ b0) << 4) + (((cin & 1) ^ b1) << 3)) * 2);
-}
-// hd 128 only: a piece = one 4-row block row of the image; piece i of wave w is instruction w * NP + i.  Rows past the end of the
-// sequence re-read row T - 1 (`last` = T - 1 - key0 >= 0; masked by index later): one v_min per piece, and no second code path.
-template <int HD, int NW>
-__device__ __forceinline__ void pipe_stage_piece(int i, const char* base, unsigned ldb, unsigned row0, unsigned colb, unsigned last, unsigned lds_addr, int wave) {
-    static_assert(HD == 128, "pipe_stage: hd 128");
-    constexpr int NP = PipeStage<HD, NW>::NP;
-    // b0 = i & 1 always (w * NP is even); b1 = (i >> 1) & 1 when NP = 4 (w * NP a multiple of 4), a wave constant (in colb) when NP = 2
-    const unsigned cx = (unsigned)((((i & 1) << 4) ^ (NP == 4 ? (((i >> 1) & 1) << 3) : 0)) * 2);
-    const unsigned off = __umul24(min(row0 + 4u * i, last), ldb) + (colb ^ cx);
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr + (unsigned)((wave * NP + i) * 1024));
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(dst) : "memory", "m0");
-}
-template <int HD, int NW>
-__device__ __forceinline__ void pipe_stage(const char* base, unsigned ldb, unsigned row0, unsigned colb, unsigned last, unsigned lds_addr, int wave) {
-    constexpr int NP = PipeStage<HD, NW>::NP;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) pipe_stage_piece<HD, NW>(i, base, ldb, row0, colb, last, lds_addr, wave);
-}
-
-// one-instruction helpers (asm without `volatile`: pure, the scheduler may still move them inside their slot): a three-way
-// maximum on accumulator registers without hipcc's canonicalising v_max in front (the guide's 4-wave example notes the same)
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ float vmax2(float a, float b) {
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-#define SLOT_END() __builtin_amdgcn_sched_barrier(0)
-// fragment reads run this many MFMA slots ahead of the MFMA that consumes them (K: ds_read_b128, V: two ds_read_b64_tr_b16)
-#ifndef MOLLY_ATTN_PIPE_KD
-#define MOLLY_ATTN_PIPE_KD 1
-#endif
-#ifndef MOLLY_ATTN_PIPE_VD
-#define MOLLY_ATTN_PIPE_VD 2
-#endif
-#ifndef MOLLY_ATTN_PIPE_MFMA_LATE
-#define MOLLY_ATTN_PIPE_MFMA_LATE 1
-#endif
-// MFMAs issued from asm with the register FILE of each operand chosen here.  With two waves per SIMD a wave has 256 registers, and
-// LLVM splits them 128 architected + 128 accumulation as soon as an `a` operand appears; left to itself at 256 architected registers
-// the allocator ping-ponged O between two register sets across the loop body's two steps (128 registers for 64) and spilled Q.
-// So everything that only MFMAs touch lives in the accumulation file — O^T (64), the Q fragments (32), and the K / V fragments on
-// their way from LDS to their MFMA (ds_read writes a-registers directly) — and the softmax's working set (S twice, P, the row
-// statistics) in the architected one.  hipcc does not see these as MFMAs, so the hazards its recognizer would pad are ours: a vector
-// instruction that reads an MFMA result needs the MFMA's passes + 3 wait states behind it — the fast path has >= 20 instructions
-// there by construction, the other paths call mfma_settle() — and back-to-back accumulation into the same registers is legal as is.
-// ASM = true (one wave per SIMD, 512 registers = 256 architected + 256 accumulation): the register FILE of every operand is chosen here.
-#ifndef MOLLY_ATTN_PIPE_ASM_O
-#define MOLLY_ATTN_PIPE_ASM_O 1
-#endif
-template <bool ASM> __device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    // (the V^T fragment is put together from two ds_read_b64_tr_b16: as an `a` operand hipcc reads it into architected registers and
-    // copies it over, four v_accvgpr_write per fragment; as a `v` operand it is used where it lands)
-    if constexpr (ASM && MOLLY_ATTN_PIPE_ASM_O) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-}
-template <bool ASM> __device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& bq) {
-    if constexpr (ASM) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(a), "v"(bq));
-    else {
-        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, z, 0, 0, 0);
-    }
-}
-template <bool ASM> __device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& bq) {
-    if constexpr (ASM) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(bq));
-    else d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, d, 0, 0, 0);
-}
-template <bool ASM> __device__ __forceinline__ void mfma_settle() {
-    if constexpr (ASM) {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// QB = query blocks (32 rows) per wave.  QB 1 x NW 8: two waves per SIMD, 256 registers each.  QB 2 x NW 4: ONE wave per SIMD with the
-// whole 512-register file, every K / V fragment feeding two MFMAs (half the LDS reads and LDS-DMA issue per MFMA), fragments read
-// KD / VD = 3 slots ahead — the guide's 4-wave structure (cdna_hip_programming.md 'Fused attention prefill'); nothing covers a stall
-// there, so the stream has to be dense by itself: its vector work (4 cycles of issue per instruction for a lone wave, 8 per exp) is
-// 0.6-0.7 of the MFMA time per step.
-template <int HD, int NW, int QB>
-__global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void attn_fwd_pipe_kernel(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);        // [3 K tiles][3 V tiles]
-    constexpr int TILE = BKV * HD;
-    constexpr int NS = HD / 16, ND = HD / 32, BQW = NW * 32 * QB;
-    static_assert(NS == 8 && ND == 4, "attn_fwd_pipe_kernel: the slot schedule is written for hd 128");
-    constexpr int KD = QB == 2 ? 3 : MOLLY_ATTN_PIPE_KD, VD = QB == 2 ? 3 : MOLLY_ATTN_PIPE_VD;
-    constexpr bool ASM = QB == 2;                               // asm MFMAs with chosen register files (see mfma_o)
-    // FIXED (with ASM): no vector instruction ever writes O.  The running maximum of a row is set ONCE, by the first step that has a
-    // live key for it, and kept: P = 2^(scale S - m_ref) may then exceed 1, which bf16 (fp32's exponent range) and the fp32 sums carry
-    // without loss — every term is scaled by the same 2^-m_ref, the quotient O / l does not see it.  What the online rescale protects
-    // against is overflow, so that is what is tested: a row whose maximum outgrows its reference by more than 2^64 raises *redo and
-    // attn_fwd_kernel, launched behind this kernel, recomputes the launch (it returns at once otherwise).  Why: `o *= alpha` in ANY
-    // path makes hipcc carry a second home for O in architected registers — 128 at QB 2 — and spill Q into the MFMA slots.
-    constexpr bool FIXED = ASM;
-    constexpr float REDO_THR = 64.f;
-    bool overflow = false;
-    static_assert(KD >= 1 && KD <= 3 && VD >= 1 && VD <= 3, "prefetch distance 1..3 slots");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    // STAGGER (NW = 8): the two waves of a SIMD are waves w and w + 4.  Run in lockstep they sit in the same phase at the same time:
-    // they halve the matrix pipe between them in the MFMA slots and leave it idle together at the barrier and while both issue
-    // LDS-DMA (stamps, round 5: waves 4-7 took 1,230 cycles for a phase A that waves 0-3 finished in 615, and those then waited
-    // 1,100 cycles per tile at the barrier).  Waves 4-7 therefore take the tile barrier between the phases of the tile's FIRST
-    // step, waves 0-3 of its second: the first barrier holds waves 4-7 back by one step and from then on every phase A (vector-heavy)
-    // runs beside the partner's phase B, and one half's barrier + staging beside the other's MFMA slots.  The rings need no extra
-    // slot: behind Z_t the laggards still read V(t) and K(t+1), never K(t) or V(t-1).
-    const int bsub = (NW == 8 && wave >= 4 && p.stagger) ? 0 : 1;
-    if (NW == 8 && wave >= 4 && p.prio > 0) __builtin_amdgcn_s_setprio(1);   // (knob: static priority for the younger half)
-    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, p.nh / p.nkv, p.nblk, p.order_set);
-    const int qb = p.nblk - 1 - bi.blk;
-    const int b = bi.b, kvh = bi.kvh, head = kvh * (p.nh / p.nkv) + bi.g;
-    const int q0 = qb * BQW + wave * 32 * QB;                  // the wave's first query row; its query block c covers q0 + 32 c ..
-    const int T = p.T;
-    // (readfirstlane: the loads are wave-uniform, but hipcc cannot prove it and would carry every loop counter that depends on them
-    // in vector registers)
-    const int lo = __builtin_amdgcn_readfirstlane(p.kv_lo ? p.kv_lo[b] : 0);
-    const int hi = __builtin_amdgcn_readfirstlane(p.kv_hi ? p.kv_hi[b] : T);
-    const bf16_t* Qb = p.Q + (size_t)b * T * p.ldq + head * HD;
-    const bf16_t* Kb = p.K + (size_t)b * T * p.ldk + kvh * HD;
-    const bf16_t* Vb = p.V + (size_t)b * T * p.ldv + kvh * HD;
-
-    bf16x8 qf[QB][NS];
-#pragma unroll
-    for (int c = 0; c < QB; ++c) {
-        int qrow = q0 + 32 * c + r;
-        qrow = qrow < T ? qrow : T - 1;
-        const bf16_t* qp = Qb + (size_t)qrow * p.ldq + 8 * h;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) qf[c][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-    }
-#pragma unroll
-    for (int c = 0; c < QB; ++c)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            arrived(qf[c][s]);
-        }
-    f32x16 o[QB][ND];
-#pragma unroll
-    for (int c = 0; c < QB; ++c)
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[c][d][e] = 0.f;
-    float m_run[QB], l_run[QB], m_new[QB];
-#pragma unroll
-    for (int c = 0; c < QB; ++c) { m_run[c] = -INFINITY; l_run[c] = 0.f; m_new[c] = 0.f; }
-    const int qi = q0 + r;                                      // query row of block 0 on this lane (block c: qi + 32 c)
-#if MOLLY_ATTN_STAMP
-    unsigned long long tq0_ = 0, tq1_ = 0, ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-
-    // tiles of the BLOCK [t_first, t_last]; steps (32 keys) of the wave's query block c: [s_first, s_last[c]]
-    const int blk_q_last = min(qb * BQW + BQW - 1, T - 1);
-    const int kv_end = p.causal ? min(blk_q_last + 1, hi) : hi;       // exclusive
-    const int t_first = lo / BKV;
-    const int t_last = kv_end > lo ? (kv_end - 1) / BKV : t_first - 1;
-    const int s_first = 2 * t_first;
-    int s_last[QB];
-#pragma unroll
-    for (int c = 0; c < QB; ++c) {
-        const int kv_end_w = p.causal ? min(q0 + 32 * c + 32, kv_end) : kv_end;
-        s_last[c] = kv_end_w > lo ? (kv_end_w - 1) / 32 : s_first - 1;
-    }
-
-    unsigned row0, colb;
-    pipe_lane_const<HD, NW>(wave, lane, row0, colb);
-    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));
-    // staging walks the rings with running slot counters (tiles are staged in order)
-    int kslot = 0, vslot = 0;
-    auto stage_k = [&](int t) {
-        const int key0 = t * BKV;
-        pipe_stage<HD, NW>(reinterpret_cast<const char*>(Kb + (size_t)key0 * p.ldk), (unsigned)p.ldk * 2u, row0, colb, (unsigned)(T - 1 - key0),
-                           smem_lds + (unsigned)(kslot * TILE * 2), wave);
-        kslot = kslot == 2 ? 0 : kslot + 1;
-    };
-    auto stage_v = [&](int t) {
-        const int key0 = t * BKV;
-        pipe_stage<HD, NW>(reinterpret_cast<const char*>(Vb + (size_t)key0 * p.ldv), (unsigned)p.ldv * 2u, row0, colb, (unsigned)(T - 1 - key0),
-                           smem_lds + (unsigned)((3 + vslot) * TILE * 2), wave);
-        vslot = vslot == 2 ? 0 : vslot + 1;
-    };
-    // barrier Z_t (between the phases of tile t's second step) and the staging behind it: K(t+3) into K(t)'s slot, V(t+2) into V(t-1)'s
-    auto tile_sync = [&]() {
-        // own LDS-DMA pieces landed AND own fragment reads returned (the slots behind the barrier are overwritten by other waves' DMA)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    auto tile_barrier = [&](int t) {
-        tile_sync();
-        if (t + 3 <= t_last) stage_k(t + 3);
-        if (t + 2 <= t_last) stage_v(t + 2);
-    };
-    // the same staging, one piece at a time (fast path: a piece per MFMA slot of phase B): piece i < NP of K(t+3), then of V(t+2)
-    constexpr int NPW = PipeStage<HD, NW>::NP;
-    auto stage_piece = [&](int t, int i) {
-        if (i < NPW) {
-            if (t + 3 <= t_last) {
-                const int key0 = (t + 3) * BKV;
-                pipe_stage_piece<HD, NW>(i, reinterpret_cast<const char*>(Kb + (size_t)key0 * p.ldk), (unsigned)p.ldk * 2u, row0, colb,
-                                         (unsigned)(T - 1 - key0), smem_lds + (unsigned)(kslot * TILE * 2), wave);
-                if (i == NPW - 1) kslot = kslot == 2 ? 0 : kslot + 1;
-            }
-        } else if (t + 2 <= t_last) {
-            const int key0 = (t + 2) * BKV;
-            pipe_stage_piece<HD, NW>(i - NPW, reinterpret_cast<const char*>(Vb + (size_t)key0 * p.ldv), (unsigned)p.ldv * 2u, row0, colb,
-                                     (unsigned)(T - 1 - key0), smem_lds + (unsigned)((3 + vslot) * TILE * 2), wave);
-            if (i == 2 * NPW - 1) vslot = vslot == 2 ? 0 : vslot + 1;
-        }
-    };
-
-    // ---- shared state of the phases
-    bf16x8 kpre[KD];                  // fast path: the first KD fragments of the K half whose S^T comes next (read at the end of the phase before)
-    bf16x8 p0[QB], p1[QB];            // P^T of the step whose P.V comes next
-    bool resc = false;                // a rescale is pending (m_new valid)
-    int ks = 0, vs = 0;               // ring slots of the CURRENT tile's K and V (advance per tile)
-    auto k_tile = [&](int slot) { return smem + slot * TILE; };
-    auto v_tile = [&](int slot) { return smem + (3 + slot) * TILE; };
-    auto nxt3 = [](int x) { return x == 2 ? 0 : x + 1; };
-
-    // ---- unsliced pieces (prologue and the guarded steps): fragments read where they are used, two MFMAs per scheduling region
-    auto qk = [&](f32x16& sc, int c, const bf16_t* sK, int sub) {      // (the caller settles before vector instructions read sc)
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const bf16x8 f = row_frag<HD>(sK, 32 * sub + r, i, h);
-            if (i == 0) mfma_s0<ASM>(sc, f, qf[c][0]); else mfma_s<ASM>(sc, f, qf[c][i]);
-            if (i & 1) SLOT_END();
-        }
-    };
-    auto pv = [&](int c, const bf16_t* sV, int sub) {
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            mfma_o<ASM>(o[c][d], tr_frag<HD>(sV, 32 * sub, 0, d, lane), p0[c]);
-            mfma_o<ASM>(o[c][d], tr_frag<HD>(sV, 32 * sub, 1, d, lane), p1[c]);
-            SLOT_END();
-        }
-    };
-    // row max of S(s) (masked where the step touches the diagonal or a range edge) and the rescale decision
-    auto start = [&](f32x16& sc, int c, int s, auto MASKED) {
-        const int kbase = 32 * s;
-        float mx;
-        if (MASKED) {
-            mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const bool ok = key >= lo && key < hi && (!p.causal || key <= qi + 32 * c);
-                sc[e] = ok ? sc[e] : -INFINITY;
-                mx = fmaxf(mx, sc[e]);
-            }
-        } else {
-            mx = vmax2(vmax3(vmax3(sc[0], sc[1], sc[2]), vmax3(sc[3], sc[4], sc[5]), vmax3(sc[6], sc[7], sc[8])),
-                       vmax3(vmax3(sc[9], sc[10], sc[11]), vmax3(sc[12], sc[13], sc[14]), sc[15]));
-        }
-        mx = xhalf_max(mx) * p.scale_log2;
-        if constexpr (FIXED) {
-            m_run[c] = (m_run[c] == -INFINITY) ? mx : m_run[c];
-            if (!__all(!(mx - m_run[c] > REDO_THR))) overflow = true;
-        } else {
-            if (!__all(mx - m_run[c] <= RESCALE_THR)) resc = true;
-            m_new[c] = fmaxf(m_run[c], mx);
-        }
-    };
-    // after P.V of the step before has been issued: everything at the old maximum is scaled once.  (With two query blocks a pending
-    // rescale moves BOTH to their exact running maxima — alpha is 1 for rows whose maximum did not grow.)
-    auto apply_rescale = [&]() {
-        if constexpr (FIXED) return;
-        if (resc) {
-            mfma_settle<ASM>();
-#pragma unroll
-            for (int c = 0; c < QB; ++c) {
-                const float m_use = (m_new[c] == -INFINITY) ? 0.f : m_new[c];
-                const float alpha = fast_exp2(m_run[c] - m_use);        // m_run = -inf -> 0
-                l_run[c] *= alpha;
-                m_run[c] = m_new[c];
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        o[c][d][e] *= alpha;
-                    }
-            }
-            mfma_settle<ASM>();
-            resc = false;
-        }
-    };
-    // P(s) = 2^(scale S - m), row sum, bf16 fragments
-    auto finish = [&](f32x16& sc, int c) {
-        const float m_ref = (m_run[c] == -INFINITY) ? 0.f : m_run[c];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sc[e] = fast_exp2(sc[e] * p.scale_log2 - m_ref);
-        float rs[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) rs[g4] = (sc[4 * g4] + sc[4 * g4 + 1]) + (sc[4 * g4 + 2] + sc[4 * g4 + 3]);
-        l_run[c] += (rs[0] + rs[1]) + (rs[2] + rs[3]);
-        p0[c] = acc_to_frag(sc, 0);
-        p1[c] = acc_to_frag(sc, 8);
-        asm volatile("" ::"v"(p0[c]), "v"(p1[c]), "v"(l_run[c]));
-    };
-    auto need_mask = [&](int s, int c) { return (p.causal && 32 * s + 31 > q0 + 32 * c) || 32 * s < lo || 32 * s + 32 > hi; };
-
-    // ---- prologue: K(t0), V(t0), K(t0+1) -> barrier -> K(t0+2), V(t0+1) behind it
-    if (t_last >= t_first) {
-        stage_k(t_first);
-        stage_v(t_first);
-        if (t_first + 1 <= t_last) stage_k(t_first + 1);
-    }
-    dma_wait();
-    __syncthreads();
-    if (t_first + 2 <= t_last) stage_k(t_first + 2);
-    if (t_first + 1 <= t_last) stage_v(t_first + 1);
-
-    f32x16 sX[QB], sY[QB];            // S of the current / the next step; the roles swap every step
-#pragma unroll
-    for (int c = 0; c < QB; ++c)
-        if (s_last[c] >= s_first) qk(sX[c], c, k_tile(0), 0);
-    mfma_settle<ASM>();
-#pragma unroll
-    for (int c = 0; c < QB; ++c)
-        if (s_last[c] >= s_first) {
-            if (need_mask(s_first, c)) start(sX[c], c, s_first, std::true_type{}); else start(sX[c], c, s_first, std::false_type{});
-        }
-    apply_rescale();
-
-    // one step under wave-uniform guards (first / last tiles of the wave, and its idle tiles behind the causal diagonal).
-    // Step s = (tile t, half sub); K(s+1) = tile t's half 1 (sub 0) or tile t+1's half 0 (sub 1).
-    auto step_guarded = [&](f32x16 (&cur)[QB], f32x16 (&nxt)[QB], int s) {
-        const int sub = s & 1;
-#pragma unroll
-        for (int c = 0; c < QB; ++c)
-            if (s + 1 <= s_last[c]) qk(nxt[c], c, sub ? k_tile(nxt3(ks)) : k_tile(ks), sub ^ 1);
-#pragma unroll
-        for (int c = 0; c < QB; ++c)
-            if (s <= s_last[c]) finish(cur[c], c);
-        if (sub == bsub) tile_barrier(s >> 1);
-#pragma unroll
-        for (int c = 0; c < QB; ++c)
-            if (s <= s_last[c]) pv(c, v_tile(vs), sub);
-        mfma_settle<ASM>();                                                  // S(s+1) is read by vector instructions next
-#pragma unroll
-        for (int c = 0; c < QB; ++c)
-            if (s + 1 <= s_last[c]) {
-                if (need_mask(s + 1, c)) start(nxt[c], c, s + 1, std::true_type{}); else start(nxt[c], c, s + 1, std::false_type{});
-            }
-        apply_rescale();
-    };
-
-    // the branch-free step, placed by hand: 8 MFMA slots per phase (one MFMA per query block each), each closed by a sched_barrier
-    // so that hipcc keeps what was put beside the MFMAs there (fragment reads KD / VD slots ahead, the softmax in slices)
-    auto step_fast = [&](f32x16 (&cur)[QB], f32x16 (&nxt)[QB], int s, auto SUB) {
-        constexpr int sub = decltype(SUB)::value;
-#if MOLLY_ATTN_STAMP
-        if (!sub) { ASTAMP(tq0_); ++ts_[7]; }
-#endif
-        // ---- phase A: S(s+1) = K(s+1) Q^T beside P(s) = 2^(scale S(s) - m)
-        const bf16_t* sKa = sub ? k_tile(nxt3(ks)) : k_tile(ks);           // K(s+1): tile t half 1 | tile t+1 half 0
-        constexpr int suba = sub ^ 1;
-        const bf16_t* sV = v_tile(vs);
-        float m_ref[QB], tot[QB];
-        u32x4 w0[QB], w1[QB];
-#pragma unroll
-        for (int c = 0; c < QB; ++c) { m_ref[c] = (m_run[c] == -INFINITY) ? 0.f : m_run[c]; tot[c] = 0.f; }
-        bf16x8 kfr[NS];
-        bf16x8 vfr[2 * ND];                                                // V^T fragments by P.V slot j = 2 d + sp
-#pragma unroll
-        for (int i = 0; i < KD; ++i) kfr[i] = kpre[i];
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            if (i + KD < NS) kfr[i + KD] = row_frag<HD>(sKa, 32 * suba + r, i + KD, h);
-            if (i + VD >= NS) vfr[i + VD - NS] = tr_frag<HD>(sV, 32 * sub, (i + VD - NS) & 1, (i + VD - NS) >> 1, lane);
-#pragma unroll
-            for (int c = 0; c < QB; ++c) {
-                cur[c][2 * i] = fast_exp2(cur[c][2 * i] * p.scale_log2 - m_ref[c]);
-                cur[c][2 * i + 1] = fast_exp2(cur[c][2 * i + 1] * p.scale_log2 - m_ref[c]);
-                if (i > 0) {
-                    const int j = i - 1;
-                    tot[c] += cur[c][2 * j] + cur[c][2 * j + 1];
-                    const unsigned pk = pack_bf2(cur[c][2 * j], cur[c][2 * j + 1]);
-                    if (j < 4) w0[c][j] = pk; else w1[c][j - 4] = pk;
-                }
-            }
-            // the MFMAs close their slot: the fragment they wait for gets this slot's vector work as extra cover
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < QB; ++c) {
-                if (i == 0) mfma_s0<ASM>(nxt[c], kfr[0], qf[c][0]); else mfma_s<ASM>(nxt[c], kfr[i], qf[c][i]);
-            }
-            SLOT_END();
-        }
-#pragma unroll
-        for (int c = 0; c < QB; ++c) {
-            tot[c] += cur[c][14] + cur[c][15];
-            w1[c][3] = pack_bf2(cur[c][14], cur[c][15]);
-            l_run[c] += tot[c];
-            p0[c] = __builtin_bit_cast(bf16x8, w0[c]);
-            p1[c] = __builtin_bit_cast(bf16x8, w1[c]);
-            // "used here": without it LLVM sinks the whole exp / sum / pack chain below the barrier's branches to its first real use,
-            // i.e. out from beside the S^T MFMAs and in front of the P.V MFMAs that wait for it
-            asm volatile("" ::"v"(p0[c]), "v"(p1[c]), "v"(l_run[c]));
-        }
-        SLOT_END();
-        ALAP(sub ? 2 : 0);                                                 // phase A
-        const bool zt = sub == bsub;                                       // this wave's tile barrier sits in this step
-        if (zt) {
-#if MOLLY_ATTN_STAMP
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            ALAP(3);                                                       // own LDS-DMA pieces landed
-            __builtin_amdgcn_s_barrier();
-            ALAP(4);                                                       // the workgroup's barrier
-#else
-            tile_sync();
-#endif
-        }
-        SLOT_END();
-        // ---- phase B: O^T += V(s)^T P(s)^T beside the row max of S(s+1); K(s+2) = tile t+1's half `sub`: first KD fragments prefetched
-        const bf16_t* sKb = k_tile(nxt3(ks));
-        float ma[QB], mb[QB], mc[QB], md[QB], me[QB], mx[QB];
-#pragma unroll
-        for (int c = 0; c < QB; ++c) ma[c] = mb[c] = mc[c] = md[c] = me[c] = mx[c] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2 * ND; ++j) {
-            if (j + VD < 2 * ND) vfr[j + VD] = tr_frag<HD>(sV, 32 * sub, (j + VD) & 1, (j + VD) >> 1, lane);
-            if (j + KD >= 2 * ND) kpre[j + KD - 2 * ND] = row_frag<HD>(sKb, 32 * sub + r, j + KD - 2 * ND, h);
-            // behind the barrier: the LDS-DMA of K(t+3), V(t+2), a piece per slot (issued in a lump they cost ~ 90 cycles each with
-            // the matrix pipe idle: 360 of a tile's 3,600)
-            if (zt && j < 2 * NPW) stage_piece(s >> 1, j);
-            // S(s+1) is complete one MFMA latency behind phase A's last MFMA: nothing reads it in slots 0, 1
-#pragma unroll
-            for (int c = 0; c < QB; ++c) {
-                f32x16& n = nxt[c];
-                if (j == 2) { ma[c] = vmax3(n[0], n[1], n[2]); mb[c] = vmax3(n[3], n[4], n[5]); }
-                if (j == 3) { mc[c] = vmax3(n[6], n[7], n[8]); md[c] = vmax3(n[9], n[10], n[11]); }
-                if (j == 4) { me[c] = vmax3(n[12], n[13], n[14]); ma[c] = vmax3(ma[c], mb[c], mc[c]); }
-                if (j == 5) { md[c] = vmax3(md[c], me[c], n[15]); mx[c] = vmax2(ma[c], md[c]); }
-                if (j == 6) { mx[c] = xhalf_max(mx[c]) * p.scale_log2; }
-                if (j == 7) {
-                    if constexpr (FIXED) {
-                        m_run[c] = (m_run[c] == -INFINITY) ? mx[c] : m_run[c];
-                        if (!__all(!(mx[c] - m_run[c] > REDO_THR))) overflow = true;
-                    } else {
-                        if (!__all(mx[c] - m_run[c] <= RESCALE_THR)) resc = true;
-                        m_new[c] = fmaxf(m_run[c], mx[c]);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < QB; ++c) mfma_o<ASM>(o[c][j >> 1], vfr[j], (j & 1) ? p1[c] : p0[c]);
-            SLOT_END();
-        }
-        apply_rescale();
-        SLOT_END();
-        ALAP(sub ? 6 : 1);                                                 // phase B
-    };
-    // interior for this wave: steps 2t, 2t+1 with S(2t+1), S(2t+2) unmasked for every query block (block 0's diagonal comes first)
-    // and K(2t+3) still wanted
-    auto is_fast = [&](int t) { return 2 * t + 3 <= s_last[0] && !need_mask(2 * t + 1, 0) && !need_mask(2 * t + 2, 0); };
-
-    // ONE loop over the tiles with the two bodies as the arms of a branch: guarded tiles (a range that starts inside a tile, the wave's
-    // causal diagonal, its idle tiles up to the block's last) and interior ones.  (Loops per kind — in sequence, or nested in an outer
-    // one — made hipcc keep a second copy of O and S, 96 registers, alive across the fast loop and spill Q into its MFMA slots.)
-    bool prev_fast = false;
-    for (int t = t_first; t <= t_last; ++t) {
-        if (is_fast(t)) {
-            if (!prev_fast) {         // entering a fast run at step 2t: the first KD fragments of K(2t+1) = tile t's half 1
-#pragma unroll
-                for (int i = 0; i < KD; ++i) kpre[i] = row_frag<HD>(k_tile(ks), 32 + r, i, h);
-            }
-            step_fast(sX, sY, 2 * t, std::false_type{});
-            step_fast(sY, sX, 2 * t + 1, std::true_type{});
-            prev_fast = true;
-        } else {
-            step_guarded(sX, sY, 2 * t);
-            step_guarded(sY, sX, 2 * t + 1);
-            prev_fast = false;
-        }
-        ks = nxt3(ks);
-        vs = nxt3(vs);
-    }
-
-    // ---- epilogue: O[q][d] = o / l ; LSE2 = m + log2(l).  Behind the last tile barrier waves still read V (and, staggered, K)
-    // fragments, so one more barrier before the slabs overwrite the rings.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    mfma_settle<ASM>();
-#pragma unroll
-    for (int c = 0; c < QB; ++c) {
-        const float l_tot = l_run[c] + __shfl_xor(l_run[c], 32, 64);
-        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-        const int qc = q0 + 32 * c;
-        store_rows<HD, ND>(smem + wave * 32 * (HD + 8), o[c], inv, p.O + ((size_t)b * T + qc) * p.ldo + head * HD, p.ldo, T - qc, lane);
-        if (qc + r < T && p.LSE && h == 0)
-            p.LSE[((size_t)b * p.nh + head) * T + qc + r] = l_tot > 0.f ? m_run[c] + log2f(l_tot) : -INFINITY;
-    }
-    if (FIXED && overflow && lane == 0) __hip_atomic_store(p.redo, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if MOLLY_ATTN_STAMP
-    if (lane == 0 && (blockIdx.x * NW + wave) < 32768 * 4) {            // [block][wave][8]: laps 0..6 of the FAST tiles, [7] = their count
-        unsigned long long* q = g_attn_stamp + ((size_t)blockIdx.x * NW + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] += ts_[i];
-    }
-#endif
-}
 
 // ================================================================================================
 // Small head dims (8 <= hd <= 64, hd % 8 == 0, not 64): the mini encoders of the reference's plumbing config (ESM2-t6-8M:
@@ -1565,7 +1021,7 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
     MOLLY_CHECK(B > 0 && T > 0, "attn_fwd: empty problem");
     AttnArgs p{(const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, lse2, kv_lo, kv_hi, T, n_heads,
                n_kv_heads, ldq, ldk, ldv, ldo, scale * LOG2E, causal, cdiv(T, BQ), order_set(0, B * n_kv_heads), wave_prio(),
-               [] { const char* e = getenv("MOLLY_ATTN_PIPE_STAGGER"); return e ? atoi(e) : 1; }(), (bf16_t*)OT, ldot, nullptr, 0};
+               (bf16_t*)OT, ldot};
     if (OT) {
         MOLLY_CHECK(head_dim == 128 || head_dim == 64, "attn_fwd: the transposed second store is built for head dims 64 and 128");
         MOLLY_CHECK(T % 128 == 0 && ldot >= B * T && ldot % 8 == 0 && ((uintptr_t)OT % 16) == 0,
@@ -1578,45 +1034,6 @@ static int attn_fwd_impl(void* stream, const void* Q, const void* K, const void*
 #undef MOLLY_SMALL
         MOLLY_LAUNCH_CHECK();
         return 0;
-    }
-    // MOLLY_ATTN_FWD_PIPE: the software-pipelined forward (attn_fwd_pipe_kernel), 8 = eight waves x 32 query rows (two waves per SIMD),
-    // 4 = four waves x 64 rows (one wave per SIMD); 0: attn_fwd_kernel
-    {
-        const char* e = getenv("MOLLY_ATTN_FWD_PIPE");
-        const int nw = e ? atoi(e) : 0;
-        if (head_dim == 128 && (nw == 4 || nw == 8) && !OT) {
-            static bool pipe_attr = false;
-            if (!pipe_attr) {
-                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
-                (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<128, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * BKV * 128 * 2);
-                pipe_attr = true;
-            }
-            p.nblk = cdiv(T, 256);
-            const dim3 gp(n_heads * B * p.nblk);
-            const size_t ldsp = 6 * BKV * 128 * sizeof(bf16_t);
-            if (nw == 8) {
-                hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 8, 1>), gp, dim3(512), ldsp, (hipStream_t)stream, p);
-                MOLLY_LAUNCH_CHECK();
-                return 0;
-            }
-            // fixed-reference kernel + its conditional fall-back: a ring of flags (one per launch in flight), each holding the sequence
-            // number of the launch that raised it — nothing to reset, and launches on other streams use other slots
-            static int* flags = nullptr;
-            static int seq = 0;
-            if (!flags) {
-                MOLLY_CHECK(hipMalloc(&flags, 64 * sizeof(int)) == hipSuccess, "attn_fwd: flag ring allocation failed");
-                MOLLY_CHECK(hipMemset(flags, 0, 64 * sizeof(int)) == hipSuccess, "attn_fwd: flag ring reset failed");
-            }
-            seq = seq == 0x7fffffff ? 1 : seq + 1;
-            p.redo = flags + (seq & 63);
-            p.seq = seq;
-            hipLaunchKernelGGL((attn_fwd_pipe_kernel<128, 4, 2>), gp, dim3(256), ldsp, (hipStream_t)stream, p);
-            p.nblk = cdiv(T, BQ);
-            if (!attr_set_fwd()) return -1;
-            hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3(n_heads * B * cdiv(T, BQ)), dim3(256), 2 * 2 * BKV * 128 * sizeof(bf16_t), (hipStream_t)stream, p);
-            MOLLY_LAUNCH_CHECK();
-            return 0;
-        }
     }
     dim3 grid(n_heads * B * cdiv(T, BQ));                  // 1-D: block_item() decodes it
     // MOLLY_ATTN_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, e.g. 40960 leaves room for ONE workgroup per CU — what the
@@ -1699,20 +1116,17 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     AttnBwdArgs pk = p;                                                             // their block order
     pk.nblk = cdiv(T, 128);
     pk.order_set = order_set(1, B * n_kv_heads);
-    // MOLLY_ATTN_DKV_ONE_PASS=1: dK and dV from one pass (7 MFMA products in the backward instead of 8, but 256 accumulator
-    // registers = one wave per SIMD); default: two passes at two waves per SIMD (measured faster: DESIGN.md §4)
-    static const bool one_pass = [] { const char* e = getenv("MOLLY_ATTN_DKV_ONE_PASS"); return e && atoi(e) != 0; }();
+    // head dim 128: dV and dK as two passes at two waves per SIMD (one pass holding both needs 256 accumulator registers = one wave per SIMD and
+    // measured equal at best: LOG.md rounds 1, 4); head dim 64 (the encoders): one pass
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
         const long need = molly_attn_bwd_workspace(B, T, n_heads, n_kv_heads, head_dim);
-        if (!one_pass && need > 0 && workspace && workspace_floats >= need) {
+        if (need > 0 && workspace && workspace_floats >= need) {
             p.part = pk.part = workspace;
             const dim3 gs(n_heads * B * cdiv(T, 128));
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, pk);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, pk);
             hipLaunchKernelGGL(attn_dkv_reduce_kernel<128>, dim3(gk.x * 4, gk.y, 2), dim3(64), 0, st, p);
-        } else if (one_pass) {
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 0>), gk1, dim3(256), lds_dkv, st, pk);
         } else {
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk1, dim3(256), lds_dkv, st, pk);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2>), gk1, dim3(256), lds_dkv, st, pk);

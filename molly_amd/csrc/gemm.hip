@@ -73,6 +73,11 @@ struct GemmArgs {
 #ifndef MOLLY_GEMM_SE_FORM
 #define MOLLY_GEMM_SE_FORM 1        // streaming epilogue: 1 = the product; 2 = timing-only diagnostic, the row halves are packed but never stored
 #endif
+#ifndef MOLLY_GEMM_EPI_LDS
+#define MOLLY_GEMM_EPI_LDS 1        // epilogues that read or write more than the plain tile (SwiGLU backward / forward, residual add): 1 = the wave's packed
+#endif                              // accumulators go through a 4 KB slab of the free A stage and come back with lane = (row of 8, 16-byte chunk of 8), so every
+                                    // load and store instruction covers whole 128-byte lines (2.4x the store rate of one CU: tools/r06/store_diag); 0 = round 2's
+                                    // lane-row regrouping (16 rows x 64 bytes per instruction) — A/B
 #ifndef MOLLY_GEMM_SBW_AHEAD
 #define MOLLY_GEMM_SBW_AHEAD 2     // row groups of gate / up in flight ahead of the SwiGLU-backward epilogue's arithmetic (of 8)
 #endif
@@ -1253,6 +1258,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // (Tried on top: whole 128-byte rows through a per-wave 2 KB slab in the A slot that is free during the epilogue — 4 ds_write_b64
     // + 2 ds_read_b128 per row-block instead of the swaps: K = 2048 launches 202.5 / 108.4 us against 200.1 / 101.5 with the swaps,
     // bit-identical; not kept.)
+    // ---- whole-line access for the epilogues that touch memory beyond one plain store (round 6).  The swapped MFMA operands leave the ROW index in
+    // the low four lane bits, so any access shaped like the accumulators touches 16 lines per 16 consecutive lanes — 8,600 cycles per 128 KB tile and
+    // CU, against 3,550 when 8 consecutive lanes cover one line (tools/r06/store_diag/store_bench.hip).  The SwiGLU-backward epilogue moves four tiles
+    // that way (gate, up in; d gate, d up out): 18 us per tile, most of what the fusion cost.  So the wave's packed bf16 results pass through a 4 KB
+    // slab of the A stage that is free between two tiles (the one the last K-tile was read from; every read of it has returned: the closing barrier
+    // above), 32 rows at a time: written as the lanes own them (8-byte quads, 16-byte chunks XOR-swizzled by the row), read back as
+    // lane = (row l >> 3 of 8, chunk l & 7) — 16 bytes per lane, 8 rows x 128 bytes per instruction.  DS operations of one wave execute in order,
+    // so the slab needs no barrier and no wait between its writes and reads beyond the register dependencies hipcc tracks.
+    constexpr bool EPI_LDS = MOLLY_GEMM_EPI_LDS && !SKM && !P2;     // (not in the stream-K and two-phase instantiations: their register files are full)
+    char* const epi_slab = reinterpret_cast<char*>(smem + ((abuf == 0 ? 2 : abuf - 1) * 2) * HT) + wave * 4096;
+    const int epi_row = lane >> 3, epi_ch = lane & 7;
+    // rows 32 c .. 32 c + 31 of the wave's 128 (row blocks i = 2c, 2c + 1), packed with pack_bf2: -> out[k] = row 32 c + 8 k + epi_row, columns 8 epi_ch .. + 7
+    auto epi_transpose = [&](int cidx, u32x4 (&out)[4]) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 2 * cidx + ib, row = ib * 16 + fr;
+                const u32x2 q = u32x2{pack_bf2(acc[i][j][0], acc[i][j][1]), pack_bf2(acc[i][j][2], acc[i][j][3])};
+                *reinterpret_cast<u32x2*>(epi_slab + row * 128 + (((2 * j + (fq >> 1)) ^ (fr & 7)) << 4) + (fq & 1) * 8) = q;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            out[k] = *reinterpret_cast<const u32x4*>(epi_slab + (k * 8 + epi_row) * 128 + ((epi_ch ^ epi_row) << 4));
+    };
     const bool interior = em0 + 256 <= eM && en0 + 256 <= eN && p.splits <= 1 && !(GRP ? eto : TO);
     // (+ MOLLY_GEMM_ACCUMULATE alone, bf16: the residual path with C itself as the second operand — the weight gradients of every micro-batch but
     // the first under gradient accumulation, which took the generic epilogue's 32 dependent 8-byte read-add-write round trips: +9 % on the grouped
@@ -1332,6 +1362,66 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else if (fast16 && EPI_LDS) {
+        // plain / residual-add / accumulate epilogue, whole-line form (round 6).  Without a second operand the packed result goes through the slab
+        // once.  With one, the fp32 sums must be formed where the accumulators are, so the OPERAND travels first: it is loaded in whole lines (lane = row of 8, 16-byte chunk), written to the slab and read back as the accumulators
+        // lie (8-byte quads), added in fp32 with one rounding exactly as before, and the packed sums return through the slab to whole-line stores.
+        bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + epi_row) * eldc + en0 + wc * 64 + epi_ch * 8;
+        if (p.flags == 0) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                u32x4 d[4];
+                epi_transpose(cidx, d);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(c0 + (size_t)(cidx * 32 + k * 8) * eldc) = d[k];
+            }
+        } else {
+            const bool acc_c = p.flags == MOLLY_GEMM_ACCUMULATE;
+            const int ldr = acc_c ? eldc : p.ldres;
+            const bf16_t* r0 = (acc_c ? reinterpret_cast<const bf16_t*>(eC) : p.res) + (size_t)(em0 + wr * 128 + epi_row) * ldr + en0 + wc * 64 + epi_ch * 8;
+            // the second operand of the next 32 rows is requested before this chunk is worked on (a ring of two sets of four 16-byte pieces)
+            u32x4 rva[2][4];
+            auto res_load4 = [&](int cidx, u32x4 (&rv)[4]) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rv[k] = *reinterpret_cast<const u32x4*>(r0 + (size_t)(cidx * 32 + k * 8) * ldr);
+            };
+            res_load4(0, rva[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                if (cidx + 1 < 4) {
+                    res_load4(cidx + 1, rva[(cidx + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                u32x4 (&rv)[4] = rva[cidx & 1];
+                // operand: whole-line layout -> slab -> accumulator layout
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<u32x4*>(epi_slab + (k * 8 + epi_row) * 128 + ((epi_ch ^ epi_row) << 4)) = rv[k];
+                u32x2 rq[2][4];
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        rq[ib][j] = *reinterpret_cast<const u32x2*>(epi_slab + (ib * 16 + fr) * 128 + (((2 * j + (fq >> 1)) ^ (fr & 7)) << 4) + (fq & 1) * 8);
+                // sums (fp32, one rounding) back through the slab
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 2 * cidx + ib;
+                        const u32x2 o = rq[ib][j];
+                        const u32x2 q = u32x2{pack_bf2(acc[i][j][0] + bflo(o[0]), acc[i][j][1] + bfhi(o[0])),
+                                              pack_bf2(acc[i][j][2] + bflo(o[1]), acc[i][j][3] + bfhi(o[1]))};
+                        *reinterpret_cast<u32x2*>(epi_slab + (ib * 16 + fr) * 128 + (((2 * j + (fq >> 1)) ^ (fr & 7)) << 4) + (fq & 1) * 8) = q;
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(epi_slab + (k * 8 + epi_row) * 128 + ((epi_ch ^ epi_row) << 4));
+                    *reinterpret_cast<u32x4*>(c0 + (size_t)(cidx * 32 + k * 8) * eldc) = d;
+                }
+            }
+        }
     } else if (fast16) {
         bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + fr) * eldc + en0 + wc * 64 + fq * 8;
         if (p.flags == 0) {
@@ -1463,6 +1553,49 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             *reinterpret_cast<u32x4*>(gp) = u32x4{gq[0][0], gq[0][1], gq[1][0], gq[1][1]};
             *reinterpret_cast<u32x4*>(gp + ff) = u32x4{uq[0][0], uq[0][1], uq[1][0], uq[1][1]};
             *reinterpret_cast<u32x4*>(a0 + (size_t)i * 16 * p.ldres) = u32x4{aq[0][0], aq[0][1], aq[1][0], aq[1][1]};
+        }
+    } else if (swiglu_bwd16 && EPI_LDS) {
+        // SwiGLU backward in the down-projection's dgrad, interior tile, whole-line form: d(act) packed (the rounding the unfused path applies),
+        // transposed through the slab, then gate / up loaded and d(gate) / d(up) stored 16 bytes per lane with 8 lanes per 128-byte line; the
+        // arithmetic is swiglu_bwd_pair on the same bf16 pairs: bit-identical to dgrad + molly_swiglu_bwd and to the regrouped form below.
+        const int ff = eN;
+        const size_t col = (size_t)en0 + wc * 64 + epi_ch * 8;
+        const bf16_t* g0 = p.res + (size_t)(em0 + wr * 128 + epi_row) * p.ldres + col;
+        bf16_t* c0 = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + epi_row) * eldc + col;
+        // gate / up of the NEXT 16 rows (two row groups) are requested before the current 16 are worked on: a ring of two sets of two
+        u32x4 gva[2][2], uva[2][2];
+        auto sbw_load2 = [&](int h, u32x4 (&gv)[2], u32x4 (&uv)[2]) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bf16_t* gp = g0 + (size_t)(h * 16 + k * 8) * p.ldres;
+                gv[k] = *reinterpret_cast<const u32x4*>(gp);
+                uv[k] = *reinterpret_cast<const u32x4*>(gp + ff);
+            }
+        };
+        sbw_load2(0, gva[0], uva[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 dq[4];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            if (h + 1 < 8) {
+                sbw_load2(h + 1, gva[(h + 1) & 1], uva[(h + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((h & 1) == 0) epi_transpose(h >> 1, dq);
+            u32x4 (&gv)[2] = gva[h & 1], (&uv)[2] = uva[h & 1];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u32x4 og, ou;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32x2 r = swiglu_bwd_pair(gv[k][e], uv[k][e], dq[(h & 1) * 2 + k][e]);
+                    og[e] = r[0];
+                    ou[e] = r[1];
+                }
+                bf16_t* c = c0 + (size_t)(h * 16 + k * 8) * eldc;
+                *reinterpret_cast<u32x4*>(c) = og;
+                *reinterpret_cast<u32x4*>(c + ff) = ou;
+            }
         }
     } else if (swiglu_bwd16) {
         // SwiGLU backward in the down-projection's dgrad, interior tile: as the general branch below, with d(act) regrouped
@@ -2344,6 +2477,15 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
                     if (t < best_t) { best_t = t; best = sp; }
                 }
             }
+            // ONE partial round instead of K slices (round 6): a grid of 128..199 tiles keeps at least half the CUs busy by itself, and a CU that runs
+            // beside idle ones walks its K-tiles faster (1.2 us per K-tile measured against 1.4 on a full chip) — while the slices pay their slabs and
+            // the reduce launch.  The encoders at the headline's 8,224 rows: ffn2 (165 tiles x 80 K-tiles) 107.4 us as one round against 125.7 as
+            // three slices, o-proj (165 x 20) 47.6 against 54.9 on the 128x128 kernel (profiles/r06_logs/esm_gemm_a.log)
+            if (best > 0 && !skinny && c.small_split && t256 >= 128 && t256 < 200 && p.M >= 256 && p.N >= 256) {
+                const double t_one = 18.0 + 1.25 * nk;
+                const double t_split = 12.0 + cdiv(t256 * best, 256) * (6.0 + 1.4 * nk / best) + 4.0 + 8.0 * p.M * p.N * best / 9e6;
+                if (t_one < t_split) best = 0;
+            }
             // the slab path applies bias/GELU/residual in its reduce kernel (not for the transposed-output form)
             if (best && (plain_epilogue || !TO) && p.N % 4 == 0 && ((p.M >= 256 && p.N >= 256) || skinny)) {
                 force_tile = 512;
@@ -2355,8 +2497,10 @@ int launch_cfg(hipStream_t st, GemmCtx& c, GemmArgs& p, int force_tile) {
                 // 2,560 = 192 tiles x 40 K-tiles): ONE round of the 256x256 kernel on three quarters of the CUs beats 768 tiles of the 128x128
                 // kernel (109.7 us = 587 TFLOP/s measured there, profiles/r04_logs/c3_gemm_table.txt) — priced with the constants used below
                 static const int partial_round = [] { const char* e = getenv("MOLLY_GEMM_PARTIAL_ROUND"); return e ? atoi(e) : 1; }();
+                // (the 128x128 kernel's last, partly filled round costs a whole one: 650 blocks x 20 K-tiles measured 54.9 us, 1,040 blocks 66.2 —
+                // 1.3 us per K-tile and round, half a round on top: round 6, profiles/r06_logs/esm_gemm_a.log)
                 if (partial_round && force_tile == 128 && t256 >= 128 && t256 < 256 && p.M >= 256 && p.N >= 256 &&
-                    12.0 + 6.0 + 1.4 * nk < 5.0 + (t128 > 512 ? (t128 / 512.0 + 0.35) * 1.17 : 1.25) * nk)
+                    12.0 + 6.0 + 1.25 * nk < 5.0 + (t128 > 512 ? (t128 / 512.0 + 0.5) * 1.3 : 1.25) * nk)
                     force_tile = 512;
             }
         }

@@ -140,7 +140,8 @@ class EsmEngine:
         A changed shape (reserve), another GEMM context or a replaced scratch tensor drops the graph; after four captures the engine stays eager
         (batches whose span length keeps changing would pay a capture — a device synchronize — each time).  MOLLY_ENC_GRAPH=0: always eager.
         Measured (same box, config 3): 198.0 -> 197.0 ms per step; neutral at 16 samples per GPU, where the launches are long."""
-        key = (n_seq, K, ops._ctx())
+        # (the captured launches bake in the weight addresses too: a re-prepared engine — another parameter buffer — is another graph)
+        key = (n_seq, K, ops._ctx(), self.wemb.data_ptr())
         ws = ops.current_gemm_scratch()
         if self._g is not None and (self._g_key != key or ws is None or ws.data_ptr() != self._g_ws_ptr):
             self._g, self._g_seen = None, 0
@@ -160,6 +161,14 @@ class EsmEngine:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._forward_frozen(self._g_ids, n_seq, K)
                 self._g_prof = ops.GEMM_PROFILE or []
+            except Exception as e:                              # noqa: BLE001 — an op that is illegal inside a capture, no memory for the graph pool
+                # stay eager for good: without this every later call retried the capture and failed again, and the encoder was unusable until
+                # MOLLY_ENC_GRAPH=0 was set
+                import warnings
+                warnings.warn(f"EsmEngine: capturing the frozen forward failed ({type(e).__name__}: {str(e)[:120]}); running eagerly from now on")
+                self._g, self._g_seen, self._g_recaptures = None, 0, 4
+                ops.GEMM_PROFILE = prof
+                return self._forward_frozen(ids, n_seq, K)
             finally:
                 ops.GEMM_PROFILE = prof
             assert ops.current_gemm_scratch() is ws, "the GEMM scratch was replaced during graph capture"

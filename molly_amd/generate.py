@@ -327,9 +327,13 @@ class NoRepeatNGram:
 def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_list=None, max_new_tokens=3072, do_sample=True,
              temperature=0.8, top_p=0.95, top_k=None, repetition_penalty=None, pad_token_id=None, eos_token_id=None,
              generator: Optional[torch.Generator] = None, no_repeat_ngram_size: Optional[int] = None, num_beams: int = 1,
-             length_penalty: float = 1.0, early_stopping=False) -> torch.Tensor:
-    """Returns the NEW tokens only, int64 [B, n_new] (what HF returns when called with inputs_embeds and no input_ids)."""
+             length_penalty: float = 1.0, early_stopping=False, min_new_tokens: int = 0) -> torch.Tensor:
+    """Returns the NEW tokens only, int64 [B, n_new] (what HF returns when called with inputs_embeds and no input_ids).
+    min_new_tokens: HF's MinNewTokensLengthLogitsProcessor — the eos scores are -inf while fewer new tokens than that exist (it runs among
+    the processors, in front of the warpers)."""
     if num_beams and num_beams > 1:
+        if min_new_tokens:
+            raise NotImplementedError("generate: min_new_tokens together with molly_num_beams > 1 is not built")
         return _generate_beams(model, input_ids, attention_mask, omic_ids, omic_info_list, max_new_tokens, do_sample, repetition_penalty,
                                pad_token_id, eos_token_id, no_repeat_ngram_size, int(num_beams), length_penalty, early_stopping,
                                temperature, top_k, top_p, generator)
@@ -357,6 +361,9 @@ def generate(model, input_ids, attention_mask=None, omic_ids=None, omic_info_lis
             # HF's order: repetition penalty, then the n-gram ban, then the warpers; a banned logit is -inf and the penalty leaves -inf
             # where it is, so banning first gives the same scores
             logits = ngram.apply(logits)
+        if min_new_tokens and it < min_new_tokens and eos is not None:
+            logits = logits.clone()
+            logits[:, eos] = float("-inf")
         if fused:
             nxt = ops.sample_logits(logits, out if out.shape[1] else None, repetition_penalty, temperature, top_k, top_p,
                                     seed, it)

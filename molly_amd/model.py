@@ -669,12 +669,30 @@ class OmicsOne(_MetaSafe):
                 assert len(omic_ids[i]) == len(omic_info_list[i]), f"Mismatch in omic count vs info count at index {i}"
         from .generate import generate as _gen
         cfg = self.text_config
-        return _gen(self, input_ids, attention_mask, omic_ids, omic_info_list,
-                    max_new_tokens=generate_kwargs.pop("max_new_tokens", 3072), do_sample=do_sample, temperature=temperature,
-                    top_p=top_p, top_k=top_k, repetition_penalty=generate_kwargs.pop("repetition_penalty", None),
-                    pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id, generator=generate_kwargs.pop("generator", None),
-                    no_repeat_ngram_size=no_repeat_ngram_size, num_beams=int(generate_kwargs.pop("molly_num_beams", 1) or 1),
-                    length_penalty=generate_kwargs.pop("length_penalty", 1.0), early_stopping=generate_kwargs.pop("early_stopping", False))
+        # ---- **generate_kwargs: the reference forwards every one of them to HuggingFace's generate (:220-232).  What this build honours is
+        # taken out below; anything left over is REFUSED (a silently dropped `stopping_criteria` or `bad_words_ids` would change the output
+        # without a word — VERDICT r05).  `use_cache`: the reference sets it to False under world > 1 (:202-204: HF then re-runs the whole
+        # sequence per token, same tokens); here the KV cache is this rank's own memory and is always used, so both values mean the same.
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            generate_kwargs.setdefault("use_cache", False)
+        use_cache = generate_kwargs.pop("use_cache", None)
+        if use_cache not in (None, True, False):
+            raise TypeError(f"OmicsOne.generate: use_cache={use_cache!r}")
+        kw = dict(max_new_tokens=generate_kwargs.pop("max_new_tokens", 3072), repetition_penalty=generate_kwargs.pop("repetition_penalty", None),
+                  generator=generate_kwargs.pop("generator", None), num_beams=int(generate_kwargs.pop("molly_num_beams", 1) or 1),
+                  length_penalty=generate_kwargs.pop("length_penalty", 1.0), early_stopping=generate_kwargs.pop("early_stopping", False),
+                  min_new_tokens=int(generate_kwargs.pop("min_new_tokens", 0) or 0))
+        for k in ("pad_token_id", "eos_token_id"):                 # (the reference passes these itself: a second copy in **kwargs is a TypeError there too)
+            if k in generate_kwargs:
+                raise TypeError(f"OmicsOne.generate() got multiple values for keyword argument '{k}' (the reference passes the model config's)")
+        if generate_kwargs:
+            raise NotImplementedError(
+                "OmicsOne.generate: generate_kwargs not honoured by this build: " + ", ".join(sorted(generate_kwargs)) +
+                " (honoured: max_new_tokens, min_new_tokens, repetition_penalty, use_cache, generator, length_penalty / early_stopping with "
+                "molly_num_beams); the reference forwards them to HuggingFace's generate (src/model/omics_one.py:220-232)")
+        return _gen(self, input_ids, attention_mask, omic_ids, omic_info_list, do_sample=do_sample, temperature=temperature,
+                    top_p=top_p, top_k=top_k, pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id,
+                    no_repeat_ngram_size=no_repeat_ngram_size, **kw)
 
 
 class _GradHandOff(torch.autograd.Function):

@@ -120,33 +120,91 @@ class _NullComm:
         pass
 
 
-def sweep_exchange(candidates, measure, steps_each: int):
+def sweep_exchange(candidates, measure, steps_each: int, build=None, agree=None, budget_s: Optional[float] = None, broadcast=None,
+                   clock=None):
     """Which (bucket size, reduce-scatter algorithm) runs this job's step fastest on this job's own ranks?  The reference fixes
     `reduce_bucket_size` / `allgather_bucket_size` at 5e8 elements in a config file (src/configs/ds_z2_config.json:18-27); here the
-    first multi-GPU run measures its own: `measure(bucket_mib, rs_algo)` builds the optimizer with that layout, runs one settling
-    step + `steps_each` timed ones and returns the step time in ms ALREADY maximised over the ranks (so every rank sees the same
-    table and picks the same winner), or raises — a candidate that fails (out of memory at 1 GiB buckets, an algorithm the backend
-    refuses) is recorded with its error and skipped.  Returns {"ms_per_step": {"<MiB>/<algo>": ms | None}, "errors": {...},
-    "chosen": {"bucket_mib": ..., "rs_algo": ...}, "steps_each": n}; ties go to the earlier candidate (smaller bucket first)."""
-    table, errors = {}, {}
+    first multi-GPU run measures its own.
+
+    Per candidate: `build(bucket_mib, rs_algo)` (optional) constructs the optimizer with that layout — the step that can fail on ONE
+    rank (out of memory at 1 GiB buckets on the fullest rank, an IPC open the driver refuses) — then `agree(ok, err) -> (ok_all, err)`
+    makes the verdict COLLECTIVE (bench.py: an all-reduce MIN + the first failing rank's message): if any rank failed, every rank
+    records the error and skips the candidate together, so no rank ever runs a layout the others do not (a rank that moved
+    on alone met the others inside the previous candidate's collectives — a hang until the 30-minute timeout, or wrong-sized reductions).
+    `measure(bucket_mib, rs_algo)` then runs one settling step + `steps_each` timed ones and returns the step time in ms ALREADY
+    maximised over the ranks; an exception out of it is NOT caught: collectives are in flight by then, and the only safe thing is to
+    abort the job (bench.py prints its one failure line and exits non-zero).  Without `build`, `measure` does both and its exceptions are
+    recorded and skipped as before (single process, the CPU tests).
+
+    `budget_s`: wall budget of the whole sweep; before each candidate every rank asks `agree(not over_budget)` — one rank over its budget
+    stops all of them — and the best so far is kept: `truncated` / `not_run` in the result say so.  `broadcast(obj) -> obj` (bench.py:
+    rank 0's) makes `chosen` the same object everywhere even if the table's floats differed in the last bit.
+
+    Returns {"ms_per_step": {"<MiB>/<algo>": ms | None}, "errors": {...}, "chosen": {"bucket_mib": ..., "rs_algo": ...}, "steps_each": n
+    [, "truncated": True, "not_run": [...], "budget_s": ...]}; ties go to the earlier candidate (smaller bucket first)."""
+    import time
+    clock = clock or time.monotonic
+    agree = agree or (lambda ok, err=None: (ok, err))
+    t0 = clock()
+    table, errors, not_run = {}, {}, []
     best_key, best_ms, best = None, None, None
-    for mib, algo in candidates:
+    candidates = list(candidates)
+    for ci, (mib, algo) in enumerate(candidates):
         key = f"{mib:g}/{algo}"
-        try:
-            ms = float(measure(mib, algo))
-        except Exception as e:                                    # noqa: BLE001 — recorded, the sweep goes on
-            table[key] = None
-            errors[key] = f"{type(e).__name__}: {str(e)[:200]}"
-            continue
+        if budget_s is not None and ci > 0:
+            go, _ = agree(clock() - t0 <= budget_s, None)
+            if not go:
+                not_run = [f"{m:g}/{a}" for m, a in candidates[ci:]]
+                break
+        if build is not None:
+            err = None
+            try:
+                build(mib, algo)
+            except Exception as e:                                # noqa: BLE001 — made collective below
+                err = f"{type(e).__name__}: {str(e)[:200]}"
+            ok, err_all = agree(err is None, err)
+            if not ok:
+                table[key] = None
+                errors[key] = err_all or err or "a rank failed to build this layout"
+                continue
+            ms = float(measure(mib, algo))                        # collectives in flight: a failure here aborts (see above)
+        else:
+            try:
+                ms = float(measure(mib, algo))
+            except Exception as e:                                # noqa: BLE001 — recorded, the sweep goes on
+                table[key] = None
+                errors[key] = f"{type(e).__name__}: {str(e)[:200]}"
+                continue
         table[key] = round(ms, 2)
         if best_ms is None or ms < best_ms:
             best_key, best_ms, best = key, ms, (mib, algo)
     if best is None:
         raise RuntimeError(f"bucket sweep: every candidate failed: {errors}")
-    out = {"ms_per_step": table, "chosen": {"bucket_mib": best[0], "rs_algo": best[1], "key": best_key}, "steps_each": steps_each}
+    chosen = {"bucket_mib": best[0], "rs_algo": best[1], "key": best_key}
+    if broadcast is not None:
+        chosen = broadcast(chosen)
+    out = {"ms_per_step": table, "chosen": chosen, "steps_each": steps_each}
     if errors:
         out["errors"] = errors
+    if not_run:
+        out["truncated"] = True
+        out["not_run"] = not_run
+        out["budget_s"] = budget_s
     return out
+
+
+def dist_agree(device, group=None):
+    """-> agree(ok, err) for `sweep_exchange` over torch.distributed: MIN over the ranks of `ok`, and the message of the lowest failing rank."""
+    def agree(ok, err=None):
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if flag.item() > 0:
+            return True, None
+        errs = [None] * dist.get_world_size(group)
+        dist.all_gather_object(errs, err, group=group)
+        first = next(((r, e) for r, e in enumerate(errs) if e), None)
+        return False, (f"rank {first[0]}: {first[1]}" if first else None)
+    return agree
 
 
 _STAGED_DEFAULT = False        # set by preflight_collectives when the in-place forms misbehave on this backend
@@ -275,11 +333,18 @@ class Zero2Optimizer:
         self.t = 0
         # ---- overlap machinery -------------------------------------------------------------------------------
         rs_algo = rs_algo or os.environ.get("MOLLY_RS_ALGO", "rccl")
+        self.rs_algo_fallback = None            # why a requested transport was not used (recorded in bench.py's comm line)
         if comm is None and rs_algo == "p2p" and self.world > 1:
-            # direct peer exchange over mapped peer memory (trainer/p2p.py; SURVEY.md 5 option 3): no collective for the buckets at all
-            assert stage == 2 and flat_params.is_cuda, "rs_algo='p2p' is the ZeRO-2 exchange on GPU buffers"
-            from .p2p import P2PComm
-            comm = P2PComm(flat_grads, flat_params, len(self.buckets), group)
+            # direct peer exchange over mapped peer memory (trainer/p2p.py; SURVEY.md 5 option 3): no collective for the buckets at all.
+            # The transport refuses itself — on every rank together, before anything is mapped — where the devices cannot reach each
+            # other's memory or the allocator's IPC handles would not cover the buffers: all-to-all then (the same arithmetic, bit for bit)
+            assert stage == 2, "rs_algo='p2p' is the ZeRO-2 exchange"
+            from .p2p import P2PComm, P2PUnavailable
+            try:
+                comm = P2PComm(flat_grads, flat_params, len(self.buckets), group)
+            except P2PUnavailable as e:
+                self.rs_algo_fallback = f"p2p refused ({e}); using a2a"
+                rs_algo = "a2a"
         self.comm = comm if comm is not None else _DistComm(group, staged=_STAGED_DEFAULT, rs_algo=rs_algo,
                                                             reduce_rows=getattr(self.k, "reduce_rows", None))
         self.rs_algo = getattr(self.comm, "rs_algo", "rccl")
@@ -470,6 +535,8 @@ class Zero2Optimizer:
         """reduce-scatter -> global-norm clip -> AdamW on the owned chunks -> all-gather.  Returns the (device) grad norm."""
         self.t += 1
         lr = self.lr if lr is None else lr
+        if hasattr(self.comm, "check"):
+            self.comm.check()                   # direct peer exchange: a wait of an earlier step gave up (plain read of a pinned word, no sync)
         if self.ustream is not None:
             # the previous step's side-stream AdamW reads the clip coefficient this step is about to overwrite; in the training
             # loop it finished long ago (the backward waited for every parameter), this only orders back-to-back step() calls
@@ -531,8 +598,12 @@ class Zero2Optimizer:
         self._async_armed = True
 
     def skipped_steps(self) -> int:
-        """Optimizer steps skipped because the gradient norm was not finite (host sync: call when logging)."""
-        return int(self.scal[3].item())
+        """Optimizer steps skipped because the gradient norm was not finite (host sync: call when logging).  With the direct peer exchange a
+        skipped step may be a peer that never arrived: that raises here (and at the transport's next call) instead of being counted."""
+        n = int(self.scal[3].item())
+        if hasattr(self.comm, "check"):
+            self.comm.check()
+        return n
 
     @torch.no_grad()
     def refresh_master(self):

@@ -47,7 +47,7 @@ def test_dynamic_fetch_equals_static_walk(form, M, N, K):
     on, off = _ctx(1), _ctx(0)
     with ops.use_gemm_context(off):
         ref = ops.gemm(a, b, **FORMS[form])
-        assert off.get("last_config") % 1000 == 512
+        assert off.get("last_config") % 1000 in (512, 514)      # (514: the streaming-epilogue instantiation of the plain NT launch)
     with ops.use_gemm_context(on):
         outs = [ops.gemm(a, b, **FORMS[form]) for _ in range(3)]
         assert on.get("last_config") % 1000 == 513, on.get("last_config")

@@ -189,6 +189,38 @@ def test_frozen_encoder_forward_replayed_from_a_graph_equals_the_eager_launches(
         _replay_checks(eng, ids, eager)
 
 
+def test_a_failed_encoder_graph_capture_leaves_the_engine_eager(tiny_meta, monkeypatch):
+    """a capture that raises (an op illegal inside a capture, no memory for the graph pool) must not be retried on every later
+    call — the engine warns once, stays eager and keeps producing the eager values."""
+    from molly_amd import esm, ops
+    monkeypatch.setattr(esm, "_ENC_GRAPH", True)
+    m = _build(tiny_meta, train_llm=True, train_mlp=True)
+    eng = m._rt.prot
+    eng._g_recaptures = 0
+    x = torch.randint(4, eng.cfg.vocab_size, (3, 64), generator=torch.Generator().manual_seed(5)).cuda()
+    ctx = m._rt.gemm_ctx
+    ctx.ensure_workspace(0)
+    with ops.use_gemm_context(ctx):
+        eng.forward(x)                                           # first call with the shape: eager (and the buffers exist)
+        ref = eng._forward_frozen(x, 3, 64).clone()
+
+        class Boom:
+            def __init__(self, *a, **k):
+                pass
+
+            def __enter__(self):
+                raise RuntimeError("hipErrorStreamCaptureUnsupported (stand-in)")
+
+            def __exit__(self, *a):
+                return False
+        monkeypatch.setattr(torch.cuda, "graph", Boom)
+        with pytest.warns(UserWarning, match="running eagerly"):
+            got = eng.forward(x).clone()                         # second call: the capture is attempted and fails
+        assert torch.equal(got, ref) and eng._g is None and eng._g_recaptures >= 4
+        got = eng.forward(x).clone()                             # later calls do not try again (Boom would raise: no warning, no error)
+        assert torch.equal(got, ref)
+
+
 def _replay_checks(eng, ids, eager):
     eng._g_recaptures = 0
     for call in range(6):

@@ -375,3 +375,28 @@ def test_generate_beam_search_through_the_reference_signature(tiny_meta):
     g = torch.Generator(device="cuda").manual_seed(5)
     s2 = m.generate(ids, mask, omic, info, molly_num_beams=3, do_sample=True, temperature=0.8, top_k=20, top_p=0.95, max_new_tokens=6, generator=g)
     assert s1.shape[0] == 2 and s1.shape[1] <= 6 and torch.equal(s1, s2)
+
+
+def test_generate_kwargs_are_honoured_or_refused_never_dropped(tiny_meta):
+    """reference src/model/omics_one.py:200-204, 220-232: every extra keyword goes to HuggingFace's generate, and under world > 1 the
+    reference sets use_cache=False.  Here: use_cache (either value: the KV cache is this rank's own memory, same tokens), min_new_tokens
+    (HF's MinNewTokensLengthLogitsProcessor) and the sampling extras are honoured; anything this build does not implement raises instead of
+    silently changing the output."""
+    m = build_tiny(tiny_meta)
+    ids, mask, omic, info = _left_padded_batch(tiny_meta)
+    base = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6)
+    assert torch.equal(base, m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, use_cache=False))
+    assert torch.equal(base, m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, use_cache=True))
+    # min_new_tokens: make the first greedy token of sample 0 the EOS — without it the row stops at once, with it EOS cannot be chosen before
+    # three new tokens exist
+    m.text_config.eos_token_id = int(base[0, 0])
+    m.text_config.pad_token_id = 1000
+    stopped = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6)
+    assert bool((stopped[0, 1:] == 1000).all())
+    kept = m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=6, min_new_tokens=3)
+    assert not bool((kept[0, :3] == int(base[0, 0])).any()) and kept.shape[1] >= 3
+    for bad in (dict(stopping_criteria=[lambda *a: True]), dict(bad_words_ids=[[5]]), dict(num_return_sequences=2)):
+        with pytest.raises(NotImplementedError, match=next(iter(bad))):
+            m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=2, **bad)
+    with pytest.raises(TypeError, match="eos_token_id"):
+        m.generate(ids, mask, omic, info, do_sample=False, max_new_tokens=2, eos_token_id=3)

@@ -292,38 +292,9 @@ def test_attn_fwd_transposed_second_store(hd, nh, nkv, T, causal, ragged):
     assert torch.equal(o0, o1) and torch.equal(l0, l1) and torch.equal(ot, o0.t().contiguous())
 
 
-@pytest.mark.parametrize("pipe", ["8", "4"])
-@pytest.mark.parametrize("nh,nkv,T,causal,ragged", [(4, 2, 256, True, False), (4, 2, 200, True, True), (2, 1, 512, True, True),
-                                                     (16, 8, 2048, True, False), (8, 2, 1100, False, True), (4, 4, 777, True, True)])
-def test_attn_fwd_software_pipelined_forms(pipe, nh, nkv, T, causal, ragged, monkeypatch):
-    """attn_fwd_pipe_kernel (round 5, opt-in by MOLLY_ATTN_FWD_PIPE: 8 = eight waves x 32 query rows, staggered halves; 4 = four waves x 64
-    rows, one wave per SIMD, fixed reference maximum + conditional fall-back) against the fp32 reference, at lengths that make every
-    kind of tile: interior, diagonal, a range that starts and ends inside a tile, rows past the end of the sequence."""
-    monkeypatch.setenv("MOLLY_ATTN_FWD_PIPE", pipe)
-    hd, B = 128, 2
-    M = B * T
-    qkv = _rand(M, (nh + 2 * nkv) * hd, seed=31).to(BF)
-    q, k, v = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
-    lo = hi = None
-    if ragged:
-        lo = torch.tensor([0, 70], device=DEV, dtype=torch.int32)
-        hi = torch.tensor([T, T - 37], device=DEV, dtype=torch.int32)
-    scale = hd ** -0.5
-    o, lse = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, causal, lo, hi)
-    ro, rl = _attn_ref(q, k, v, B, T, nh, nkv, hd, scale, causal, lo, hi)
-    live = torch.isfinite(rl)
-    rof = ro.view(B, T, nh, hd).transpose(1, 2)
-    of = o.float().view(B, T, nh, hd).transpose(1, 2)
-    _close(of[live], rof[live], 2e-2, 1e-2, "attn O (pipe %s)" % pipe)
-    _close(lse[live], rl[live], 2e-3, 1e-4, "attn lse2 (pipe %s)" % pipe)
-
-
-@pytest.mark.parametrize("pipe", ["4", "8"])
-def test_attn_fwd_pipelined_forms_survive_a_running_maximum_that_explodes(pipe, monkeypatch):
-    """Scores that grow by far more than 2^64 along the key axis.  The eight-wave form rescales online (guide T13); the four-wave form
-    keeps the row's FIRST maximum as its reference, so here its P overflows by design — it raises the redo flag and attn_fwd_kernel,
-    launched behind it, recomputes the launch.  Either way the result is the reference's (softmax concentrates on the late keys)."""
-    monkeypatch.setenv("MOLLY_ATTN_FWD_PIPE", pipe)
+def test_attn_fwd_survives_a_running_maximum_that_explodes():
+    """Scores that grow by far more than 2^64 along the key axis: the online rescale (guide T13) must keep O and the LSE finite and equal to the
+    fp32 reference (softmax concentrates on the late keys)."""
     hd, nh, nkv, B, T = 128, 2, 1, 1, 512
     g = torch.Generator(device=DEV).manual_seed(3)
     q = torch.randn(B * T, nh * hd, device=DEV, generator=g) * 0.3
@@ -338,12 +309,6 @@ def test_attn_fwd_pipelined_forms_survive_a_running_maximum_that_explodes(pipe, 
     assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
     _close(o.float().view(B, T, nh, hd).transpose(1, 2), ro.view(B, T, nh, hd).transpose(1, 2), 2e-2, 1e-2, "attn O (exploding maximum)")
     _close(lse, rl, 2e-3, 1e-3, "attn lse2 (exploding maximum)")
-    # and the next, ordinary launch is not disturbed by the raised flag
-    qkv = _rand(B * T, (nh + 2 * nkv) * hd, seed=5).to(BF)
-    q2, k2, v2 = qkv[:, :nh * hd], qkv[:, nh * hd:(nh + nkv) * hd], qkv[:, (nh + nkv) * hd:]
-    o2, l2 = ops.attn_fwd(q2, k2, v2, B, T, nh, nkv, hd, scale, True)
-    r2, rl2 = _attn_ref(q2, k2, v2, B, T, nh, nkv, hd, scale, True)
-    _close(o2.float().view(B, T, nh, hd).transpose(1, 2), r2.view(B, T, nh, hd).transpose(1, 2), 2e-2, 1e-2, "attn O (launch after a redo)")
 
 
 def _attn_ref_grads(q, k, v, do, B, T, nh, nkv, hd, scale, causal, lo=None, hi=None, chunk=1024):

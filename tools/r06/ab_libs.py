@@ -26,7 +26,10 @@ def main():
     M = a.m
     shapes = [("qkv fwd", "nt", M, 4096, 2048, 0), ("o fwd +res", "nt", M, 2048, 2048, 4), ("gate|up (plain)", "nt", M, 12288, 2048, 0),
               ("down fwd +res", "nt", M, 2048, 6144, 4), ("qkv dgrad", "nn", M, 2048, 4096, 0), ("gate|up dgrad", "nn", M, 2048, 12288, 0),
-              ("o dgrad", "nn", M, 2048, 2048, 0), ("down dgrad (plain)", "nn", M, 6144, 2048, 0)]
+              ("o dgrad", "nn", M, 2048, 2048, 0), ("down dgrad (plain)", "nn", M, 6144, 2048, 0),
+              # the fused epilogues: SwiGLU backward in the down-projection's dgrad (res = [gate | up] [M][2 ff], C = d[gate | up]), SwiGLU forward in
+              # the gate | up projection (C = [gate | up] [M][2 ff], res = the activation [M][ff])
+              ("down dgrad +swiglu'", "nn", M, 6144, 2048, 128), ("gate|up +swiglu", "nt", M, 12288, 2048, 64)]
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).bfloat16()
@@ -52,14 +55,16 @@ def main():
             continue
         A = rnd(m, k)
         B = rnd(n, k) if form == "nt" else rnd(k, n)
-        R = rnd(m, n) if flags & 4 else None
-        ldc = n + a.ldc_pad
+        R = rnd(m, n) if flags & 4 else rnd(m, 2 * n) if flags & 128 else torch.empty(m, n // 2, dtype=torch.bfloat16, device=dev) if flags & 64 else None
+        ldc = (2 * n if flags & 128 else n) + a.ldc_pad
         outs = [torch.empty(m, ldc, dtype=torch.bfloat16, device=dev) for _ in cols]
+        acts = [torch.empty(m, n // 2, dtype=torch.bfloat16, device=dev) for _ in cols] if flags & 64 else None
 
         def run(i):
             _, L, h, _ = cols[i]
-            L.call("molly_gemm_bf16_ctx", h, st, A, B, outs[i], None, R, m, n, k, A.stride(0), B.stride(0), ldc, n if R is not None else 0, flags,
-                   0, int(form == "nn"))
+            res = acts[i] if flags & 64 else R
+            L.call("molly_gemm_bf16_ctx", h, st, A, B, outs[i], None, res, m, n, k, A.stride(0), B.stride(0), ldc, res.stride(0) if res is not None else 0,
+                   flags, 0, int(form == "nn"))
         best = [1e9] * len(cols)
         for rr in range(a.rounds):
             for i in range(len(cols)):
@@ -86,7 +91,7 @@ def main():
                 tb = min(tb, e0.elapsed_time(e1) / 5)
             tcol = f"   {2.0 * m * n * k / tb / 1e9:8.0f}"
         fl = 2.0 * m * n * k
-        same = [bool(torch.equal(outs[0], o)) for o in outs]
+        same = [bool(torch.equal(outs[0], o)) and (acts is None or bool(torch.equal(acts[0], acts[i]))) for i, o in enumerate(outs)]
         print(f"{name:20s} {m:6d} {n:7d} {k:6d} " + " ".join(f"{b * 1e3:9.1f} {fl / b / 1e9:6.0f}" for b in best) + tcol + "   " + "".join("y" if x else "N" for x in same), flush=True)
 
 
