@@ -374,7 +374,7 @@ def attention_flops_per_step(cfg, enc_cfgs, B, T, micro, train_bio=False):
 def vendor_gemm_yardstick(dev, M):
     """torch.matmul (the vendor library: hipBLASLt / rocBLAS) beside molly's own kernel on the forward and dgrad shapes of the
     decoder layer at this batch, same process, same box, OUTSIDE the timed region: a same-node yardstick next to `vs_baseline:
-    null`.  Random data, best of 3 rounds of 5 launches each, HIP events.  TFLOP/s."""
+    null`.  Random data, best of 5 interleaved rounds of 5 launches each, HIP events.  TFLOP/s."""
     import torch
     from molly_amd import ops
     g = torch.Generator(device=dev).manual_seed(0)
@@ -382,17 +382,20 @@ def vendor_gemm_yardstick(dev, M):
     shapes = [("qkv fwd", "nt", 4096, 2048), ("o fwd", "nt", 2048, 2048), ("gate|up fwd", "nt", 12288, 2048), ("down fwd", "nt", 2048, 6144),
               ("qkv dgrad", "nn", 2048, 4096), ("down dgrad", "nn", 6144, 2048)]
 
-    def t_of(f):
-        f()
-        best = 1e9
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                f()
-            e1.record()
-            torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) / 5)
+    def t_pair(f, g_):
+        """best of 5 INTERLEAVED rounds of 5 launches each (guide 5.4 rule 24: both arms see the same clock and cache state; measured one after
+        the other, the arm that ran first read 3-6 % low — tools/r06/chk_se.py)"""
+        f(); g_()
+        best = [1e9, 1e9]
+        for _ in range(5):
+            for i, fn in enumerate((f, g_)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best[i] = min(best[i], e0.elapsed_time(e1) / 5)
         return best
     out = {}
     for name, form, n, k in shapes:
@@ -404,7 +407,8 @@ def vendor_gemm_yardstick(dev, M):
             ours, vend = (lambda: ops.gemm_nt(a, b, out=c)), (lambda: torch.matmul(a, b.t(), out=c))
         else:
             ours, vend = (lambda: ops.gemm(a, b, out=c, b_kmajor=True)), (lambda: torch.matmul(a, b, out=c))
-        out[name] = {"M": M, "N": n, "K": k, "molly": round(fl / t_of(ours) / 1e9, 1), "torch_matmul": round(fl / t_of(vend) / 1e9, 1)}
+        t_ours, t_vend = t_pair(ours, vend)
+        out[name] = {"M": M, "N": n, "K": k, "molly": round(fl / t_ours / 1e9, 1), "torch_matmul": round(fl / t_vend / 1e9, 1)}
     return out
 
 
@@ -821,8 +825,9 @@ def main(argv=None):
         names = {(False, False): "NT gemm256_kernel<false,false>", (False, True): "NN gemm256_kernel<false,true>",
                  (True, True): "TN gemm256_kernel<true,true>"}
         def klass(kcfg, lay):
-            # cfg = 128 | 512 (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems of a grouped launch)
-            key = (names[lay] if kcfg % 1000 in (512, 513) else
+            # cfg = 128 | 512 | 513 (drawing its tiles) | 514 (streaming epilogue) (+ 1000 * split-K factor, + 50000 stream-K, + 100000 * problems of a grouped launch)
+            key = ("NT gemm256_kernel<false,false,...,SE> (streaming epilogue: plain launches of whole tiles)" if kcfg % 1000 == 514 else
+                   names[lay] if kcfg % 1000 in (512, 513) else
                    "gemm_rows_kernel (64-row tiles: small grids at <= 1,024 rows)" if kcfg % 1000 == 32 else
                    "gemm_skinny_kernel (decode rows)" if kcfg % 1000 == 16 else "gemm_kernel<...,128,2,64> (a side narrower than a tile)")
             if kcfg % 1000 in (16, 32):
