@@ -432,7 +432,7 @@ def copy_bandwidth(dev, nbytes: int = 1 << 30):
 def clock_under_load(dev, M):
     """Shader clock and socket power while the step's dominant kernel runs (`rocm-smi`, read-only, polled beside ~2.5 s of queued gate|up forward
     GEMMs, OUTSIDE the timed region).  The part runs every heavy kernel at its power cap, so the clock — not 2.4 GHz — sets the matrix pipes' peak
-    (DESIGN.md §7 round 5 item 15); `roofline.frac` keeps the guide's 2.5 PFLOP/s, this says what that peak is at the clock the kernel really gets."""
+    (LOG.md round 5 item 15); `roofline.frac` keeps the guide's 2.5 PFLOP/s, this says what that peak is at the clock the kernel really gets."""
     import re
     import subprocess
     import torch
