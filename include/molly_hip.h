@@ -367,6 +367,19 @@ int molly_attn_bwd(void* stream, const void* Q, const void* K, const void* V, co
  * writes the rows: still no atomics, still bitwise reproducible.  molly_attn_bwd_workspace: the floats that takes (0 = the split
  * does not apply to these sizes); a smaller or NULL workspace runs the unsplit passes. */
 int molly_attn_bwd_workspace(int B, int T, int n_heads, int n_kv_heads, int head_dim);
+/* molly_attn_bwd with the q/k-norm + rotary BACKWARD (HF:models/qwen3/modeling_qwen3.py:225-236, what molly_norm_rope_bwd computes) inside the dQ and
+ * dK kernels' row epilogues (round 6): Q / K are the normed + rotated rows the forward saved, X the PRE-norm projection rows [B*T][>= (nq + nk) * hd]
+ * pointing at q head 0 (k heads follow), dX the gradient of that projection in the same layout (its q and k parts are written here, dV goes to dV as
+ * before); qw / kw the gains, cos / sin [T][hd / 2] fp32 with position = token index within the sample.  Gain gradients leave as one row of hd floats
+ * per workgroup: dwq_part [molly_attn_bwd_rope_blocks(.., 0)][hd], dwk_part [..(.., 1)][hd] (sum the rows: molly_colsum_batched).
+ * Head dim 128; the dK / dV passes are never split by query head here: where molly_attn_bwd_workspace(..) > 0 (one sample per GPU) prefer
+ * molly_attn_bwd_ws + molly_norm_rope_bwd. */
+int molly_attn_bwd_rope_blocks(int B, int T, int n_heads, int n_kv_heads, int which);
+int molly_attn_bwd_rope(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse2,
+                        float* delta_ws, void* dV, const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads,
+                        int head_dim, int ldq, int ldk, int ldv, int ldo, int lddo, int lddv, float scale, int causal, const void* X,
+                        int ldx, const void* qw, const void* kw, const float* cos_t, const float* sin_t, float eps, void* dX, int lddx,
+                        float* dwq_part, float* dwk_part);
 int molly_attn_bwd_ws(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
                       const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo, const int* kv_hi,
                       int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk, int ldv, int ldo, int lddo,

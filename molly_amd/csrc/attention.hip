@@ -613,6 +613,122 @@ __global__ __launch_bounds__(128) void attn_fwd_small_kernel(AttnArgs p) {
 // δ[q] = rowsum(dO ⊙ O) comes from a small preprocess kernel.  7 MFMA products instead of flash-bwd's 5, traded
 // for no cross-workgroup dQ reduction (guide Appendix B "Attention backward": dQ atomics are rate-limited).
 // ================================================================================================
+// ---- q/k-norm + rotary BACKWARD inside the attention backward's row epilogues (round 6).  HF applies, per head row, RMSNorm with a gain and
+// then the rotary embedding (HF:models/qwen3/modeling_qwen3.py:225-236: q_norm / k_norm, apply_rotary_pos_emb); its backward was a kernel of its
+// own between the attention backward and the q | k | v dgrad (norm_rope_bwd_kernel: 154 us per layer at 32 k tokens, instruction-bound at
+// 3.9 TB/s: one more read of dq | dk and of the saved pre-norm rows, one more write).  The dQ and dK kernels leave their rows through a
+// wave-private LDS slab as WHOLE head rows (store_rows), so the same arithmetic runs there: a lane holds 8 consecutive elements of a row
+// (16 lanes per 256-byte row), its rotary partners sit 8 lanes away in the same DPP row, the two row sums are DPP adds — and the rows go
+// straight into d(q | k | v) as the dgrad GEMM reads them.  Gain gradients: per-lane sums over the wave's rows, lanes and waves combined
+// through LDS, one row of HD floats per workgroup into `dw_part` (summed by the batched column reduction at the end of the backward).
+struct RopeBwdFuse {
+    const bf16_t* X; int ldx;        // the saved PRE-norm projection rows, pointing at head 0 of q (or of k); nullptr = off
+    const bf16_t* w;                 // the norm's gain [HD]
+    const float* cos; const float* sin;   // [positions][HD / 2] (position = token index within the sample)
+    bf16_t* dX; int lddx;            // output: d(projection), pointing at head 0 of q (or of k)
+    float* dw_part;                  // [gridDim.x][HD]
+    float eps;
+};
+
+// the wave's 32 rows of acc * mul (rows row0 .. of the (batch x T) token axis, positions pos0 .., head columns head_col ..): rounded to bf16 as the
+// unfused path stores dq / dk, then rotary^T, norm backward against the saved row, stored; dw[e] += this lane's share of the gain gradient
+template <int HD, int ND>
+__device__ __forceinline__ void store_rows_rope_bwd(bf16_t* slab, const f32x16 (&acc)[ND], float mul, const RopeBwdFuse& f, size_t row0, int pos0,
+                                                    int head_col, int rows_valid, int lane, float (&dw)[8]) {
+    static_assert(HD == 128, "the fused rotary backward is built for head dim 128");
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int PITCH = HD + 8;
+    // the saved pre-norm rows come from HBM (2 us away under load): all eight 16-byte pieces this lane needs are requested NOW, before the slab is
+    // written — one round trip per workgroup instead of one per pass (the first version, with the load inside the loop, cost the dQ kernel 66 us
+    // and the dK kernel 31 us per layer of the 154 the separate kernel took: profiles/r06_logs/fuse1_kernel_stats.csv)
+    u32x4 xall[8];
+    {
+        const int lr_ = lane >> 4, c_ = lane & 15;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + lr_;
+            xall[it] = *reinterpret_cast<const u32x4*>(f.X + (row0 + (row < rows_valid ? row : 0)) * (size_t)f.ldx + head_col + 8 * c_);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<u32x2*>(slab + r * PITCH + 32 * d + 8 * g4 + 4 * h) =
+                u32x2{pack_bf2(acc[d][4 * g4] * mul, acc[d][4 * g4 + 1] * mul), pack_bf2(acc[d][4 * g4 + 2] * mul, acc[d][4 * g4 + 3] * mul)};
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int lr = lane >> 4, c = lane & 15;                    // row of 4 per pass, 16-byte chunk of the 256-byte row
+    const bool first = c < 8;                                   // elements 8c .. 8c+7 lie in the first half: their partners are 64 further
+    const int i0 = (c & 7) * 8;                                 // index into the cos / sin row
+    float wv[8];
+    {
+        const u32x4 wq = *reinterpret_cast<const u32x4*>(f.w + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wv[2 * e] = bflo(wq[e]); wv[2 * e + 1] = bfhi(wq[e]); }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + lr;
+        const bool ok = row < rows_valid;
+        const int rowc = ok ? row : 0;
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(slab + row * PITCH + 8 * c);
+        const u32x4 xv = xall[it];
+        const float* cp = f.cos + (size_t)(pos0 + rowc) * (HD / 2) + i0;
+        const float* sp = f.sin + (size_t)(pos0 + rowc) * (HD / 2) + i0;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        float g[8], pg[8], x[8], t[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned pv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)gv[e], 0x128, 0xf, 0xf, true);     // row_ror:8: the lane 8 away in the row
+            g[2 * e] = bflo(gv[e]); g[2 * e + 1] = bfhi(gv[e]);
+            pg[2 * e] = bflo(pv); pg[2 * e + 1] = bfhi(pv);
+            x[2 * e] = bflo(xv[e]); x[2 * e + 1] = bfhi(xv[e]);
+        }
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float cs = e < 4 ? c0[e & 3] : c1[e & 3], sn = e < 4 ? s0[e & 3] : s1[e & 3];
+            // rotary^T (the forward: y1 = x1 c - x2 s, y2 = x2 c + x1 s): first half g1 c + g2 s, second half g2 c - g1 s
+            t[e] = first ? g[e] * cs + pg[e] * sn : g[e] * cs - pg[e] * sn;
+            ss += x[e] * x[e];
+            dot += t[e] * wv[e] * x[e];
+        }
+        ss = dpp_row_sum<16>(ss);
+        dot = dpp_row_sum<16>(dot);
+        const float rstd = rsqrtf(ss / (float)HD + f.eps);
+        const float coef = dot * rstd * rstd * rstd / (float)HD;
+        float dx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dx[e] = t[e] * wv[e] * rstd - x[e] * coef;
+            if (ok) dw[e] += t[e] * x[e] * rstd;
+        }
+        if (ok)
+            *reinterpret_cast<u32x4*>(f.dX + (row0 + row) * (size_t)f.lddx + head_col + 8 * c) =
+                u32x4{pack_bf2(dx[0], dx[1]), pack_bf2(dx[2], dx[3]), pack_bf2(dx[4], dx[5]), pack_bf2(dx[6], dx[7])};
+    }
+}
+
+// the workgroup's gain-gradient row: the four row-lanes of a wave (lanes l, l + 16, l + 32, l + 48 hold the same columns), then the four waves
+template <int HD>
+__device__ __forceinline__ void rope_bwd_dw_flush(float (&dw)[8], float* red /* LDS, 4 x HD floats, free */, float* dst, int wave, int lane, int tid) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        dw[e] += __shfl_xor(dw[e], 16, 64);
+        dw[e] += __shfl_xor(dw[e], 32, 64);
+    }
+    __syncthreads();                                            // every wave is done with its slab (red aliases the staging memory)
+    if (lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * HD + 8 * lane + e] = dw[e];
+    }
+    __syncthreads();
+    if (tid < HD) dst[tid] = red[tid] + red[HD + tid] + red[2 * HD + tid] + red[3 * HD + tid];
+}
+
 struct AttnBwdArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO; const bf16_t* O;
     const float* LSE; float* delta;            // delta[b, head, q] = sum_d dO[q,d] * O[q,d]: written by the dQ kernel, read by dK's
@@ -624,6 +740,7 @@ struct AttnBwdArgs {
     float* part;               // head-split dK/dV pass: per-(block, query head) accumulator images, register order (see SPLIT)
     int nblk, order_set;       // block order (block_item): query / key blocks per head, (batch, kv head) pairs walked together
     int prio;                  // wave_priority()
+    RopeBwdFuse fq, fk;        // round 6: the q/k-norm + rotary backward inside the dQ / dK row epilogues (X == nullptr: off)
 };
 
 template <int HD>
@@ -751,6 +868,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
         dma_wait();
         __syncthreads();
         cur ^= 1;
+    }
+    if constexpr (HD == 128) {
+        if (p.fq.X) {
+            // q-norm + rotary backward on the rows as they leave (RopeBwdFuse above): d(q) goes straight into d(q | k | v)
+            float dw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            store_rows_rope_bwd<HD, ND>(smem + wave * 32 * (HD + 8), dq, p.scale, p.fq, (size_t)b * T + q0, q0, head * HD, T - q0, lane, dw);
+            rope_bwd_dw_flush<HD>(dw, reinterpret_cast<float*>(smem_raw), p.fq.dw_part + (size_t)blockIdx.x * HD, wave, lane, tid);
+            return;
+        }
     }
     store_rows<HD, ND>(smem + wave * 32 * (HD + 8), dq, p.scale, p.dQ + ((size_t)b * T + q0) * p.lddq + head * HD, p.lddq, T - q0, lane);
 }
@@ -939,7 +1065,16 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     } else {
         bf16_t* slab = reinterpret_cast<bf16_t*>(smem_raw) + wave * 32 * (HD + 8);
         const int key0w = key - (lane & 31);                                           // the wave's first key
-        if (DO_DK) store_rows<HD, ND>(slab, dk, p.scale, p.dK + ((size_t)b * T + key0w) * p.lddk + kvh * HD, p.lddk, T - key0w, lane);
+        bool fused_k = false;
+        if constexpr (HD == 128 && DO_DK && !DO_DV) {
+            if (p.fk.X) {
+                float dw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                store_rows_rope_bwd<HD, ND>(slab, dk, p.scale, p.fk, (size_t)b * T + key0w, key0w, kvh * HD, T - key0w, lane, dw);
+                rope_bwd_dw_flush<HD>(dw, reinterpret_cast<float*>(smem_raw), p.fk.dw_part + (size_t)blockIdx.x * HD, wave, lane, tid);
+                fused_k = true;
+            }
+        }
+        if (DO_DK && !fused_k) store_rows<HD, ND>(slab, dk, p.scale, p.dK + ((size_t)b * T + key0w) * p.lddk + kvh * HD, p.lddk, T - key0w, lane);
         if (DO_DV) store_rows<HD, ND>(slab, dv, 1.0f, p.dV + ((size_t)b * T + key0w) * p.lddv + kvh * HD, p.lddv, T - key0w, lane);
     }
 }
@@ -1085,7 +1220,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
                               const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo,
                               const int* kv_hi, int B, int T, int n_heads, int n_kv_heads, int head_dim, int ldq, int ldk,
                               int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal,
-                              float* workspace, long workspace_floats) {
+                              float* workspace, long workspace_floats, const RopeBwdFuse* fq = nullptr, const RopeBwdFuse* fk = nullptr) {
     MOLLY_ENTER();
     MOLLY_CHECK(head_dim == 128 || head_dim == 64, "attn_bwd: head_dim=%d not built (64 and 128 are)", head_dim);
     MOLLY_CHECK(n_heads % n_kv_heads == 0, "attn_bwd: n_heads %% n_kv_heads != 0");
@@ -1106,13 +1241,19 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         attr_set = true;
     }
     const dim3 gq(n_heads * B * cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));   // dQ pass 1-D; gk: the reduce kernel's 2-D shape
     const dim3 gk1(gk.x * gk.y);                                                    // dK / dV passes 1-D (block_item)
+    if (fq) {
+        // (the fused form never splits the dK / dV passes by query head: callers for whom molly_attn_bwd_workspace(..) > 0 — one sample per GPU —
+        // are better served by molly_attn_bwd_ws + molly_norm_rope_bwd; qwen3.py decides that way)
+        MOLLY_CHECK(fk && head_dim == 128, "attn_bwd_rope: the fused q/k-norm + rotary backward is built for head dim 128");
+        p.fq = *fq;
+        p.fk = *fk;
+    }
     AttnBwdArgs pk = p;                                                             // their block order
     pk.nblk = cdiv(T, 128);
     pk.order_set = order_set(1, B * n_kv_heads);
@@ -1145,6 +1286,26 @@ extern "C" int molly_attn_bwd(void* stream, const void* Q, const void* K, const 
                               int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, int causal) {
     return attn_bwd_impl(stream, Q, K, V, O, dO, lse2, delta_ws, dQ, dK, dV, kv_lo, kv_hi, B, T, n_heads, n_kv_heads, head_dim, ldq, ldk,
                          ldv, ldo, lddo, lddq, lddk, lddv, scale, causal, nullptr, 0);
+}
+extern "C" int molly_attn_bwd_rope_blocks(int B, int T, int n_heads, int n_kv_heads, int which) {
+    return (which ? n_kv_heads : n_heads) * B * cdiv(T, 128);
+}
+extern "C" int molly_attn_bwd_rope(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse2,
+                                   float* delta_ws, void* dV, const int* kv_lo, const int* kv_hi, int B, int T, int n_heads, int n_kv_heads,
+                                   int head_dim, int ldq, int ldk, int ldv, int ldo, int lddo, int lddv, float scale, int causal, const void* X,
+                                   int ldx, const void* qw, const void* kw, const float* cos_t, const float* sin_t, float eps, void* dX, int lddx,
+                                   float* dwq_part, float* dwk_part) {
+    MOLLY_ENTER();
+    MOLLY_CHECK(X && qw && kw && cos_t && sin_t && dX && dwq_part && dwk_part, "attn_bwd_rope: null operand");
+    MOLLY_CHECK(ldx % 8 == 0 && lddx % 8 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)dX % 16) == 0 && ((uintptr_t)qw % 16) == 0 &&
+                ((uintptr_t)kw % 16) == 0 && ((uintptr_t)cos_t % 16) == 0 && ((uintptr_t)sin_t % 16) == 0,
+                "attn_bwd_rope: X / dX row strides must be multiples of 8 and every operand 16-byte aligned");
+    const size_t kcol = (size_t)n_heads * head_dim;                  // k heads follow the q heads in the projection's row
+    const RopeBwdFuse fq{(const bf16_t*)X, ldx, (const bf16_t*)qw, cos_t, sin_t, (bf16_t*)dX, lddx, dwq_part, eps};
+    const RopeBwdFuse fk{(const bf16_t*)X + kcol, ldx, (const bf16_t*)kw, cos_t, sin_t, (bf16_t*)dX + kcol, lddx, dwk_part, eps};
+    // (dQ / dK are not written: the rows leave as d(q | k | v); the strides passed for them only have to satisfy the checks)
+    return attn_bwd_impl(stream, Q, K, V, O, dO, lse2, delta_ws, dX, (bf16_t*)dX + kcol, dV, kv_lo, kv_hi, B, T, n_heads, n_kv_heads, head_dim, ldq,
+                         ldk, ldv, ldo, lddo, lddx, lddx, lddv, scale, causal, nullptr, 0, &fq, &fk);
 }
 extern "C" int molly_attn_bwd_ws(void* stream, const void* Q, const void* K, const void* V, const void* O, const void* dO,
                                  const float* lse2, float* delta_ws, void* dQ, void* dK, void* dV, const int* kv_lo,

@@ -526,6 +526,24 @@ def attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, causal, dq, dk, dv, 
     return dq, dk, dv
 
 
+def attn_bwd_rope_blocks(B, T, nh, nkv):
+    """(rows of the q gain-gradient partials, rows of the k ones) `attn_bwd_rope` writes: one per workgroup of the dQ / dK kernels."""
+    return lib().query("molly_attn_bwd_rope_blocks", B, T, nh, nkv, 0), lib().query("molly_attn_bwd_rope_blocks", B, T, nh, nkv, 1)
+
+
+def attn_bwd_rope(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, causal, dv, x_saved, qw, kw, cos, sin, eps, dx, dwq_part, dwk_part,
+                  kv_lo=None, kv_hi=None, delta_ws=None):
+    """attn_bwd + norm_rope_bwd in one pass over dq / dk (round 6): q, k = the normed + rotated rows the forward saved, x_saved = the PRE-norm
+    q | k | v projection rows, dx = the gradient of that projection (q and k parts written here; dv as before).  dwq_part [nbq, hd] / dwk_part
+    [nbk, hd] fp32 (attn_bwd_rope_blocks) receive one row of gain-gradient partials per workgroup.  Head dim 128, attn_bwd_workspace(..) == 0."""
+    if delta_ws is None:
+        delta_ws = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    lib().call("molly_attn_bwd_rope", _stream(), q, k, v, o, do, lse, delta_ws, dv, kv_lo, kv_hi, B, T, nh, nkv, hd, q.stride(0), k.stride(0),
+               v.stride(0), o.stride(0), do.stride(0), dv.stride(0), float(scale), int(causal), x_saved, x_saved.stride(0), qw, kw, cos, sin,
+               float(eps), dx, dx.stride(0), dwq_part, dwk_part)
+    return dx
+
+
 def ce_fwd_bwd(logits, labels, row_loss, scale, ignore_index=-100, write_grad=True):
     rows, V = logits.shape
     lib().call("molly_ce_fwd_bwd", _stream(), logits, labels, row_loss, scale, rows, V, logits.stride(0), ignore_index,

@@ -227,16 +227,33 @@ class Qwen3Engine:
             # its per-block partials in a workspace of its own (2L + 1 RMSNorm gains: nb1 x h floats each — 8 MB at h 2048;
             # 2L q/k-norm gains: nb2 x 2 hd) instead of launching a 64-block reduce behind itself
             self.ws_defer = None
-            if self.train_base and os.environ.get("MOLLY_DEFER_COLSUM", "1") != "0":
+            defer = self.train_base and os.environ.get("MOLLY_DEFER_COLSUM", "1") != "0"
+            # round 6: the q/k-norm + rotary backward inside the attention backward's dQ / dK row epilogues (ops.attn_bwd_rope) instead of a kernel
+            # of its own behind it — where the attention backward is not split by query head (one sample per GPU) and the gain gradients
+            # either go through the deferred column reduction or are not wanted at all (frozen base)
+            self.rope_fused = (self.hd == 128 and ops.attn_bwd_workspace(B, T, self.nh, self.nkv, self.hd) == 0 and (defer or not self.train_base)
+                               and os.environ.get("MOLLY_ATTN_ROPE_FUSE", "1") != "0")
+            nbq, nbk = ops.attn_bwd_rope_blocks(B, T, self.nh, self.nkv) if self.rope_fused else (0, 0)
+            if self.rope_fused and not self.train_base:
+                self.ws_ropeq = [torch.empty(nbq * self.hd, dtype=torch.float32, device=dev)] * self.L      # gain gradients nobody reads
+                self.ws_ropek = [torch.empty(nbk * self.hd, dtype=torch.float32, device=dev)] * self.L
+            if defer:
                 L = self.L
                 self.ws_rms = torch.empty(2 * L + 1, nb1 * h, dtype=torch.float32, device=dev)
-                self.ws_qk = torch.empty(L, nb2 * 2 * self.hd, dtype=torch.float32, device=dev)
+                if self.rope_fused:
+                    self.ws_ropeq = torch.empty(L, nbq * self.hd, dtype=torch.float32, device=dev)
+                    self.ws_ropek = torch.empty(L, nbk * self.hd, dtype=torch.float32, device=dev)
+                else:
+                    self.ws_qk = torch.empty(L, nb2 * 2 * self.hd, dtype=torch.float32, device=dev)
                 ent = [(self.ws_rms[2 * L], self.d_norm_w, nb1, h, h)]
                 for i in range(L):
                     g = self.dW[i]
-                    ent += [(self.ws_rms[2 * i], g["ln2"], nb1, h, h), (self.ws_rms[2 * i + 1], g["ln1"], nb1, h, h),
-                            (self.ws_qk[i], g["qn"], nb2, self.hd, 2 * self.hd),
-                            (self.ws_qk[i][self.hd:], g["kn"], nb2, self.hd, 2 * self.hd)]
+                    ent += [(self.ws_rms[2 * i], g["ln2"], nb1, h, h), (self.ws_rms[2 * i + 1], g["ln1"], nb1, h, h)]
+                    if self.rope_fused:
+                        ent += [(self.ws_ropeq[i], g["qn"], nbq, self.hd, self.hd), (self.ws_ropek[i], g["kn"], nbk, self.hd, self.hd)]
+                    else:
+                        ent += [(self.ws_qk[i], g["qn"], nb2, self.hd, 2 * self.hd),
+                                (self.ws_qk[i][self.hd:], g["kn"], nb2, self.hd, 2 * self.hd)]
                 self.ws_defer = ops.colsum_items(ent, dev)
 
     # ---- forward ---------------------------------------------------------------------------------------------
@@ -579,12 +596,19 @@ class Qwen3Engine:
                 self._lora_bwd(i, a, "o_proj", a["attn"], dx2, self.d_attn, accumulate)
             if tb:
                 self._wgrad_layer(1, dx2, a["attn"], g["o"], accumulate, xt=a.get("attnT"))
-            ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
-                         self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
-                         self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta, ws=self.attn_ws)
-            ops.norm_rope_bwd(a["qkv"], self.d_qk, self.d_qkv, self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos,
-                              self.sin, None if (defer or not tb) else gw(g, "qn"), None if (defer or not tb) else gw(g, "kn"), eps=cfg.rms_norm_eps,
-                              dw_accumulate=acc_n, workspace=self.ws_qk[i] if defer else self.ws)
+            if getattr(self, "rope_fused", False):
+                # d(q), d(k) leave the attention backward already through the rotary and the q/k-norm: straight into d(q | k | v)
+                ops.attn_bwd_rope(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
+                                  self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qkv[:, self.nqk:], a["qkv"], w["qn"], w["kn"],
+                                  self.cos, self.sin, cfg.rms_norm_eps, self.d_qkv, self.ws_ropeq[i], self.ws_ropek[i], kv_lo, kv_hi,
+                                  delta_ws=self.delta)
+            else:
+                ops.attn_bwd(a["qk"][:, :nq], a["qk"][:, nq:], a["qkv"][:, self.nqk:], a["attn"], self.d_attn, a["lse"], B, T,
+                             self.nh, self.nkv, self.hd, self.hd ** -0.5, True, self.d_qk[:, :nq], self.d_qk[:, nq:],
+                             self.d_qkv[:, self.nqk:], kv_lo, kv_hi, delta_ws=self.delta, ws=self.attn_ws)
+                ops.norm_rope_bwd(a["qkv"], self.d_qk, self.d_qkv, self.nh, self.nkv, self.hd, T, w["qn"], w["kn"], self.cos,
+                                  self.sin, None if (defer or not tb) else gw(g, "qn"), None if (defer or not tb) else gw(g, "kn"), eps=cfg.rms_norm_eps,
+                                  dw_accumulate=acc_n, workspace=self.ws_qk[i] if defer else self.ws)
             dxn = spare[0]
             self._dgrad(self.d_qkv, w["qkv"], dxn)
             if lora is not None:

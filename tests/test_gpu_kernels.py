@@ -418,6 +418,50 @@ def test_attn_bwd_check_notices_one_zeroed_key_tile(hd, nh, nkv, T, causal, ragg
     _attn_bwd_check(got, ref, live, nh, hd)
 
 
+@pytest.mark.parametrize("nh,nkv,T,B,ragged", [(4, 2, 256, 2, False), (4, 2, 200, 2, True), (16, 8, 2048, 8, "right"), (8, 2, 1100, 3, True)])
+def test_attn_bwd_with_the_rotary_and_qk_norm_backward_in_its_row_epilogues(nh, nkv, T, B, ragged):
+    """molly_attn_bwd_rope (round 6): the q/k-norm + rotary backward (HF:models/qwen3/modeling_qwen3.py:225-236) runs inside the dQ / dK kernels' row
+    epilogues instead of norm_rope_bwd_kernel behind them.  Same arithmetic on the same bf16-rounded dq / dk rows; what differs is the order of the
+    two 128-element row sums (8 elements per lane here, 4 + 4 there) and of the gain-gradient sums over rows: d(q | k | v) within bf16 rounding
+    of the two-kernel path (and dV bit-identical), gain gradients to fp32 summation noise."""
+    hd = 128
+    M = B * T
+    nq, nk = nh * hd, nkv * hd
+    x = _rand(M, nq + 2 * nk, seed=50, scale=0.8).to(BF)                    # the pre-norm q | k | v projection rows
+    qw, kw = (1.0 + 0.2 * _rand(hd, seed=51)).to(BF), (1.0 + 0.2 * _rand(hd, seed=52)).to(BF)
+    from molly_amd.qwen3 import rope_tables
+    cos, sin = rope_tables(T, hd, 1e6, DEV)
+    qk = torch.empty(M, nq + nk, dtype=BF, device=DEV)
+    ops.norm_rope_fwd(x, qk, nh, nkv, hd, T, qw, kw, cos, sin, eps=1e-6)
+    q, k, v = qk[:, :nq], qk[:, nq:], x[:, nq + nk:]
+    lo, hi = _ragged_ranges(ragged, B, T)
+    scale = hd ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, B, T, nh, nkv, hd, scale, True, lo, hi)
+    do = _rand(M, nq, seed=53).to(BF)
+    # two kernels
+    d_qk = torch.zeros(M, nq + nk, dtype=BF, device=DEV)
+    dx_ref = torch.zeros(M, nq + 2 * nk, dtype=BF, device=DEV)
+    ops.attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, True, d_qk[:, :nq], d_qk[:, nq:], dx_ref[:, nq + nk:], lo, hi)
+    dqw_ref, dkw_ref = torch.zeros(hd, dtype=torch.float32, device=DEV), torch.zeros(hd, dtype=torch.float32, device=DEV)
+    ops.norm_rope_bwd(x, d_qk, dx_ref, nh, nkv, hd, T, qw, kw, cos, sin, dqw_ref, dkw_ref, eps=1e-6, dw_accumulate=False)
+    # one pass
+    nbq, nbk = ops.attn_bwd_rope_blocks(B, T, nh, nkv)
+    assert (nbq, nbk) == (nh * B * ((T + 127) // 128), nkv * B * ((T + 127) // 128))
+    dx = torch.full((M, nq + 2 * nk), 7.0, dtype=BF, device=DEV)
+    pq = torch.full((nbq, hd), float("nan"), dtype=torch.float32, device=DEV)
+    pk_ = torch.full((nbk, hd), float("nan"), dtype=torch.float32, device=DEV)
+    ops.attn_bwd_rope(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, True, dx[:, nq + nk:], x, qw, kw, cos, sin, 1e-6, dx, pq, pk_, lo, hi)
+    torch.cuda.synchronize()
+    assert torch.equal(dx[:, nq + nk:], dx_ref[:, nq + nk:])                      # dV: the same kernel, the same output
+    assert bool(torch.isfinite(pq).all()) and bool(torch.isfinite(pk_).all())    # every workgroup wrote its row
+    ref = dx_ref[:, :nq + nk].float()
+    err = (dx[:, :nq + nk].float() - ref).abs()
+    assert float(err.max()) <= 2e-2 * float(ref.abs().max()) + 1e-3, (float(err.max()), float(ref.abs().max()))
+    assert float((err > 1e-2 * ref.abs() + 1e-3).float().mean()) < 1e-3         # almost everywhere to the last bf16 bit
+    for got, want, name in ((pq.sum(0), dqw_ref, "d q_norm.weight"), (pk_.sum(0), dkw_ref, "d k_norm.weight")):
+        _close(got, want, 2e-3 * float(want.abs().max()) + 1e-4, 2e-3, name)
+
+
 @pytest.mark.parametrize("nh,nkv,T,ragged", [(32, 8, 1024, False), (16, 8, 2048, True), (8, 2, 1000, True), (32, 8, 3072, False)])
 def test_attn_bwd_split_by_query_head(nh, nkv, T, ragged):
     """One sample per GPU (BASELINE configs 3 / 4, scripts/train/examples/run_train_4B_z2_b1.sh:29): the dK / dV passes run one block
