@@ -535,7 +535,13 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return _self_launch(args, argv)
 
+    # MOLLY_BENCH_WATCHDOG_S: after that many seconds every thread's Python stack goes to stderr and the rank exits — a hung collective in a first
+    # multi-GPU run then leaves a trace instead of a silent timeout (default: 1500 s for the ranks of an N > 1 run, off at N = 1; 0 = off)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    wd = os.environ.get("MOLLY_BENCH_WATCHDOG_S", "1500" if world > 1 else "")     # (ranks of a multi-GPU run: 25 minutes, under the process group's 30)
+    if wd and float(wd) > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(wd), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -668,12 +674,23 @@ def main(argv=None):
             # the part that can fail on one rank only (memory for the layout's receive buffers, an IPC mapping): followed by a collective
             # verdict inside sweep_exchange, so the ranks skip a candidate TOGETHER
             nonlocal opt
+            if os.environ.get("MOLLY_BENCH_VERBOSE"):
+                print(f"[rank {rank}] sweep: building {mib:g} MiB / {algo}", file=sys.stderr, flush=True)
+            # the previous layout's last all-gathers may still be in flight on its communication stream (nobody has run the forward that waits for
+            # them): drain them on every rank, and meet, BEFORE the optimizer that owns them goes away — a new layout's first collectives
+            # issued beside the old one's last ones hung four gloo ranks in reduce_scatter (profiles/r06_logs/four_ranks_hang.log)
+            if opt is not None:
+                opt.wait_all_params()
+            torch.cuda.synchronize()
+            dist.barrier()
             opt = None
             m._rt.opt = None
             torch.cuda.empty_cache()
             opt = make_opt(mib, algo)
 
         def measure(mib, algo):
+            if os.environ.get("MOLLY_BENCH_VERBOSE"):
+                print(f"[rank {rank}] sweep: measuring {mib:g} MiB / {algo}", file=sys.stderr, flush=True)
             step(0)
             dtm, _, _ = timed_steps(args.bucket_ab_steps, 1)
             tm = torch.tensor([dtm], device=dev, dtype=torch.float64)
@@ -688,6 +705,9 @@ def main(argv=None):
         bucket_ab = sweep_exchange([(mib, algo) for algo in algos for mib in sizes], measure, args.bucket_ab_steps, build=build,
                                    agree=dist_agree(dev), budget_s=args.tune_budget_s if args.tune_budget_s > 0 else None, broadcast=bcast)
         ch = bucket_ab["chosen"]
+        opt.wait_all_params()
+        torch.cuda.synchronize()
+        dist.barrier()
         opt = None
         m._rt.opt = None
         torch.cuda.empty_cache()

@@ -215,6 +215,18 @@ def _sweep_worker(rank, world, port, ret, budget):
     dist.destroy_process_group()
 
 
+def test_sweep_at_world_four_runs_every_candidate():
+    """The same sweep at world 4 with no budget and no failing build: every rank builds and measures every candidate in the same order
+    (four ranks' in-place reduce-scatters / all-gathers of freshly built layouts back to back) and chooses the same one."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sweep_worker, args=(4, 29589, ret, None), nprocs=4, join=True)
+    r0 = ret[0][0]
+    for r in range(4):
+        assert ret[r][0]["chosen"] == r0["chosen"] and ret[r][2] == [1, 2, 4, 5] and ret[r][1] == [1, 3, 2, 4, 5]
+    assert "truncated" not in r0 and r0["ms_per_step"]["3/rccl"] is None
+
+
 def test_sweep_over_two_ranks_skips_and_stops_together():
     """The pre-warm-up sweep of bench.py --gpus N rehearsed at world 2 on gloo with real optimizers and collectives: a layout that fails to
     BUILD on rank 1 only is skipped by both ranks (neither measures it: no mismatched collectives), and when the slow rank's clock passes the
