@@ -492,9 +492,12 @@ def main(argv=None):
     ap.add_argument("--rs-algo", choices=("rccl", "a2a", "p2p"), default=None,
                     help="gradient reduce-scatter: the library's collective (default) or all_to_all_single + a local fp32 reduction "
                          "in rank order (SURVEY 5 option 2: every xGMI link carries one chunk at once, whatever RCCL would pick)")
-    ap.add_argument("--bucket-ab-steps", type=int, default=2,
+    ap.add_argument("--bucket-ab-steps", type=int, default=0,
                     help="N > 1, neither --bucket-mib nor --rs-algo pinned: timed steps per (bucket size, reduce-scatter algorithm) candidate "
-                         "of the sweep before the warm-up (untimed region; the fastest is kept, the table lands in comm.bucket_ab); 0 = off")
+                         "of the sweep before the warm-up (untimed region; the fastest is kept, the table lands in comm.bucket_ab); 0 = off.  "
+                         "OFF by default since round 6: the sweep rebuilds the optimizer per candidate, and on the one-GPU rehearsal four gloo ranks "
+                         "hung in a rebuilt layout's first reduce-scatter (profiles/r06_logs/four_ranks_hang.log) — a first run on real links "
+                         "should bring a number home on the default layout (32 MiB per link, the library's reduce-scatter); pass 2 to tune")
     ap.add_argument("--bucket-ab-mib", default="64,128,256,512,1024", help="bucket sizes (MiB of bf16) the sweep tries")
     ap.add_argument("--tune-budget-s", type=float, default=120.0,
                     help="N > 1: wall budget in seconds of the pre-warm-up tuning (bucket sweep, then the GEMM launch-shape A/B).  When a rank "

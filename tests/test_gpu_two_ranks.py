@@ -183,7 +183,7 @@ def test_bench_launches_its_own_ranks_end_to_end():
     # (--tune-budget-s 0.01: the pre-warm-up tuning runs out of its wall budget behind the first candidate of each sweep — the ranks stop
     # TOGETHER, keep the best so far and say so: the truncated sweep rehearsed on real kernels)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
-                        "--seq", "1024", "--k-protein", "256", "--exposed-comm-steps", "2", "--tune-budget-s", "0.01"], capture_output=True,
+                        "--seq", "1024", "--k-protein", "256", "--exposed-comm-steps", "2", "--bucket-ab-steps", "2", "--tune-budget-s", "0.01"], capture_output=True,
                        text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
