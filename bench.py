@@ -876,9 +876,9 @@ def main(argv=None):
         # passes of this same workload (tools/pmc_hbm_traffic.py; corrected as MI355X_MICROARCH.md §HBM prescribes)
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        tj = next((os.path.join(prof_dir, f) for f in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02b_hbm_traffic.json", "r02_hbm_traffic.json", "r01b_hbm_traffic.json")
+        tj = next((os.path.join(prof_dir, f) for f in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02b_hbm_traffic.json", "r02_hbm_traffic.json", "r01b_hbm_traffic.json")
                    if os.path.exists(os.path.join(prof_dir, f))), None)
-        if args.train_mode == "full" and (B, T, K, args.model) == (16, 2048, 512, "1.7b") and args.micro is None and tj and ("r05" in tj or "r04" in tj):
+        if args.train_mode == "full" and (B, T, K, args.model) == (16, 2048, 512, "1.7b") and args.micro is None and tj and any(r in tj for r in ("r06", "r05", "r04")):
             with open(tj) as f:
                 tr = json.load(f)
             traffic, traffic_src = tr["gemm_hbm_bytes_per_launch"], tr["source"]

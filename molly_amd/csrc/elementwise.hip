@@ -383,6 +383,130 @@ __global__ __launch_bounds__(256) void norm_rope_fwd_kernel(RopeArgs p) {
     }
 }
 
+// The training / prefill form of the above (no cache append) for a head_dim known at compile time and M * heads < 2^31.  The same arithmetic, bit
+// for bit (the shared helpers of common.h, the same lanes per head), with a fraction of the index instructions: norm_rope_fwd_kernel runs ~300
+// vector instructions per thread for 16 bytes in and 16 out — a 64-bit division and modulo by the head count, three more divisions by run-time
+// powers of two — and is bound by them (97 us per Qwen3-1.7B layer at 32 k tokens = 4.1 TB/s).  Here: one 32-bit division per item, shifts for the
+// rest, no branches in front of the loads (a dead item's address is clamped, only its store is masked), and TWO heads per thread whose loads are
+// all issued ahead of the arithmetic (32 bytes per thread in flight instead of 16).
+template <int HD>
+__global__ __launch_bounds__(256) void norm_rope_fwd_fast_kernel(RopeArgs p) {
+    constexpr int half = HD / 2, tph = half / 4, HPB = 256 / tph;
+    const int i = (threadIdx.x % tph) * 4, sub = threadIdx.x / tph;
+    const unsigned nh = (unsigned)(p.nq + p.nk), total = (unsigned)p.M * nh;
+    const bool t_pow2 = (p.T & (p.T - 1)) == 0;
+    unsigned m[2], head[2], pos[2];
+    bool live[2];
+    u32x2 a[2], b[2];
+    f32x4 c[2], sn[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const unsigned it = blockIdx.x * (2 * HPB) + k * HPB + sub;
+        live[k] = it < total;
+        const unsigned itc = live[k] ? it : total - 1;
+        m[k] = itc / nh;
+        head[k] = itc - m[k] * nh;
+        pos[k] = p.pos ? (unsigned)p.pos[m[k]] : t_pow2 ? (m[k] & (unsigned)(p.T - 1)) : m[k] % (unsigned)p.T;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const bf16_t* s = p.src + (size_t)m[k] * p.ld_src + head[k] * HD;
+        a[k] = ld_stream<u32x2>(s + i);
+        b[k] = ld_stream<u32x2>(s + i + half);
+    }
+    if (p.cos) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            c[k] = *reinterpret_cast<const f32x4*>(p.cos + (size_t)pos[k] * half + i);
+            sn[k] = *reinterpret_cast<const f32x4*>(p.sin + (size_t)pos[k] * half + i);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float x1[4] = {bflo(a[k][0]), bfhi(a[k][0]), bflo(a[k][1]), bfhi(a[k][1])};
+        float x2[4] = {bflo(b[k][0]), bfhi(b[k][0]), bflo(b[k][1]), bfhi(b[k][1])};
+        const bool isq = head[k] < (unsigned)p.nq;
+        const bf16_t* w = isq ? p.qw : p.kw;
+        if (w) {
+            const float ss = head_lanes_sum(head_sumsq8(x1, x2), tph);
+            head_norm8(x1, x2, rsqrtf(ss / (float)HD + p.eps), w, i, half);
+        }
+        if (isq && p.q_scale != 1.0f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x1[e] = bf2f(f2bf(x1[e] * p.q_scale));
+                x2[e] = bf2f(f2bf(x2[e] * p.q_scale));
+            }
+        }
+        float y1[4], y2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+        if (p.cos) head_rope8(x1, x2, c[k], sn[k], y1, y2);
+        if (live[k]) {
+            bf16_t* d = p.dst + (size_t)m[k] * p.ld_dst + head[k] * HD;
+            st_stream<u32x2>(d + i, u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])});
+            st_stream<u32x2>(d + i + half, u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])});
+        }
+    }
+}
+
+// Many rows (the decoder layer's launch at 16-32 k tokens): one group of hd/8 lanes walks ALL the heads of one token, so the token's cos / sin
+// values are loaded once instead of once per head (per 256 bytes of a head the kernels above read 512 bytes of tables through the same L1 path) and
+// nothing is divided at all; four heads' loads are in flight per thread.  Same arithmetic, bit for bit.  Used when the rows fill the chip.
+template <int HD>
+__global__ __launch_bounds__(256) void norm_rope_fwd_rows_kernel(RopeArgs p) {
+    constexpr int half = HD / 2, tph = half / 4, RPB = 256 / tph, U = 4;
+    const int i = (threadIdx.x % tph) * 4, sub = threadIdx.x / tph;
+    const int nh = p.nq + p.nk;
+    const int m_raw = blockIdx.x * RPB + sub;
+    const bool row_live = m_raw < p.M;
+    const int m = row_live ? m_raw : p.M - 1;
+    f32x4 c = {1.f, 1.f, 1.f, 1.f}, sn = {0.f, 0.f, 0.f, 0.f};
+    if (p.cos) {
+        const unsigned pos = p.pos ? (unsigned)p.pos[m] : (unsigned)m % (unsigned)p.T;
+        c = *reinterpret_cast<const f32x4*>(p.cos + (size_t)pos * half + i);
+        sn = *reinterpret_cast<const f32x4*>(p.sin + (size_t)pos * half + i);
+    }
+    const bf16_t* s = p.src + (size_t)m * p.ld_src;
+    bf16_t* d = p.dst + (size_t)m * p.ld_dst;
+    for (int h0 = 0; h0 < nh; h0 += U) {
+        u32x2 a[U], b[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int head = h0 + k < nh ? h0 + k : nh - 1;
+            a[k] = ld_stream<u32x2>(s + head * HD + i);
+            b[k] = ld_stream<u32x2>(s + head * HD + i + half);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int head = h0 + k < nh ? h0 + k : nh - 1;
+            float x1[4] = {bflo(a[k][0]), bfhi(a[k][0]), bflo(a[k][1]), bfhi(a[k][1])};
+            float x2[4] = {bflo(b[k][0]), bfhi(b[k][0]), bflo(b[k][1]), bfhi(b[k][1])};
+            const bool isq = head < p.nq;
+            const bf16_t* w = isq ? p.qw : p.kw;
+            if (w) {
+                const float ss = head_lanes_sum(head_sumsq8(x1, x2), tph);
+                head_norm8(x1, x2, rsqrtf(ss / (float)HD + p.eps), w, i, half);
+            }
+            if (isq && p.q_scale != 1.0f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x1[e] = bf2f(f2bf(x1[e] * p.q_scale));
+                    x2[e] = bf2f(f2bf(x2[e] * p.q_scale));
+                }
+            }
+            float y1[4], y2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { y1[e] = x1[e]; y2[e] = x2[e]; }
+            if (p.cos) head_rope8(x1, x2, c, sn, y1, y2);
+            if (row_live && h0 + k < nh) {
+                st_stream<u32x2>(d + head * HD + i, u32x2{pack_bf2(y1[0], y1[1]), pack_bf2(y1[2], y1[3])});
+                st_stream<u32x2>(d + head * HD + i + half, u32x2{pack_bf2(y2[0], y2[1]), pack_bf2(y2[2], y2[3])});
+            }
+        }
+    }
+}
+
 // backward of the above (Qwen3 form: norm + rotary; q_scale==1).  g = d(dst) [M, ld_dst];
 // writes d(src) for the q/k heads [M, ld_out] and per-block fp32 partials of d(q_norm.w), d(k_norm.w):
 // dw_part[blk][2][hd]
@@ -1327,6 +1451,23 @@ extern "C" int molly_norm_rope_fwd(void* stream, const void* src, void* dst, con
                M, T, n_q_heads, n_k_heads, head_dim, ld_src, ld_dst, eps, q_scale, nullptr, nullptr, nullptr, 0, 0};
     const long items = (long)M * (n_q_heads + n_k_heads);
     const int hpb = 256 / (head_dim / 8);
+    static const bool fast = [] { const char* e = getenv("MOLLY_ROPE_FWD_FAST"); return !e || atoi(e) != 0; }();
+    if (fast && items > 0 && items < (1L << 31) && T > 0 && (head_dim == 128 || head_dim == 64)) {      // (norm_rope_fwd_fast_kernel / _rows_kernel)
+        static const int rows_min = [] { const char* e = getenv("MOLLY_ROPE_FWD_ROWS_MIN"); return e ? atoi(e) : 1024; }();   // workgroups of the rows form
+        const int rpb = hpb;                                 // token rows per workgroup: one group of hd/8 lanes each
+        if ((M + rpb - 1) / rpb >= rows_min) {
+            const unsigned nbr = (unsigned)((M + rpb - 1) / rpb);
+            if (head_dim == 128) hipLaunchKernelGGL(norm_rope_fwd_rows_kernel<128>, dim3(nbr), dim3(256), 0, ST, p);
+            else hipLaunchKernelGGL(norm_rope_fwd_rows_kernel<64>, dim3(nbr), dim3(256), 0, ST, p);
+            MOLLY_LAUNCH_CHECK();
+            return 0;
+        }
+        const unsigned nb = (unsigned)((items + 2 * hpb - 1) / (2 * hpb));
+        if (head_dim == 128) hipLaunchKernelGGL(norm_rope_fwd_fast_kernel<128>, dim3(nb), dim3(256), 0, ST, p);
+        else hipLaunchKernelGGL(norm_rope_fwd_fast_kernel<64>, dim3(nb), dim3(256), 0, ST, p);
+        MOLLY_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(norm_rope_fwd_kernel, dim3((unsigned)((items + hpb - 1) / hpb)), dim3(256), 0, ST, p);
     MOLLY_LAUNCH_CHECK();
     return 0;

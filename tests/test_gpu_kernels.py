@@ -986,6 +986,39 @@ def test_norm_rope_with_cache_append_equals_the_three_launches():
     assert kc1.abs().sum().item() > 0 and vc1.abs().sum().item() > 0
 
 
+@pytest.mark.parametrize("M,T,nh,nkv,hd,norm,with_pos", [(1000, 96, 5, 2, 128, True, False), (777, 64, 4, 4, 64, False, False),
+                                                        (333, 1, 16, 8, 128, True, True), (37, 50, 3, 1, 128, True, False),
+                                                        # >= 1,024 workgroups of token rows: norm_rope_fwd_rows_kernel (one lane group per token)
+                                                        (16400, 96, 3, 2, 128, True, False), (32790, 64, 2, 1, 64, False, False),
+                                                        (16390, 1, 4, 2, 128, True, True)])
+def test_norm_rope_fast_kernel_is_bit_identical_to_the_general_one(M, T, nh, nkv, hd, norm, with_pos):
+    """molly_norm_rope_fwd's compile-time-head_dim kernels (two heads per thread with 32-bit index arithmetic; one lane group per token row when
+    the rows fill the chip: the training / prefill launch) against
+    norm_rope_fwd_kernel, reached through the cache-append entry point: the same bits in every q | k row, on item counts that leave the last
+    workgroup partly dead, with a position table, with T not a power of two, with and without the norm (ESM: q scaled, no norm)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    nq, nkvd = nh * hd, nkv * hd
+    qkv = ((torch.rand(M, nq + 2 * nkvd, device="cuda", generator=g) * 2 - 1)).to(BF)
+    qn = (torch.rand(hd, device="cuda", generator=g) + 0.5).to(BF) if norm else None
+    kn = (torch.rand(hd, device="cuda", generator=g) + 0.5).to(BF) if norm else None
+    npos = 128
+    cos = torch.rand(npos, hd // 2, device="cuda", generator=g)
+    sin = torch.rand(npos, hd // 2, device="cuda", generator=g)
+    pos = torch.randint(0, npos, (M,), device="cuda", generator=g).int() if with_pos else None
+    q_scale = 1.0 if norm else hd ** -0.5
+    guard = 7.0
+    qk0 = torch.full((M + 1, nq + nkvd), guard, dtype=BF, device="cuda")
+    ops.norm_rope_fwd(qkv, qk0[:M], nh, nkv, hd, T, qn, kn, cos, sin, positions=pos, q_scale=q_scale)
+    qk1 = torch.empty(M, nq + nkvd, dtype=BF, device="cuda")
+    kc = torch.zeros(M, nkvd, dtype=BF, device="cuda"); vc = torch.zeros_like(kc)
+    slot = torch.arange(M, dtype=torch.int32, device="cuda")
+    ops.norm_rope_fwd(qkv, qk1, nh, nkv, hd, T, qn, kn, cos, sin, positions=pos, q_scale=q_scale, kcache=kc, vcache=vc, slot=slot)
+    torch.cuda.synchronize()
+    assert torch.equal(qk0[:M], qk1)
+    assert bool((qk0[M] == guard).all())                      # nothing written past the last item
+    assert torch.equal(kc, qk1[:, nq:])
+
+
 def test_gemm_decode_rows_qkv_tail_equals_the_separate_launches():
     """Decode step: fused q | k | v projection -> q/k-norm -> rotary -> KV-cache append as GEMM + ONE tail launch
     (molly_gemm_rows_qkv_bf16_ctx; HF:models/qwen3/modeling_qwen3.py:225-236) — bit-identical q | k rows and cache rows to
