@@ -56,11 +56,11 @@ template <int HD> __device__ __forceinline__ int img_off(int row, int col) {    
 
 // stage a [64 rows][HD] tile with global_load_lds; LDS image is lane-linear, so each lane decodes which (row, col chunk)
 // its 16-byte destination slot holds and fetches that from global memory.
-template <int HD, bool IS_V>
+template <int HD, bool IS_V, int ROWS = BKV>
 __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, int key0, int T, bf16_t* lds, int wave,
                                          int lane) {
     constexpr int NCB = HD / 16;
-    constexpr int NINST = BKV * HD * 2 / 1024;   // 1 KiB per wave-instruction
+    constexpr int NINST = ROWS * HD * 2 / 1024;  // 1 KiB per wave-instruction
     const char* base = reinterpret_cast<const char*>(g + (size_t)key0 * ld);
 #pragma unroll
     for (int i = 0; i < NINST / 4; ++i) {
@@ -113,9 +113,9 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ g, int ld, i
 //   piece i of wave w = instruction w * NP + i:  row = row0 + RSTEP * i,  col = col0 ^ cx(i)      (row0 / col0: stage_lane_const)
 // so a piece costs one XOR, one three-operand add with a scalar, the m0 move and the load.
 template <int HD> struct StageConst { unsigned rowb, colb; };          // per lane: row0 * ld * 2 bytes, col0 * 2 bytes
-template <int HD>
+template <int HD, int ROWS = BKV>
 __device__ __forceinline__ void stage_lane_const(int ld, int wave, int lane, unsigned& rowb, unsigned& colb) {
-    constexpr int NCB = HD / 16, NP = BKV * HD * 2 / 1024 / 4;
+    constexpr int NCB = HD / 16, NP = ROWS * HD * 2 / 1024 / 4;
     const int P = wave * NP * 64 + lane;                  // piece 0 of this wave
     const int blk = P >> 3, cin = P & 7;
     const int rowblk = blk / NCB, cbs = blk % NCB;
@@ -124,9 +124,10 @@ __device__ __forceinline__ void stage_lane_const(int ld, int wave, int lane, uns
     colb = (unsigned)((((cbs ^ b0) << 4) + (((cin & 1) ^ b1) << 3)) * 2);
 }
 // base = tile row 0 of the (batch, head) slice (wave-uniform), lds_addr = LDS byte address of the tile image (wave-uniform, 32 bit)
-template <int HD>
+template <int HD, int ROWS = BKV>
 __device__ __forceinline__ void stage_tile_fast(const char* base, int ld, unsigned rowb, unsigned colb, unsigned lds_addr, int wave) {
-    constexpr int NP = BKV * HD * 2 / 1024 / 4;           // pieces per wave: 4 (hd 128) / 2 (hd 64)
+    static_assert(ROWS == BKV || (ROWS == 32 && HD == 128), "a 32-row tile: hd 128 only (rowblk = 2 w + i: b1 = w & 1 is in colb, b0 = i & 1)");
+    constexpr int NP = ROWS * HD * 2 / 1024 / 4;          // pieces per wave: 4 (hd 128) / 2 (hd 64; hd 128 at 32 rows)
     constexpr int RSTEP = HD == 128 ? 4 : 8;              // tile rows between two pieces of a wave
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -1079,6 +1080,181 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
     }
 }
 
+// dK AND dV in one pass at two waves per SIMD (7 executed matmuls per attention backward instead of 8, the exponentials of a
+// block once instead of twice).  What made the one-pass form need a whole SIMD's registers (MODE 0: K and V fragments 64 + dK and dV accumulators
+// 128 + two 32-query blocks in flight) is cut three ways: V is NOT held in registers — the workgroup's 128 V rows sit in LDS beside the stages and are
+// read as row fragments per use (+8 KB of LDS reads per block: 40 KB per 32 MFMAs, the LDS-bandwidth cap moves from 1.0 to 0.8 of the matrix pipe's
+// time; the two-pass kernels run at 0.45); the stages hold 32 query rows instead of 64 (2 x 16 KB + V 32 KB = 64 KB: two workgroups per CU still
+// fit, which the 64-row stages + V would not), so one block is in flight per wave; the row statistics are read per 4-row group.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs p) {
+    static_assert(HD == 128, "built for head dim 128");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int QR = 32;                                       // query rows per stage
+    constexpr int TILE = QR * HD;                                // elements of one 32-row image
+    constexpr int NS = HD / 16, ND = HD / 32;
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);          // [2 stages][Q 32 rows | dO 32 rows]
+    bf16_t* sV = smem + 2 * 2 * TILE;                            // [2 images of 64 keys][HD]
+    float* sStat = reinterpret_cast<float*>(smem_raw + (2 * 2 * TILE + 2 * BKV * HD) * sizeof(bf16_t));   // [2 stages][lse 64 | delta 64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    wave_priority(p.prio);
+    const int group = p.nh / p.nkv;
+    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, 1, p.nblk, p.order_set);
+    const int kb = bi.blk, kvh = bi.kvh, b = bi.b;
+    const int T = p.T;
+    const int lo = p.kv_lo ? p.kv_lo[b] : 0;
+    const int hi = p.kv_hi ? p.kv_hi[b] : T;
+    const int key0 = kb * 128 + wave * 32;
+    const int key = key0 + r;
+    const int krow = key < T ? key : T - 1;
+    const bool key_ok = key >= lo && key < hi;
+
+    // the workgroup's V rows -> LDS (two 64-row images); this wave's K rows -> registers
+    {
+        const bf16_t* Vb = p.V + (size_t)b * T * p.ldv + kvh * HD;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k0 = kb * 128 + 64 * j;
+            stage_kv<HD, false>(Vb, p.ldv, k0 < T ? k0 : T - 1, T, sV + j * BKV * HD, wave, lane);
+        }
+    }
+    bf16x8 kf[NS];
+    {
+        const bf16_t* kp = p.K + ((size_t)b * T + krow) * p.ldk + kvh * HD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kp + 16 * s);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) arrived(kf[s]);
+    }
+    const bf16_t* sVw = sV + (wave >> 1) * BKV * HD;             // the image holding this wave's keys
+    const int vrow = 32 * (wave & 1) + r;
+    f32x16 dk[ND], dv[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+
+    // 32-row query tiles this block needs: causal -> tiles whose last row >= first key of the block
+    const int nqt = (T + QR - 1) / QR;
+    const int qt_first = p.causal ? (kb * 128) / QR : 0;
+    const int n_tiles = nqt > qt_first ? nqt - qt_first : 0;
+    const int total = n_tiles * group;
+
+    unsigned rbQ, rbD, cbQ, cbD;
+    stage_lane_const<HD, QR>(p.ldq, wave, lane, rbQ, cbQ);
+    stage_lane_const<HD, QR>(p.ldo, wave, lane, rbD, cbD);
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(smem));
+    int sg = 0, sj = 0;                                          // (g, j) of the NEXT tile to stage
+    int cj = 0;                                                  // j of the tile being computed
+    auto stage = [&](int stg) {
+        const int g = sg, qt = qt_first + sj;
+        if (++sj == n_tiles) { sj = 0; ++sg; }
+        const int head = kvh * group + g;
+        const bf16_t* Qb = p.Q + (size_t)b * T * p.ldq + head * HD;
+        const bf16_t* Db = p.dO + (size_t)b * T * p.ldo + head * HD;
+        bf16_t* sQ = smem + stg * 2 * TILE;
+        if (qt * QR + QR <= T) {
+            stage_tile_fast<HD, QR>(reinterpret_cast<const char*>(Qb + (size_t)qt * QR * p.ldq), p.ldq, rbQ, cbQ, smem_lds + stg * 2 * TILE * 2, wave);
+            stage_tile_fast<HD, QR>(reinterpret_cast<const char*>(Db + (size_t)qt * QR * p.ldo), p.ldo, rbD, cbD, smem_lds + (stg * 2 + 1) * TILE * 2, wave);
+        } else {
+            stage_kv<HD, false, QR>(Qb, p.ldq, qt * QR, T, sQ, wave, lane);
+            stage_kv<HD, false, QR>(Db, p.ldo, qt * QR, T, sQ + TILE, wave, lane);
+        }
+        if (wave < 2) {                                          // row statistics by LDS-DMA as well (the note in attn_bwd_dkv_kernel); lanes 32.. fetch rows nobody reads
+            int q = qt * QR + lane;
+            q = q < T ? q : T - 1;
+            const size_t idx = ((size_t)b * p.nh + head) * T + q;
+            const float* src = wave == 0 ? p.LSE + idx : p.delta + idx;
+            const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(sStat + stg * 128 + wave * 64));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+        }
+    };
+    if (total > 0) stage(0);
+    dma_wait();
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < total; ++it) {
+        if (it + 1 < total) stage(cur ^ 1);
+        const int qsub = (qt_first + cj) * QR;
+        if (++cj == n_tiles) cj = 0;
+        const bf16_t* sQ = smem + cur * 2 * TILE;
+        const bf16_t* sD = sQ + TILE;
+        const float* sL = sStat + cur * 128;
+        if (!(p.causal && qsub + 31 < key0)) {                    // (else: these 32 queries all precede this wave's keys — wave-uniform)
+            f32x16 sA, dpA;                                       // [q rows (regs), key cols (lane)]
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sA[e] = 0.f; dpA[e] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, r, s, h), kf[s], sA, 0, 0, 0);
+                dpA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sD, r, s, h), row_frag<HD>(sVw, vrow, s, h), dpA, 0, 0, 0);
+            }
+            const bool need_mask = (p.causal && qsub < key0 + 31) || key0 < lo || key0 + 32 > hi || qsub + 32 > T;
+            f32x16 pA;
+            if (need_mask) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g4 + j;
+                        const int q = qsub + j + 8 * g4 + 4 * h;
+                        const bool ok = key_ok && q < T && (!p.causal || key <= q);
+                        const float pr = ok ? fast_exp2(sA[e] * p.scale_log2 - l4[j]) : 0.f;
+                        pA[e] = pr;
+                        sA[e] = pr * (dpA[e] - d4[j]);           // dS (unscaled)
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g4 + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g4 + j;
+                        const float pr = fast_exp2(sA[e] * p.scale_log2 - l4[j]);
+                        pA[e] = pr;
+                        sA[e] = pr * (dpA[e] - d4[j]);
+                    }
+                }
+            }
+            {
+                const bf16x8 p0 = acc_to_frag(pA, 0), p1 = acc_to_frag(pA, 8);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 0, 0, d, lane), p0, dv[d], 0, 0, 0);
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sD, 0, 1, d, lane), p1, dv[d], 0, 0, 0);
+                }
+            }
+            {
+                const bf16x8 d0 = acc_to_frag(sA, 0), d1 = acc_to_frag(sA, 8);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 0, 0, d, lane), d0, dk[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 0, 1, d, lane), d1, dk[d], 0, 0, 0);
+                }
+            }
+        }
+        dma_wait();
+        __syncthreads();
+        cur ^= 1;
+    }
+    bf16_t* slab = reinterpret_cast<bf16_t*>(smem_raw) + wave * 32 * (HD + 8);
+    const int key0w = key - (lane & 31);                                           // the wave's first key
+    store_rows<HD, ND>(slab, dv, 1.0f, p.dV + ((size_t)b * T + key0w) * p.lddv + kvh * HD, p.lddv, T - key0w, lane);
+    if (p.fk.X) {
+        float dw[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        store_rows_rope_bwd<HD, ND>(slab, dk, p.scale, p.fk, (size_t)b * T + key0w, key0w, kvh * HD, T - key0w, lane, dw);
+        rope_bwd_dw_flush<HD>(dw, reinterpret_cast<float*>(smem_raw), p.fk.dw_part + (size_t)blockIdx.x * HD, wave, lane, tid);
+    } else {
+        store_rows<HD, ND>(slab, dk, p.scale, p.dK + ((size_t)b * T + key0w) * p.lddk + kvh * HD, p.lddk, T - key0w, lane);
+    }
+}
+
 // the head-split pass's second half: one WAVE per (batch, kv head, key block, 32 keys, dK | dV) — 100 MB of images at one sample
 // per GPU want thousands of waves with loads in flight, not 192 workgroups (41 -> ~20 us at B = 1, T = 3072) — adds the group's
 // images in head order, then the same row store as the unsplit kernel (dK scaled, dV not)
@@ -1121,6 +1297,10 @@ __global__ __launch_bounds__(64) void attn_dkv_reduce_kernel(AttnBwdArgs p) {
 static int wave_prio() {          // MOLLY_ATTN_PRIO: see wave_priority()
     static const int v = [] { const char* e = getenv("MOLLY_ATTN_PRIO"); return e ? atoi(e) : 0; }();
     return v;
+}
+static bool dkv_fused() {          // dK and dV in one pass (attn_bwd_dkv_fused_kernel) where the passes are not split by query head; MOLLY_ATTN_DKV_FUSED=0: the
+    const char* e = getenv("MOLLY_ATTN_DKV_FUSED");          // two single-output passes (read per call: the A/B test switches it inside one process)
+    return !e || atoi(e) != 0;
 }
 static int order_set(int dkv, int npairs) {
     static const int v[2] = {[] { const char* e = getenv("MOLLY_ATTN_ORDER_SET"); return e ? atoi(e) : -1; }(),
@@ -1234,6 +1414,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
                   lddq, lddk, lddv, scale, scale * LOG2E, causal, nullptr, cdiv(T, BQ), order_set(0, B * n_kv_heads), wave_prio()};
     const size_t lds_dq = 2 * 2 * BKV * head_dim * sizeof(bf16_t);
     const size_t lds_dkv = lds_dq + 2 * 128 * sizeof(float);
+    const size_t lds_fused = (2 * 2 * 32 * 128 + 2 * BKV * 128) * sizeof(bf16_t) + 2 * 128 * sizeof(float);   // attn_bwd_dkv_fused_kernel<128>
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1243,6 +1424,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
         attr_set = true;
     }
     const dim3 gq(n_heads * B * cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));   // dQ pass 1-D; gk: the reduce kernel's 2-D shape
@@ -1257,8 +1439,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
     AttnBwdArgs pk = p;                                                             // their block order
     pk.nblk = cdiv(T, 128);
     pk.order_set = order_set(1, B * n_kv_heads);
-    // head dim 128: dV and dK as two passes at two waves per SIMD (one pass holding both needs 256 accumulator registers = one wave per SIMD and
-    // measured equal at best: LOG.md rounds 1, 4); head dim 64 (the encoders): one pass
+    // head dim 128: dK and dV in ONE pass at two waves per SIMD (attn_bwd_dkv_fused_kernel: V read from LDS, 32-row stages; round 6: 1,289 -> 1,087 us
+    // per backward at B 16) unless the passes are split by query head (one sample per GPU: two passes + reduce); head dim 64 (the encoders): one pass
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), lds_dq, st, p);
         const long need = molly_attn_bwd_workspace(B, T, n_heads, n_kv_heads, head_dim);
@@ -1268,6 +1450,8 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, pk);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, pk);
             hipLaunchKernelGGL(attn_dkv_reduce_kernel<128>, dim3(gk.x * 4, gk.y, 2), dim3(64), 0, st, p);
+        } else if (dkv_fused()) {
+            hipLaunchKernelGGL(attn_bwd_dkv_fused_kernel<128>, gk1, dim3(256), lds_fused, st, pk);
         } else {
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1>), gk1, dim3(256), lds_dkv, st, pk);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2>), gk1, dim3(256), lds_dkv, st, pk);

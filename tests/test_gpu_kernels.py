@@ -404,6 +404,21 @@ def test_attn_bwd(hd, nh, nkv, T, causal, ragged):
     _attn_bwd_check(got, ref, live, nh, hd)
 
 
+@pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [c for c in ATTN_BWD_CASES if c[0] == 128] + [(128, 6, 2, 333, False, True), (128, 4, 4, 97, True, False)])
+def test_attn_bwd_one_pass_dk_dv_is_bit_identical_to_the_two_passes(hd, nh, nkv, T, causal, ragged, monkeypatch):
+    """attn_bwd_dkv_fused_kernel (dK and dV in one pass: V fragments from LDS, 32-row stages; the default at head dim 128) against the two
+    single-output passes it replaces (MOLLY_ATTN_DKV_FUSED=0): the same MFMAs on the same operands in the same order, so dK and dV agree bit
+    for bit — on every head-dim-128 case of the closed-form test plus a bidirectional ragged one and a length below one key block."""
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MOLLY_ATTN_DKV_FUSED", fused)
+        got, _, _ = _attn_bwd_run(hd, nh, nkv, T, causal, ragged)
+        torch.cuda.synchronize()
+        outs.append([g.clone() for g in got])
+    for a, b, name in zip(outs[0], outs[1], ("dQ", "dK", "dV")):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("hd,nh,nkv,T,causal,ragged", [(128, 4, 2, 200, True, True), (128, 16, 8, 2048, True, "right")])
 @pytest.mark.parametrize("what", ["dK", "dV"])
 def test_attn_bwd_check_notices_one_zeroed_key_tile(hd, nh, nkv, T, causal, ragged, what):
