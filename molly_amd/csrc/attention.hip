@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
 // read as row fragments per use (+8 KB of LDS reads per block: 40 KB per 32 MFMAs, the LDS-bandwidth cap moves from 1.0 to 0.8 of the matrix pipe's
 // time; the two-pass kernels run at 0.45); the stages hold 32 query rows instead of 64 (2 x 16 KB + V 32 KB = 64 KB: two workgroups per CU still
 // fit, which the 64-row stages + V would not), so one block is in flight per wave; the row statistics are read per 4-row group.
-template <int HD>
+// SPLIT (one sample per GPU): one block per QUERY head, both accumulator images left in `part` for attn_dkv_reduce_kernel (see attn_bwd_dkv_kernel).
+template <int HD, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs p) {
     static_assert(HD == 128, "built for head dim 128");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1101,8 +1102,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs 
     const int r = lane & 31, h = lane >> 5;
     wave_priority(p.prio);
     const int group = p.nh / p.nkv;
-    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, 1, p.nblk, p.order_set);
-    const int kb = bi.blk, kvh = bi.kvh, b = bi.b;
+    const BlockItem bi = block_item(blockIdx.x, gridDim.x, p.nkv, SPLIT ? group : 1, p.nblk, p.order_set);
+    const int kb = bi.blk, kvh = bi.kvh, b = bi.b, g0 = bi.g;
     const int T = p.T;
     const int lo = p.kv_lo ? p.kv_lo[b] : 0;
     const int hi = p.kv_hi ? p.kv_hi[b] : T;
@@ -1140,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs 
     const int nqt = (T + QR - 1) / QR;
     const int qt_first = p.causal ? (kb * 128) / QR : 0;
     const int n_tiles = nqt > qt_first ? nqt - qt_first : 0;
-    const int total = n_tiles * group;
+    const int total = SPLIT ? n_tiles : n_tiles * group;
 
     unsigned rbQ, rbD, cbQ, cbD;
     stage_lane_const<HD, QR>(p.ldq, wave, lane, rbQ, cbQ);
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs 
     int sg = 0, sj = 0;                                          // (g, j) of the NEXT tile to stage
     int cj = 0;                                                  // j of the tile being computed
     auto stage = [&](int stg) {
-        const int g = sg, qt = qt_first + sj;
+        const int g = SPLIT ? g0 : sg, qt = qt_first + sj;
         if (++sj == n_tiles) { sj = 0; ++sg; }
         const int head = kvh * group + g;
         const bf16_t* Qb = p.Q + (size_t)b * T * p.ldq + head * HD;
@@ -1242,6 +1243,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs 
         dma_wait();
         __syncthreads();
         cur ^= 1;
+    }
+    if constexpr (SPLIT) {
+        // image [(b, kvh, kb)][g][wave][d][g4][lane] f32x4; dV images in the first half of `part`, dK images in the second (attn_dkv_reduce_kernel)
+        const size_t nimg = (size_t)gridDim.x;
+        const size_t img = ((size_t)(b * p.nkv + kvh) * p.nblk + kb) * group + g0;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float* dst = p.part + (img + (which ? nimg : 0)) * (4 * ND * 16 * 64) + (size_t)wave * (ND * 16 * 64) + lane * 4;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x16& a = which ? dk[d] : dv[d];
+                    *reinterpret_cast<f32x4*>(dst + (d * 4 + g4) * 256) = f32x4{a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]};
+                }
+        }
+        return;
     }
     bf16_t* slab = reinterpret_cast<bf16_t*>(smem_raw) + wave * 32 * (HD + 8);
     const int key0w = key - (lane & 31);                                           // the wave's first key
@@ -1425,6 +1443,7 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_fused_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
         attr_set = true;
     }
     const dim3 gq(n_heads * B * cdiv(T, BQ)), gk(n_kv_heads * B, cdiv(T, 128));   // dQ pass 1-D; gk: the reduce kernel's 2-D shape
@@ -1447,8 +1466,12 @@ static int attn_bwd_impl(void* stream, const void* Q, const void* K, const void*
         if (need > 0 && workspace && workspace_floats >= need) {
             p.part = pk.part = workspace;
             const dim3 gs(n_heads * B * cdiv(T, 128));
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, pk);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, pk);
+            if (dkv_fused()) {
+                hipLaunchKernelGGL((attn_bwd_dkv_fused_kernel<128, true>), gs, dim3(256), lds_fused, st, pk);
+            } else {
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 1, true>), gs, dim3(256), lds_dkv, st, pk);
+                hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 2, true>), gs, dim3(256), lds_dkv, st, pk);
+            }
             hipLaunchKernelGGL(attn_dkv_reduce_kernel<128>, dim3(gk.x * 4, gk.y, 2), dim3(64), 0, st, p);
         } else if (dkv_fused()) {
             hipLaunchKernelGGL(attn_bwd_dkv_fused_kernel<128>, gk1, dim3(256), lds_fused, st, pk);

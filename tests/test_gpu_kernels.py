@@ -478,7 +478,7 @@ def test_attn_bwd_with_the_rotary_and_qk_norm_backward_in_its_row_epilogues(nh, 
 
 
 @pytest.mark.parametrize("nh,nkv,T,ragged", [(32, 8, 1024, False), (16, 8, 2048, True), (8, 2, 1000, True), (32, 8, 3072, False)])
-def test_attn_bwd_split_by_query_head(nh, nkv, T, ragged):
+def test_attn_bwd_split_by_query_head(nh, nkv, T, ragged, monkeypatch):
     """One sample per GPU (BASELINE configs 3 / 4, scripts/train/examples/run_train_4B_z2_b1.sh:29): the dK / dV passes run one block
     per QUERY head and a third launch adds the group's fp32 images in head order.  Against the unsplit passes (same products, another
     order of the fp32 sums over heads: equal to bf16 rounding of near-ties), against the fp32 reference, and twice (bitwise equal)."""
@@ -515,6 +515,13 @@ def test_attn_bwd_split_by_query_head(nh, nkv, T, ragged):
         _close(o_[:, :nh * hd], rq, 3e-2, 2e-2, f"dQ ({name})")
         _close(o_[:, nh * hd:(nh + nkv) * hd], rk, 4e-2, 2e-2, f"dK ({name})")
         _close(o_[:, (nh + nkv) * hd:], rv, 4e-2, 2e-2, f"dV ({name})")
+    # the split form's images come from ONE pass (attn_bwd_dkv_fused_kernel<128, true>) by default: the same bits as the two single-output passes
+    monkeypatch.setenv("MOLLY_ATTN_DKV_FUSED", "0")
+    dqkv = torch.zeros_like(qkv)
+    ops.attn_bwd(q, k, v, o, do, lse, B, T, nh, nkv, hd, scale, True, dqkv[:, :nh * hd], dqkv[:, nh * hd:(nh + nkv) * hd], dqkv[:, (nh + nkv) * hd:],
+                 lo, hi, ws=torch.empty(n_ws, dtype=torch.float32, device=DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(dqkv, outs[1])
 
 
 def test_ce_fwd_bwd_matches_torch():
