@@ -21,7 +21,7 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -- python3 $R/bench.py --steps 1 --warmup 1 $B > $O/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -- python3 $R/bench.py --steps 1 --warmup 1 $B > $O/pmc_w.log 2>&1
 cd $R
-python tools/pmc_sq_summary.py r06 "round 6: streaming + whole-line GEMM epilogues, rotary backward inside the attention backward" /tmp/p_sq_a /tmp/p_sq_b | head -30
+python tools/pmc_sq_summary.py r06 "round 6 final: streaming + whole-line GEMM epilogues, rotary backward inside the attention backward, dK + dV in one pass" /tmp/p_sq_a /tmp/p_sq_b | head -30
 python tools/pmc_hbm_traffic.py /tmp/p_f /tmp/p_w r06 "python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary   (MI355X, B=16 T=2048 K=512; 2 steps incl. warmup)" | head -40
 cp profiles/r06_* $O/ 2>/dev/null
 ls -la $O | head -40
