@@ -732,7 +732,7 @@ __device__ __forceinline__ void rope_bwd_dw_flush(float (&dw)[8], float* red /* 
 
 struct AttnBwdArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* V; const bf16_t* dO; const bf16_t* O;
-    const float* LSE; float* delta;            // delta[b, head, q] = sum_d dO[q,d] * O[q,d]: written by the dQ kernel, read by dK's
+    const float* LSE; float* delta;            // delta[b, head, q] = MINUS sum_d dO[q,d] * O[q,d]: written by the dQ kernel, read by dK's as the dP chain's initial value
     bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     const int* kv_lo; const int* kv_hi;
     int T, nh, nkv, ldq, ldk, ldv, ldo, lddq, lddk, lddv;
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     }
     float lse = p.LSE[((size_t)b * p.nh + head) * T + qrow];
     lse = (lse == -INFINITY) ? 0.f : lse;
-    if (h == 0 && qi < T) p.delta[((size_t)b * p.nh + head) * T + qi] = dlt;       // for the dK pass
+    if (h == 0 && qi < T) p.delta[((size_t)b * p.nh + head) * T + qi] = -dlt;      // for the dK pass: NEGATED — it is the initial value of the dP accumulators there
 #pragma unroll
     for (int s = 0; s < NS; ++s) { arrived(qf[s]); arrived(dof[s]); }
     arrived(lse); arrived(dlt);
@@ -835,9 +835,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
             for (int sub = 0; sub < 2; ++sub) {
                 const int kbase = k0 + 32 * sub;
                 if (p.causal && kbase > q0 + 31) continue;           // half entirely above the diagonal (wave-uniform)
+                // -delta as the initial value of the dP accumulators (guide, 'Attention backward': row constants as the initial accumulator): dP - delta
+                // leaves the MFMA chain ready, sixteen subtractions per block gone
                 f32x16 sT, dpT;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { sT[e] = 0.f; dpT[e] = 0.f; }
+                for (int e = 0; e < 16; ++e) { sT[e] = 0.f; dpT[e] = -dlt; }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, 32 * sub + r, s, h), qf[s], sT, 0, 0, 0);
@@ -852,11 +854,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
                         const int key = kbase + (e & 3) + 8 * (e >> 2) + 4 * h;
                         const bool ok = key >= lo && key < hi && (!p.causal || key <= qi);
                         const float pr = ok ? fast_exp2(sT[e] * p.scale_log2 - lse) : 0.f;
-                        sT[e] = pr * (dpT[e] - dlt);                // dS^T (unscaled)
+                        sT[e] = pr * dpT[e];                        // dS^T (unscaled)
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) sT[e] = fast_exp2(sT[e] * p.scale_log2 - lse) * (dpT[e] - dlt);
+                    for (int e = 0; e < 16; ++e) sT[e] = fast_exp2(sT[e] * p.scale_log2 - lse) * dpT[e];
                 }
                 const bf16x8 f0 = acc_to_frag(sT, 0), f1 = acc_to_frag(sT, 8);
 #pragma unroll
@@ -995,6 +997,13 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
                 f32x16 sA, dpA;                                   // [q rows (regs), key cols (lane)]
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { sA[e] = 0.f; dpA[e] = 0.f; }
+                if (DO_DK) {                                      // -delta (the dQ kernel stores it negated) of the 4 rows each accumulator group holds: the dP
+#pragma unroll                                                    // chain's initial value, read straight into its registers
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 nd = *reinterpret_cast<const f32x4*>(sL + 64 + 32 * sub + 8 * g4 + 4 * h);
+                        dpA[4 * g4] = nd[0]; dpA[4 * g4 + 1] = nd[1]; dpA[4 * g4 + 2] = nd[2]; dpA[4 * g4 + 3] = nd[3];
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, 32 * sub + r, s, h), kf[s], sA, 0, 0, 0);
@@ -1002,12 +1011,9 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
                         dpA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sD, 32 * sub + r, s, h), vf[s], dpA, 0, 0, 0);
                 }
                 // row statistics of the 4 consecutive query rows each accumulator group holds: one 16-byte LDS read each
-                f32x4 lse4[4], dl4[4];
+                f32x4 lse4[4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    lse4[g4] = *reinterpret_cast<const f32x4*>(sL + 32 * sub + 8 * g4 + 4 * h);
-                    if (DO_DK) dl4[g4] = *reinterpret_cast<const f32x4*>(sL + 64 + 32 * sub + 8 * g4 + 4 * h);
-                }
+                for (int g4 = 0; g4 < 4; ++g4) lse4[g4] = *reinterpret_cast<const f32x4*>(sL + 32 * sub + 8 * g4 + 4 * h);
                 f32x16 pA;
                 // masks only where the 32 x 32 block touches the causal diagonal, the [lo, hi) key edges or the end of the
                 // sequence (wave-uniform test); interior blocks run the bare fma / exp2 / sub / mul
@@ -1019,14 +1025,14 @@ __global__ __launch_bounds__(256, MODE == 0 ? 1 : 2) void attn_bwd_dkv_kernel(At
                         const bool ok = key_ok && q < T && (!p.causal || key <= q);
                         const float pr = ok ? fast_exp2(sA[e] * p.scale_log2 - lse4[e >> 2][e & 3]) : 0.f;
                         pA[e] = pr;
-                        if (DO_DK) sA[e] = pr * (dpA[e] - dl4[e >> 2][e & 3]);  // dS (unscaled)
+                        if (DO_DK) sA[e] = pr * dpA[e];                         // dS (unscaled)
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const float pr = fast_exp2(sA[e] * p.scale_log2 - lse4[e >> 2][e & 3]);
                         pA[e] = pr;
-                        if (DO_DK) sA[e] = pr * (dpA[e] - dl4[e >> 2][e & 3]);
+                        if (DO_DK) sA[e] = pr * dpA[e];
                     }
                 }
                 if (DO_DV) {
@@ -1186,7 +1192,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs 
         if (!(p.causal && qsub + 31 < key0)) {                    // (else: these 32 queries all precede this wave's keys — wave-uniform)
             f32x16 sA, dpA;                                       // [q rows (regs), key cols (lane)]
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { sA[e] = 0.f; dpA[e] = 0.f; }
+            for (int e = 0; e < 16; ++e) sA[e] = 0.f;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                      // dP starts from -delta (stored negated by the dQ kernel), read straight into the accumulator
+                const f32x4 nd = *reinterpret_cast<const f32x4*>(sL + 64 + 8 * g4 + 4 * h);
+                dpA[4 * g4] = nd[0]; dpA[4 * g4 + 1] = nd[1]; dpA[4 * g4 + 2] = nd[2]; dpA[4 * g4 + 3] = nd[3];
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, r, s, h), kf[s], sA, 0, 0, 0);
@@ -1198,7 +1209,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs 
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g4 + 4 * h);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + 8 * g4 + 4 * h);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int e = 4 * g4 + j;
@@ -1206,20 +1216,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_fused_kernel(AttnBwdArgs 
                         const bool ok = key_ok && q < T && (!p.causal || key <= q);
                         const float pr = ok ? fast_exp2(sA[e] * p.scale_log2 - l4[j]) : 0.f;
                         pA[e] = pr;
-                        sA[e] = pr * (dpA[e] - d4[j]);           // dS (unscaled)
+                        sA[e] = pr * dpA[e];                     // dS (unscaled)
                     }
                 }
             } else {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 8 * g4 + 4 * h);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sL + 64 + 8 * g4 + 4 * h);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int e = 4 * g4 + j;
                         const float pr = fast_exp2(sA[e] * p.scale_log2 - l4[j]);
                         pA[e] = pr;
-                        sA[e] = pr * (dpA[e] - d4[j]);
+                        sA[e] = pr * dpA[e];
                     }
                 }
             }
