@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r06
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p_step /tmp/p_step8 /tmp/p_c3 /tmp/p_c4 /tmp/p_c5 /tmp/p_sq_a /tmp/p_sq_b /tmp/p_f /tmp/p_w /tmp/p_lora   # (a box may be handed out twice: stale runs would make the globs below ambiguous)
 B="--no-cpu-baseline --no-secondary --no-vendor-gemm --no-batch8-reference"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_step -- python3 $R/bench.py --steps 4 --warmup 2 $B > $O/prof_step.log 2>&1
 cp /tmp/p_step/*/*kernel_stats.csv $R/profiles/r06_bench_kernel_stats.csv
