@@ -104,7 +104,47 @@ def _patch_stamp_reshot(t):
     return t.replace(a, "const bf16_t* g0 = p.res + (size_t)(wr * 128 + fr) * p.ldres + wc * 64 + fq * 8;")
 
 
-PATCHES = {"stamp_reshot": _patch_stamp_reshot, "stamp_nostore": _patch_stamp_nostore, "githead": _patch_githead, "nostore": _patch_nostore, "lateprefetch": _patch_lateprefetch, "tilestamp": _patch_tilestamp}
+def _patch_swiglu_il(t):
+    """probe (round 6): the SwiGLU-forward epilogue writes the SAVED gate / up pair-interleaved ([M][ff][2] = the tile's natural column order) through the wave's
+    LDS slab as whole 128-byte lines; the activation as before.  The [gate | up] consumers do not know this layout: timing of the gate|up launch only."""
+    a = """            bf16_t* gp = g0 + (size_t)i * 16 * eldc;
+            *reinterpret_cast<u32x4*>(gp) = u32x4{gq[0][0], gq[0][1], gq[1][0], gq[1][1]};
+            *reinterpret_cast<u32x4*>(gp + ff) = u32x4{uq[0][0], uq[0][1], uq[1][0], uq[1][1]};
+            *reinterpret_cast<u32x4*>(a0 + (size_t)i * 16 * p.ldres) = u32x4{aq[0][0], aq[0][1], aq[1][0], aq[1][1]};
+        }"""
+    assert t.count(a) == 1
+    b = """            (void)g0; (void)ff;
+            *reinterpret_cast<u32x4*>(a0 + (size_t)i * 16 * p.ldres) = u32x4{aq[0][0], aq[0][1], aq[1][0], aq[1][1]};
+            if (i & 1) {
+                bf16_t* cil = reinterpret_cast<bf16_t*>(eC) + (size_t)(em0 + wr * 128 + epi_row) * eldc + en0 + wc * 64 + epi_ch * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(epi_slab + (k * 8 + epi_row) * 128 + ((epi_ch ^ epi_row) << 4));
+                    *reinterpret_cast<u32x4*>(cil + (size_t)((i >> 1) * 32 + k * 8) * eldc) = d;
+                }
+            }
+        }"""
+    t = t.replace(a, b)
+    # the interleaved (g, u) pairs into the slab BEFORE the lane swaps of the regrouped form: the lane's 4 gate + 4 up columns of block jj = one 16-byte chunk
+    a2 = """#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                regroup_rows(gq[0][w], gq[1][w]);
+                regroup_rows(uq[0][w], uq[1][w]);
+                regroup_rows(aq[0][w], aq[1][w]);
+            }"""
+    assert t.count(a2) == 1
+    b2 = """#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const u32x4 il = u32x4{__builtin_amdgcn_perm(uq[jj][0], gq[jj][0], 0x05040100u), __builtin_amdgcn_perm(uq[jj][0], gq[jj][0], 0x07060302u),
+                                       __builtin_amdgcn_perm(uq[jj][1], gq[jj][1], 0x05040100u), __builtin_amdgcn_perm(uq[jj][1], gq[jj][1], 0x07060302u)};
+                *reinterpret_cast<u32x4*>(epi_slab + ((i & 1) * 16 + fr) * 128 + (((4 * jj + fq) ^ (fr & 7)) << 4)) = il;
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) regroup_rows(aq[0][w], aq[1][w]);"""
+    return t.replace(a2, b2)
+
+
+PATCHES = {"swiglu_il": _patch_swiglu_il, "stamp_reshot": _patch_stamp_reshot, "stamp_nostore": _patch_stamp_nostore, "githead": _patch_githead, "nostore": _patch_nostore, "lateprefetch": _patch_lateprefetch, "tilestamp": _patch_tilestamp}
 
 
 def main():
