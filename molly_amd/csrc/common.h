@@ -60,7 +60,10 @@ template <typename T> __device__ __forceinline__ void st_stream(void* p, T v) {
 // bit for bit): 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division — the division is ten
 // vector instructions, and the fused epilogues (gate|up forward, down-projection dgrad) are bound by their vector arithmetic: 14 us
 // of a 73 us tile in the dgrad (round 4).  The result is rounded to bf16 right after; against the fp32 reference nothing moves.
-__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+#ifndef MOLLY_DIAG_CHEAP_SIGMOID
+#define MOLLY_DIAG_CHEAP_SIGMOID 0      // 1 (timing-only variant build): no transcendentals in the logistic — what do the fused SwiGLU epilogues pay for them?
+#endif
+__device__ __forceinline__ float sigmoid_fast(float x) { return MOLLY_DIAG_CHEAP_SIGMOID ? 0.5f + 0.25f * x : __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 // returns {d(gate) pair, d(up) pair}
 __device__ __forceinline__ u32x2 swiglu_bwd_pair(uint32_t g, uint32_t u, uint32_t d) {
     const float ga = bflo(g), gb = bfhi(g);
